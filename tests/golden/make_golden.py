@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under ``tests/golden/`` by RUNNING THE REFERENCE (``/root/reference``) on CPU.
+
+Run in the build container only (``python tests/golden/make_golden.py``); the GPU box has no reference and
+only reads the committed ``.npz`` files.  The reference's own source is never copied: it is imported from
+where it lies, after two import shims for wheels this image lacks:
+
+* ``torch_scatter.scatter(src, index, dim=0, out=, reduce='sum')`` -> ``out.scatter_add_`` (the only call shape
+  on the path: reference ``models/LSTEP.py:283-290,320-322``; plain scatter-add is its documented behaviour);
+* an empty ``tgb.linkproppred.dataset`` (only the TGB file loader uses it, ``utils/DataLoader.py:96``).
+
+Inputs are NOT stored: they are regenerated from seeds by ``lstep_amd.synth`` (numpy legacy RNG, bit-stable).
+Only call arguments that are cheap (ids, times) and the reference's outputs are written.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+REFERENCE = os.environ.get("LSTEP_REFERENCE", "/root/reference")
+
+from lstep_amd import synth  # noqa: E402
+from lstep_amd import protocol  # noqa: E402
+
+
+def import_reference():
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter(src, index, dim=0, out=None, reduce="sum"):
+        assert dim == 0 and out is not None and reduce == "sum"
+        return out.scatter_add_(0, index.view(-1, 1).expand_as(src), src)
+
+    def scatter_mean(*a, **k):
+        raise NotImplementedError("weighted_sum ablation is out of scope (SURVEY.md 8f-4)")
+
+    ts.scatter, ts.scatter_mean = scatter, scatter_mean
+    sys.modules["torch_scatter"] = ts
+    tgb = types.ModuleType("tgb")
+    lp = types.ModuleType("tgb.linkproppred")
+    ds = types.ModuleType("tgb.linkproppred.dataset")
+    ds.LinkPropPredDataset = type("LinkPropPredDataset", (), {})
+    sys.modules.update({"tgb": tgb, "tgb.linkproppred": lp, "tgb.linkproppred.dataset": ds})
+    sys.path.insert(0, REFERENCE)
+    from models.LSTEP import LSTEP
+    from models.modules import MergeLayer, TimeEncoder
+    from utils.DataLoader import Data
+    from utils.utils import get_neighbor_sampler
+
+    return LSTEP, MergeLayer, TimeEncoder, Data, get_neighbor_sampler
+
+
+LSTEP, MergeLayer, TimeEncoder, Data, get_neighbor_sampler = import_reference()
+
+
+def ref_sampler(g, upto=None):
+    sl = slice(0, upto)
+    data = Data(g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], np.zeros(len(g["src"][sl])))
+    return get_neighbor_sampler(data, sample_neighbor_strategy="recent", seed=None)
+
+
+def ref_model(node_raw, edge_raw, sampler, K, T, seed=3):
+    torch.manual_seed(0)
+    bb = LSTEP(node_raw_features=node_raw, edge_raw_features=edge_raw, neighbor_sampler=sampler,
+               full_neighbor_sampler=sampler, pe_dim=synth.PE_DIM, num_neighbors=K, time_feat_dim=synth.TIME_DIM,
+               num_fft_batches=T, device="cpu")
+    pred = MergeLayer(input_dim1=synth.FEAT_DIM, input_dim2=synth.FEAT_DIM, hidden_dim=synth.FEAT_DIM, output_dim=1)
+    model = torch.nn.Sequential(bb, pred)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(K, T, seed=seed).items()}
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model
+
+
+# ----------------------------------------------------------------------------------------------- G1 sampler
+SAMPLER_GRAPHS = {
+    "uniform": dict(num_nodes=48, num_edges=1500, seed=10),
+    "ties": dict(num_nodes=24, num_edges=1200, seed=11, time_span=12000.0, tie_quantum=50.0),
+    "epoch": dict(num_nodes=48, num_edges=1500, seed=12, time_span=1e5, epoch_offset=1.6e9),
+}
+
+
+def sampler_queries(g, seed):
+    """Query (node, time) pairs that hit every edge case of `find_neighbors_before` (utils/utils.py:129-146)."""
+    rng = np.random.RandomState(seed)
+    n = g["num_nodes"]
+    ids, ts = [], []
+    pick = rng.randint(0, len(g["ts"]), size=12)
+    for e in pick:  # time exactly equal to one of the node's own timestamps: strictly-earlier rule
+        ids.append(g["src"][e]); ts.append(g["ts"][e])
+        ids.append(g["dst"][e]); ts.append(g["ts"][e])
+    for _ in range(10):  # random node at random time
+        ids.append(rng.randint(1, n + 1)); ts.append(rng.uniform(g["ts"][0], g["ts"][-1]))
+    ids += [0, 0, 1, 2, 3, n, n]
+    ts += [g["ts"][-1] + 1.0, g["ts"][0], g["ts"][0], g["ts"][0] - 5.0, g["ts"][-1] + 1e6, g["ts"][-1] + 1.0, np.nextafter(g["ts"][5], np.inf)]
+    return np.asarray(ids, dtype=np.int64), np.asarray(ts, dtype=np.float64)
+
+
+def gen_sampler():
+    out = {}
+    for name, kw in SAMPLER_GRAPHS.items():
+        g = synth.make_temporal_graph(**kw)
+        s = ref_sampler(g)
+        ids, ts = sampler_queries(g, seed=100 + kw["seed"])
+        out[f"{name}/ids"], out[f"{name}/ts"] = ids, ts
+        for k in (1, 5, 20, 32, 8, 2000):
+            nbr, eid, nt = s.get_historical_neighbors(ids, ts, k)
+            assert nbr.dtype == np.int64 and nt.dtype == np.float32
+            if k == 2000:  # right-aligned rows: store the last 192 columns plus the non-zero count of the rest (0 here)
+                keep = 192
+                out[f"{name}/k{k}/head_nnz"] = np.asarray([(nbr[:, : k - keep] != 0).sum()], dtype=np.int64)
+                out[f"{name}/k{k}/nbr_tail"], out[f"{name}/k{k}/eid_tail"], out[f"{name}/k{k}/nt_tail"] = nbr[:, -keep:], eid[:, -keep:], nt[:, -keep:]
+                out[f"{name}/k{k}/nbr_sum"] = nbr.sum(1)
+                out[f"{name}/k{k}/eid_sum"] = eid.sum(1)
+            else:
+                out[f"{name}/k{k}/nbr"], out[f"{name}/k{k}/eid"], out[f"{name}/k{k}/nt"] = nbr, eid, nt
+        # length mismatch: zip() truncates to the shorter of (ids, times) -- utils/utils.py:160-169
+        for tag, (a, b) in {"more_ids": (ids, ts[:9]), "more_ts": (ids[:9], ts)}.items():
+            nbr, eid, nt = s.get_historical_neighbors(a, b, 5)
+            out[f"{name}/{tag}/nbr"], out[f"{name}/{tag}/eid"], out[f"{name}/{tag}/nt"] = nbr, eid, nt
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
+    print("sampler.npz", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------- G2 time encoder
+def gen_time_encoder():
+    dt = np.asarray([0.0, 1e-3, 0.5, 1.0, 3.14159, 17.0, 1e2, 1234.5, 1e4, 86400.0, 1e6, 3.3e7, 1e9, 1.6e9, -1.0, -250.0],
+                    dtype=np.float32)
+    rng = np.random.RandomState(7)
+    dt = np.concatenate([dt, rng.uniform(0, 2e4, size=48).astype(np.float32), (10 ** rng.uniform(-3, 9, size=64)).astype(np.float32)])
+    enc = TimeEncoder(synth.TIME_DIM, parameter_requires_grad=False)
+    with torch.no_grad():
+        y = enc(torch.from_numpy(dt).unsqueeze(0)).squeeze(0).numpy()
+    np.savez_compressed(os.path.join(HERE, "time_encoder.npz"), dt=dt, enc=y,
+                        w=enc.w.weight.detach().numpy().reshape(-1))
+    print("time_encoder.npz", y.shape)
+
+
+# ----------------------------------------------------------------------------------------------- G3 methods
+METHOD_GRAPH = dict(num_nodes=64, num_edges=2000, seed=20)
+METHOD_K, METHOD_T = 5, 6
+
+
+def live_pe(model, g, pe0, K):
+    """A PE table whose padding row 0 is non-zero: one update_pe on an early batch (LSTEP.py:317,339)."""
+    pe = torch.from_numpy(pe0.copy())
+    sl = slice(40, 56)
+    bn = protocol.unique_batch_nodes(g["src"][sl], g["dst"][sl])
+    with torch.no_grad():
+        model[0].update_pe(pe, bn, g["eid"][sl], g["src"][sl], g["dst"][sl], g["ts"][sl], g["ts"][sl].max(), num_neighbors=K)
+    return pe
+
+
+def gen_methods():
+    g = synth.make_temporal_graph(**METHOD_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=21)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=22)
+    sampler = ref_sampler(g)
+    out = {}
+    for K in (METHOD_K, 20):
+        model = ref_model(node_raw, edge_raw, sampler, K, METHOD_T)
+        bb = model[0]
+        pe = live_pe(model, g, pe0, K)
+        out[f"K{K}/pe_live"] = pe.numpy().copy()
+        assert np.abs(pe[0].numpy()).max() > 0, "padding row must be live for this fixture"
+        for tag, sl in {"mid": slice(1200, 1216), "early": slice(3, 19)}.items():
+            src, dst, t = g["src"][sl], g["dst"][sl], g["ts"][sl]
+            with torch.no_grad():
+                for G in (8, 2000):
+                    out[f"K{K}/{tag}/agg_G{G}"] = bb.aggregated_node_embeddings(src, t, K, G).numpy()
+                out[f"K{K}/{tag}/cpe"] = bb.compute_neighborhood_pe(pe, dst, t, K).numpy()
+                out[f"K{K}/{tag}/out_src"] = bb.combining_pe_raw_feat(pe, src, t, K, 2000).numpy()
+                out[f"K{K}/{tag}/out_dst"] = bb.combining_pe_raw_feat(pe, dst, t, K, 8).numpy()
+        # update_pe: U > B (mid batch, 16 edges over 64 nodes) -- zip-truncation leaves rows >= B as padding
+        sl = slice(1200, 1216)
+        src, dst, t, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+        bn = protocol.unique_batch_nodes(src, dst)
+        assert len(bn) > len(src)
+        pe_in = pe.clone()
+        with torch.no_grad():
+            res = bb.update_pe(pe_in, bn, eid, src, dst, t, t.max(), num_neighbors=K)
+        assert res is pe_in
+        out[f"K{K}/update_UgtB/pe_out"] = pe_in.numpy().copy()
+        # update_pe: U < B (48 edges among the 12 lowest-id endpoints of a late window)
+        idx = np.nonzero((g["src"] <= 12) & (g["dst"] <= 12))[0]
+        idx = idx[idx > 600][:24]
+        src, dst, t, eid = g["src"][idx], g["dst"][idx], g["ts"][idx], g["eid"][idx]
+        bn = protocol.unique_batch_nodes(src, dst)
+        assert len(bn) < len(src), (len(bn), len(src))
+        out[f"K{K}/update_UltB/edge_pos"] = idx.astype(np.int64)
+        pe_in = pe.clone()
+        with torch.no_grad():
+            bb.update_pe(pe_in, bn, eid, src, dst, t, t.max(), num_neighbors=K)
+        out[f"K{K}/update_UltB/pe_out"] = pe_in.numpy().copy()
+        # update_pe from a zero-padding-row table at the very start of the stream (all-padding neighbourhoods)
+        sl = slice(0, 16)
+        src, dst, t, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+        bn = protocol.unique_batch_nodes(src, dst)
+        pe_in = torch.from_numpy(pe0.copy())
+        with torch.no_grad():
+            bb.update_pe(pe_in, bn, eid, src, dst, t, t.max(), num_neighbors=K)
+        out[f"K{K}/update_first/pe_out"] = pe_in.numpy().copy()
+
+    # fourier_transform_pe: masked (stored < T), unmasked (stored == T), eval-style batch_idx != stored length
+    model = ref_model(node_raw, edge_raw, sampler, METHOD_K, METHOD_T)
+    bb = model[0]
+    rng = np.random.RandomState(23)
+    hist_full = (0.1 * rng.standard_normal((g["num_nodes"] + 1, METHOD_T, synth.PE_DIM))).astype(np.float32)
+    ids = np.asarray([1, 2, 5, 9, 17, 33, 64, 0], dtype=np.int64)
+    out["fft/ids"] = ids
+    with torch.no_grad():
+        for stored, bidx in ((3, 3), (METHOD_T, 9), (4, 2), (2, 0), (1, 1), (METHOD_T, 0)):
+            h = torch.from_numpy(hist_full[:, :stored, :].copy())
+            out[f"fft/stored{stored}_b{bidx}"] = bb.fourier_transform_pe(ids, h, bidx).numpy()
+    np.savez_compressed(os.path.join(HERE, "methods.npz"), **out)
+    print("methods.npz", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------- G4-G6 traces
+TRACE_GRAPH = dict(num_nodes=64, num_edges=2000, seed=30)
+TRACE_K, TRACE_T, TRACE_B, TRACE_G = 5, 4, 16, 2000
+TRACE_START = 640  # start mid-stream so neighbourhoods are non-trivial
+GRAD_ROW_STRIDE = 4
+TRACE_BATCHES = 7  # > T + 1 so the history trim (train:224-225) is exercised
+
+
+def trace_batches(g):
+    bs = []
+    for b in range(TRACE_BATCHES):
+        sl = slice(TRACE_START + b * TRACE_B, TRACE_START + (b + 1) * TRACE_B)
+        neg = synth.make_negatives(g["num_nodes"], TRACE_B, seed=500 + b)
+        bs.append((g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], neg))
+    return bs
+
+
+def param_digest(model):
+    d = {}
+    for k, v in model.state_dict().items():
+        a = v.detach().numpy()
+        if np.iscomplexobj(a):
+            a = np.stack([a.real, a.imag], -1)
+        a = a.astype(np.float64).reshape(-1)
+        d[k] = np.asarray([a.sum(), np.abs(a).sum(), (a * np.arange(1, a.size + 1) / a.size).sum()])
+    return d
+
+
+def gen_traces():
+    g = synth.make_temporal_graph(**TRACE_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=31)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=32)
+    sampler = ref_sampler(g)
+    out = {}
+
+    # ---- G5: training trace (also yields G4: gradients of the first optimised batch)
+    model = ref_model(node_raw, edge_raw, sampler, TRACE_K, TRACE_T)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    state = protocol.ProtocolState(history=torch.zeros(g["num_nodes"] + 1, 0, synth.PE_DIM), initial_pe=torch.from_numpy(pe0.copy()))
+    for b, (src, dst, t, eid, neg) in enumerate(trace_batches(g)):
+        res = protocol.train_iteration(model[0], model[1], opt, state, b, src, dst, t, eid, neg,
+                                       TRACE_K, TRACE_G, TRACE_T)
+        out[f"train/b{b}/snapshot"] = state.history[:, -1, :].numpy().copy()
+        if res is not None:
+            out[f"train/b{b}/losses"] = np.asarray([res["lp_loss"], res["pe_loss"], res["loss"]])
+            out[f"train/b{b}/predicts"] = res["predicts"]
+        if b == 1:
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    out[f"grads/{k}/none"] = np.zeros(0)
+                else:
+                    a = p.grad.detach().numpy()
+                    a = np.stack([a.real, a.imag], -1) if np.iscomplexobj(a) else a.copy()
+                    out[f"grads/{k}/digest"] = np.asarray([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+                    # big matrices: every 4th row is stored (fixture size); the digest covers the rest
+                    out[f"grads/{k}"] = a[::GRAD_ROW_STRIDE] if a.size > 20000 else a
+        for k, v in param_digest(model).items():
+            out[f"train/b{b}/digest/{k}"] = v
+    out["train/final_history"] = state.history.numpy().copy()
+
+    # ---- G6: evaluation trace continuing from the trained history (evaluate_model_utils.py:37)
+    model.eval()
+    ev = protocol.ProtocolState(history=state.history.clone())
+    with torch.no_grad():
+        for b in range(3):
+            s0 = TRACE_START + (TRACE_BATCHES + b) * TRACE_B
+            sl = slice(s0, s0 + TRACE_B)
+            neg_dst = synth.make_negatives(g["num_nodes"], TRACE_B, seed=700 + b)
+            neg_src = synth.make_negatives(g["num_nodes"], TRACE_B, seed=800 + b)
+            res = protocol.eval_iteration(model[0], model[1], ev, b, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl],
+                                          neg_src, neg_dst, TRACE_K, TRACE_G, TRACE_T)
+            out[f"eval/b{b}/loss"] = np.asarray([res["loss"]])
+            out[f"eval/b{b}/predicts"] = res["predicts"]
+            out[f"eval/b{b}/snapshot"] = ev.history[:, -1, :].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "traces.npz"), **out)
+    print("traces.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    which = sys.argv[1:] or ["sampler", "time", "methods", "traces"]
+    if "sampler" in which:
+        gen_sampler()
+    if "time" in which:
+        gen_time_encoder()
+    if "methods" in which:
+        gen_methods()
+    if "traces" in which:
+        gen_traces()

@@ -1,0 +1,71 @@
+"""Shared builders for the parity tests: the same seeded inputs tests/golden/make_golden.py fed to the reference."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from lstep_amd import synth  # noqa: E402
+
+# mirrors of the constants in tests/golden/make_golden.py (kept literal so the GPU box needs no reference)
+SAMPLER_GRAPHS = {
+    "uniform": dict(num_nodes=48, num_edges=1500, seed=10),
+    "ties": dict(num_nodes=24, num_edges=1200, seed=11, time_span=12000.0, tie_quantum=50.0),
+    "epoch": dict(num_nodes=48, num_edges=1500, seed=12, time_span=1e5, epoch_offset=1.6e9),
+}
+METHOD_GRAPH = dict(num_nodes=64, num_edges=2000, seed=20)
+METHOD_K, METHOD_T = 5, 6
+TRACE_GRAPH = dict(num_nodes=64, num_edges=2000, seed=30)
+TRACE_K, TRACE_T, TRACE_B, TRACE_G = 5, 4, 16, 2000
+TRACE_START, TRACE_BATCHES, GRAD_ROW_STRIDE = 640, 7, 4
+
+
+def method_inputs():
+    g = synth.make_temporal_graph(**METHOD_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=21)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=22)
+    return g, node_raw, edge_raw, pe0
+
+
+def trace_inputs():
+    g = synth.make_temporal_graph(**TRACE_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=31)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=32)
+    return g, node_raw, edge_raw, pe0
+
+
+def trace_batches(g):
+    out = []
+    for b in range(TRACE_BATCHES):
+        sl = slice(TRACE_START + b * TRACE_B, TRACE_START + (b + 1) * TRACE_B)
+        out.append((g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], synth.make_negatives(g["num_nodes"], TRACE_B, seed=500 + b)))
+    return out
+
+
+def eval_batches(g):
+    out = []
+    for b in range(3):
+        s0 = TRACE_START + (TRACE_BATCHES + b) * TRACE_B
+        sl = slice(s0, s0 + TRACE_B)
+        out.append((g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl],
+                    synth.make_negatives(g["num_nodes"], TRACE_B, seed=800 + b), synth.make_negatives(g["num_nodes"], TRACE_B, seed=700 + b)))
+    return out
+
+
+def param_digest(model):
+    d = {}
+    for k, v in model.state_dict().items():
+        a = v.detach().cpu().numpy()
+        if np.iscomplexobj(a):
+            a = np.stack([a.real, a.imag], -1)
+        a = a.astype(np.float64).reshape(-1)
+        d[k] = np.asarray([a.sum(), np.abs(a).sum(), (a * np.arange(1, a.size + 1) / a.size).sum()])
+    return d
+
+
+def state_dict_tensors(K, T, seed=3, device="cpu"):
+    return {k: torch.from_numpy(v).to(device) for k, v in synth.make_state_dict(K, T, seed=seed).items()}
