@@ -1,0 +1,137 @@
+/*
+ * lstep_hip.h -- C ABI of the MI355X (gfx950) implementation of the L-STEP hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.  Every pointer marked
+ * "device" must be a HIP device pointer valid on the current device; `stream` is a hipStream_t passed
+ * as void* (NULL = default stream).  All calls are asynchronous on `stream` and allocate nothing.
+ *
+ * The reference (kthrn22/L-STEP) is 100 % Python and has no FFI of its own; each entry point below
+ * replaces the native work hidden behind the cited reference lines (paths relative to the reference
+ * repository root).  The Python host layer that mirrors the reference classes on top of this ABI is
+ * l-step_amd/{sampler,model,engine}.py; INTEGRATION.md shows the ctypes stub a reference maintainer adds.
+ *
+ * Conventions
+ *   N+1 rows in node tables (row 0 = padding), E+1 rows in the edge table (row 0 = padding).
+ *   F = node/edge feature width, P = positional-encoding width, D = time-encoding width;
+ *   F, P multiples of 4 and <= 256, D <= 128 (the reference uses F = P = 172, D = 100).
+ *   Feature rows are dense fp32, row-major, 16-byte aligned (row stride F*4 bytes).
+ *   Return value: LSTEP_OK or a negative error code; lstep_last_error() gives the message (thread local).
+ */
+#ifndef LSTEP_HIP_H
+#define LSTEP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSTEP_ABI_VERSION 1
+
+#define LSTEP_OK 0
+#define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
+#define LSTEP_EHIP (-2)   /* a HIP runtime call or kernel launch failed */
+
+/* Time-sorted undirected temporal adjacency in CSR form, device resident.
+ * Content = reference utils/utils.py:292-299 (every edge appended to both endpoints) after the stable
+ * per-node sort by timestamp of utils/utils.py:99; row r owns entries [indptr[r], indptr[r+1]). */
+typedef struct lstep_csr {
+    const int64_t* indptr; /* device, [num_rows + 1] */
+    const int32_t* nbr;    /* device, [nnz] neighbour node id */
+    const int32_t* eid;    /* device, [nnz] edge id */
+    const double* ts;      /* device, [nnz] interaction time, non-decreasing inside a row */
+    int64_t num_rows;      /* max node id + 1 */
+    int64_t nnz;           /* 2 * number of edges */
+} lstep_csr_t;
+
+/* Branch selection for lstep_gather_aggregate_fwd/bwd */
+#define LSTEP_BRANCH_EDGE_NODE 1u /* A + N: models/LSTEP.py:147-158,177-211 */
+#define LSTEP_BRANCH_PE 2u        /* C:     models/LSTEP.py:223-238 */
+
+int lstep_abi_version(void);
+const char* lstep_last_error(void);
+
+/* S -- NeighborSampler.get_historical_neighbors, 'recent' strategy (utils/utils.py:148-213, search :129-146).
+ * Row r < min(num_ids, num_times): the last min(c, K) of the c interactions of node_ids[r] strictly earlier
+ * than times[r], right-aligned in a zero row; rows >= min(num_ids, num_times) stay zero (zip truncation, :169).
+ * out_nbr/out_eid int64 [num_ids, K], out_nt float32 [num_ids, K] (float64 -> float32 cast of :166),
+ * out_count int32 [num_ids] = c (may be NULL).  Bit-exact with the reference. */
+int lstep_sample_recent(const lstep_csr_t* csr, const int64_t* node_ids, int64_t num_ids, const double* times,
+                        int64_t num_times, int32_t num_neighbors, int64_t* out_nbr, int64_t* out_eid, float* out_nt,
+                        int32_t* out_count, void* stream);
+
+/* T -- TimeEncoder.forward (models/modules.py:27-39): out[i, d] = cos(dt[i] * w[d] + b[d]); rows with
+ * zero_mask[i] != 0 are written as 0 (the "neighbour id == 0" masking of models/LSTEP.py:154,231,316).
+ * zero_mask may be NULL.  dt float32 [n], w/b float32 [D], out float32 [n, D]. */
+int lstep_time_encode(const float* dt, const uint8_t* zero_mask, int64_t n, const float* w, const float* b,
+                      int32_t time_dim, float* out, void* stream);
+
+/* A + N + C gather stage of combining_pe_raw_feat (models/LSTEP.py:147-158, 177-211, 223-238), fused:
+ * one temporal search per row serves the K-neighbour and the time_gap-neighbour lookups.
+ *   out_edge  [B, D+F]  sum_j a[j] * cat[time_feat_j, edge_raw[eid_j]] over the K right-aligned slots
+ *                       (= edge_agg applied BEFORE edge_mlp_1; the two are linear)
+ *   out_node  [B, F]    softmax-mask mean of node_raw over the time_gap neighbours, /time_gap, + node_raw[id]
+ *   out_pe    [B, P+D]  sum_j cat[pe[nbr_j], time_feat_j] over the K slots (padding slots read pe[0])
+ *   out_self  [B, P]    pe[id]
+ *   out_count [B]       c = interactions strictly earlier than times[b] (saved for the backward)
+ * edge_agg_w float32 [K]; pe may be NULL when LSTEP_BRANCH_PE is not requested. */
+int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
+                               int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                               int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids, const double* times,
+                               int64_t batch, int32_t num_neighbors, int32_t time_gap, uint32_t branches,
+                               float* out_edge, float* out_node, float* out_pe, float* out_self, int32_t* out_count,
+                               void* stream);
+
+/* Backward of the gather stage.
+ *   grad_edge [B, D+F], grad_pe_agg [B, P+D], grad_self [B, P]  (any may be NULL = zero)
+ *   out_slot_dot [B, K]: <grad_edge[b], cat[time_feat, edge_row] of slot j>; its column sum is d(edge_agg.weight).
+ *   PE gradient, accumulated with float atomics (buffer must be zeroed by the caller):
+ *     slot_of == NULL : grad_pe_rows is dense [num_rows, P]; row nbr_j += grad_pe_agg[b, :P] for valid slots,
+ *                       row id_b += grad_self[b].  Padding slots (row 0) are NOT added here: the caller adds
+ *                       sum_b (K - min(c_b, K)) * grad_pe_agg[b, :P] to row 0 (one tiny reduction, no hot row).
+ *     slot_of != NULL : int32 [num_rows] map node id -> row of the compact gradient [U, P] or -1 (no gradient);
+ *                       grad_pe_rows is [U, P].  This is the training fast path: only the FFT-filtered rows of
+ *                       the spliced PE carry gradient (train_LSTEP_link_prediction.py:229-230). */
+int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* edge_raw, int32_t feat_dim, int32_t pe_dim,
+                               const float* time_w, const float* time_b, int32_t time_dim, const int64_t* node_ids,
+                               const double* times, const int32_t* count, int64_t batch, int32_t num_neighbors,
+                               const float* grad_edge, const float* grad_pe_agg, const float* grad_self,
+                               const int32_t* slot_of, float* out_slot_dot, float* grad_pe_rows, void* stream);
+
+/* F -- the linear core of fourier_transform_pe (models/LSTEP.py:104-137).  fft -> mask -> filter -> mask ->
+ * ifft -> mask -> real part -> fft_agg is linear in the history, so for fixed weights it is a [T, P] real
+ * coefficient table coef (built by the host layer from fft_filter / fft_agg / batch_idx):
+ *   out[u, p] = sum_{s < t_len} coef[s, p] * hist[node_ids[u], s, p].
+ * hist is addressed as base + node * node_stride + ((s + time_rot) % time_slots) * time_stride (element
+ * strides), so both the reference's [N+1, t, P] tensor and a [T, N+1, P] device ring are accepted. */
+int lstep_history_filter_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots,
+                             int32_t time_rot, int32_t t_len, int32_t pe_dim, const int64_t* node_ids, int64_t num_ids,
+                             const float* coef, float* out, void* stream);
+
+/* d(coef)[s, p] = sum_u grad_out[u, p] * hist[node_ids[u], s, p], written as per-chunk partial sums
+ * out_partial [num_chunks, t_len, P] with num_chunks = lstep_history_filter_bwd_chunks(num_ids); the caller
+ * reduces over dim 0 (deterministic, no atomics). */
+int64_t lstep_history_filter_bwd_chunks(int64_t num_ids);
+int lstep_history_filter_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots,
+                             int32_t time_rot, int32_t t_len, int32_t pe_dim, const int64_t* node_ids, int64_t num_ids,
+                             const float* grad_out, float* out_partial, void* stream);
+
+/* U1/U2 message accumulation of update_pe (models/LSTEP.py:282-290, 319-322) without the dense [N+1, P+D]
+ * scatter target: entries are pre-grouped by destination; segment s owns entries [seg_begin[s], seg_end[s])
+ * (pass ptr and ptr + 1 of one offsets array for back-to-back segments; empty segments give zero rows).
+ *   out[s, :P]    = sum_e pe[ent_row[e]]
+ *   out[s, P:P+D] = sum_e (ent_valid[e] ? cos(ent_dt[e] * w + b) : 0)
+ * ent_valid may be NULL (all valid).  Summation order inside a segment is the entry order (deterministic). */
+int lstep_segment_pe_time_sum(const float* pe, int32_t pe_dim, const float* time_w, const float* time_b,
+                              int32_t time_dim, const int64_t* seg_begin, const int64_t* seg_end, int64_t num_segments,
+                              const int32_t* ent_row, const float* ent_dt, const uint8_t* ent_valid, float* out,
+                              void* stream);
+
+/* In-place row write pe[ids[i], :] = rows[i, :] (models/LSTEP.py:303,339). ids must be unique. */
+int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* rows,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSTEP_HIP_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of ``liblstep_hip.so`` (C ABI declared in ``include/lstep_hip.h``).
+
+The library is built in-tree by :func:`build_library` (plain ``hipcc --offload-arch=gfx950``; no torch headers,
+no JIT cache) so the ``.so`` travels with the repository snapshot to the GPU box.  There is NO fallback: if the
+library cannot be loaded every op raises :class:`LstepNativeError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
+LIB_PATH = os.path.join(CSRC, "liblstep_hip.so")
+SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip"]
+HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(INCLUDE, "lstep_hip.h")]
+
+LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
+BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
+
+
+class LstepNativeError(RuntimeError):
+    pass
+
+
+class CsrStruct(C.Structure):
+    """``lstep_csr_t``"""
+    _fields_ = [("indptr", C.c_void_p), ("nbr", C.c_void_p), ("eid", C.c_void_p), ("ts", C.c_void_p),
+                ("num_rows", C.c_int64), ("nnz", C.c_int64)]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``csrc/liblstep_hip.so`` (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise LstepNativeError("hipcc not found: cannot build liblstep_hip.so")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise LstepNativeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    global _LIB
+    _LIB = None
+    return LIB_PATH
+
+
+_LIB = None
+
+# name -> (restype, argtypes); must list every symbol of include/lstep_hip.h (tests/test_abi.py checks this)
+_P, _I32, _I64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+SIGNATURES = {
+    "lstep_abi_version": (C.c_int, []),
+    "lstep_last_error": (C.c_char_p, []),
+    "lstep_sample_recent": (C.c_int, [C.POINTER(CsrStruct), _P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P]),
+    "lstep_time_encode": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P, _P]),
+    "lstep_gather_aggregate_fwd": (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32,
+                                             _I32, _U32, _P, _P, _P, _P, _P, _P]),
+    "lstep_gather_aggregate_bwd": (C.c_int, [C.POINTER(CsrStruct), _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32, _P, _P, _P,
+                                             _P, _P, _P, _P]),
+    "lstep_history_filter_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
+    "lstep_history_filter_bwd_chunks": (_I64, [_I64]),
+    "lstep_history_filter_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
+    "lstep_segment_pe_time_sum": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
+}
+
+
+def load_library():
+    """Load (never build) the shared library and attach the prototypes.  Raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise LstepNativeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the L-STEP HIP ops)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.lstep_abi_version() != 1:
+        raise LstepNativeError("liblstep_hip.so ABI version mismatch; rebuild")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int):
+    """Map the C error convention onto the reference's Python exceptions (AssertionError for K <= 0)."""
+    if rc == LSTEP_OK:
+        return
+    msg = load_library().lstep_last_error().decode("utf-8", "replace")
+    if rc == LSTEP_EINVAL and "greater than 0" in msg:
+        raise AssertionError(msg)  # reference: utils/utils.py:156
+    if rc == LSTEP_EINVAL:
+        raise ValueError(msg)
+    raise LstepNativeError(msg)
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, or NULL."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,355 @@
+// A + N + C gather stage of combining_pe_raw_feat, forward and backward.
+//   reference: models/LSTEP.py:147-158 (edge rows + time features), :177-211 (node rows over time_gap neighbours),
+//              :223-238 (PE rows + time features); sampler semantics utils/utils.py:129-146,199-208.
+//
+// Mapping: one 64-lane wave per destination row b.  A feature row is F floats = F/4 float4 (172 -> 43 lanes
+// active, one dwordx4 per lane, the row is one contiguous 688-byte burst); several rows are kept in flight per
+// wave.  The neighbour slice of the CSR is read once, 64 entries per wave-instruction, and broadcast lane ->
+// scalar with v_readlane, so row addresses are scalar and the loads are base + lane*16.
+// HBM-bound: algorithmic bytes per row = 4F*(k + 1 + valid_v) + 4P*(k + 1) + index bytes.
+#include "lstep_common.h"
+
+namespace lstep {
+
+struct GatherParams {
+    lstep_csr_t csr;
+    const float* node_raw;
+    const float* edge_raw;
+    const float* pe;
+    int F, P, D;
+    const float* time_w;
+    const float* time_b;
+    const float* edge_agg_w;
+    const int64_t* node_ids;
+    const double* times;
+    int64_t batch;
+    int K, G;
+    float* out_edge;
+    float* out_node;
+    float* out_pe;
+    float* out_self;
+    int32_t* out_count;
+};
+
+constexpr int kRowsInFlight = 8;
+
+template <bool kEdgeNode, bool kPe>
+__global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherParams p) {
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (row >= p.batch) return;
+    const int F = p.F, P = p.P, D = p.D, K = p.K;
+    const bool fa = lane < (F >> 2);  // lane owns a float4 of a feature row
+    const bool pa = lane < (P >> 2);
+    const int64_t node = p.node_ids[row];
+    const double t = p.times[row];
+    int64_t lo = 0, cnt = 0;
+    const bool in_range = node >= 0 && node < p.csr.num_rows;
+    if (in_range) {
+        lo = p.csr.indptr[node];
+        cnt = wave_count_before(p.csr.ts, lo, p.csr.indptr[node + 1], t, lane);
+    }
+    const int k = (int)(cnt < K ? cnt : K);
+    const int npad = K - k;
+    const int64_t kfirst = lo + cnt - k;
+
+    const float w0 = lane < D ? p.time_w[lane] : 0.0f, b0 = lane < D ? p.time_b[lane] : 0.0f;
+    const float w1 = lane + kWave < D ? p.time_w[lane + kWave] : 0.0f, b1 = lane + kWave < D ? p.time_b[lane + kWave] : 0.0f;
+
+    float4 accE = make_float4(0.f, 0.f, 0.f, 0.f), accP = accE;
+    float xt0 = 0.f, xt1 = 0.f, pt0 = 0.f, pt1 = 0.f;
+
+    for (int c0 = 0; c0 < k; c0 += kWave) {
+        const int m = (k - c0) < kWave ? (k - c0) : kWave;
+        int nb = 0, ed = 0;
+        float dt = 0.f, aw = 0.f;
+        if (lane < m) {
+            const int64_t e = kfirst + c0 + lane;
+            nb = p.csr.nbr[e];
+            ed = p.csr.eid[e];
+            dt = delta_t(t, p.csr.ts[e]);
+            if (kEdgeNode) aw = p.edge_agg_w[npad + c0 + lane];
+        }
+        for (int j = 0; j < m; j += kRowsInFlight) {
+            float4 re[kRowsInFlight], rp[kRowsInFlight];
+            float wj[kRowsInFlight];
+#pragma unroll
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                const bool live = (j + u) < m;
+                const int jj = live ? (j + u) : (m - 1);
+                const int64_t ej = bcast_i32(ed, jj);
+                const int64_t nj = bcast_i32(nb, jj);
+                wj[u] = live ? bcast_f32(aw, jj) : 0.f;
+                re[u] = (kEdgeNode && fa && live) ? ld4(p.edge_raw + ej * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rp[u] = (kPe && pa && live) ? ld4(p.pe + nj * P + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                if (kEdgeNode) fma4(accE, wj[u], re[u]);
+                if (kPe) { accP.x += rp[u].x; accP.y += rp[u].y; accP.z += rp[u].z; accP.w += rp[u].w; }
+            }
+        }
+        // time features of the valid slots: cos(dt * w_d), zero where the neighbour id is 0 (LSTEP.py:154,231)
+        for (int j = 0; j < m; ++j) {
+            const int nj = bcast_i32(nb, j);
+            if (nj == 0) continue;
+            const float dj = bcast_f32(dt, j);
+            const float aj = bcast_f32(aw, j);
+            const float c0v = lane < D ? time_feat(dj, w0, b0) : 0.f;
+            const float c1v = lane + kWave < D ? time_feat(dj, w1, b1) : 0.f;
+            xt0 = fmaf(aj, c0v, xt0);
+            xt1 = fmaf(aj, c1v, xt1);
+            pt0 += c0v;
+            pt1 += c1v;
+        }
+    }
+    if (npad > 0) {  // padding slots gather row 0 of the edge table and of the PE table (pe[0] is live)
+        if (kEdgeNode) {
+            float s = 0.f;
+            for (int i = lane; i < npad; i += kWave) s += p.edge_agg_w[i];
+            s = wave_sum(s);
+            if (fa) fma4(accE, s, ld4(p.edge_raw + lane * 4));
+        }
+        if (kPe && pa) fma4(accP, (float)npad, ld4(p.pe + lane * 4));
+    }
+
+    if (kEdgeNode) {
+        float* oe = p.out_edge + row * (int64_t)(D + F);
+        if (lane < D) oe[lane] = xt0;
+        if (lane + kWave < D) oe[lane + kWave] = xt1;
+        if (fa) st4(oe + D + lane * 4, accE);
+
+        // node channel: the last v = min(cnt, G) interactions; score 1/valid on ids > 0, then mean over G slots
+        const int64_t v = cnt < p.G ? cnt : p.G;
+        const int64_t vfirst = lo + cnt - v;
+        float4 accN = make_float4(0.f, 0.f, 0.f, 0.f);
+        int valid = 0;
+        for (int64_t c0 = 0; c0 < v; c0 += kWave) {
+            const int m = (int)((v - c0) < kWave ? (v - c0) : kWave);
+            const int idx = lane < m ? p.csr.nbr[vfirst + c0 + lane] : 0;
+            valid += __popcll(__ballot(idx > 0));
+            for (int j = 0; j < m; j += kRowsInFlight) {
+                float4 rn[kRowsInFlight];
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) {
+                    const bool live = (j + u) < m;
+                    const int64_t nj = bcast_i32(idx, live ? (j + u) : (m - 1));
+                    rn[u] = (fa && live && nj > 0) ? ld4(p.node_raw + nj * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) {
+                    accN.x += rn[u].x; accN.y += rn[u].y; accN.z += rn[u].z; accN.w += rn[u].w;
+                }
+            }
+        }
+        if (fa) {
+            const float invG = 1.0f / (float)p.G;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid > 0) {
+                const float s = (1.0f / (float)valid) / (float)p.G;
+                r0 = make_float4(accN.x * s, accN.y * s, accN.z * s, accN.w * s);
+            } else {  // all slots padded: softmax is uniform 1/G over G copies of row 0, then /G again
+                const float4 z = ld4(p.node_raw + lane * 4);
+                r0 = make_float4(z.x * invG, z.y * invG, z.z * invG, z.w * invG);
+            }
+            float4 self = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in_range) self = ld4(p.node_raw + node * F + lane * 4);
+            st4(p.out_node + row * (int64_t)F + lane * 4, make_float4(r0.x + self.x, r0.y + self.y, r0.z + self.z, r0.w + self.w));
+        }
+    }
+    if (kPe) {
+        float* op = p.out_pe + row * (int64_t)(P + D);
+        if (pa) st4(op + lane * 4, accP);
+        if (lane < D) op[P + lane] = pt0;
+        if (lane + kWave < D) op[P + lane + kWave] = pt1;
+        if (pa) st4(p.out_self + row * (int64_t)P + lane * 4, in_range ? ld4(p.pe + node * P + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    if (p.out_count != nullptr && lane == 0) p.out_count[row] = (int32_t)cnt;
+}
+
+struct GatherBwdParams {
+    lstep_csr_t csr;
+    const float* edge_raw;
+    int F, P, D;
+    const float* time_w;
+    const float* time_b;
+    const int64_t* node_ids;
+    const double* times;
+    const int32_t* count;
+    int64_t batch;
+    int K;
+    const float* grad_edge;
+    const float* grad_pe_agg;
+    const float* grad_self;
+    const int32_t* slot_of;
+    float* out_slot_dot;
+    float* grad_pe_rows;
+};
+
+// atomically add a P-wide gradient row held as g[i] = elements lane + 64*i (contiguous dwords per wave-instruction)
+__device__ __forceinline__ void atomic_add_row(float* dst, const float g[4], int P, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * kWave;
+        if (c < P) atomicAdd(dst + c, g[i]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdParams p) {
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (row >= p.batch) return;
+    const int F = p.F, P = p.P, D = p.D, K = p.K;
+    const bool fa = lane < (F >> 2);
+    const int64_t node = p.node_ids[row];
+    const bool in_range = node >= 0 && node < p.csr.num_rows;
+    const double t = p.times[row];
+    const int64_t cnt = in_range ? p.count[row] : 0;
+    const int64_t lo = in_range ? p.csr.indptr[node] : 0;
+    const int k = (int)(cnt < K ? cnt : K);
+    const int npad = K - k;
+    const int64_t kfirst = lo + cnt - k;
+    const bool do_edge = p.grad_edge != nullptr && p.out_slot_dot != nullptr;
+    const bool do_pe = p.grad_pe_agg != nullptr && p.grad_pe_rows != nullptr;
+
+    float gt0 = 0.f, gt1 = 0.f, w0 = 0.f, b0 = 0.f, w1 = 0.f, b1 = 0.f;
+    float4 gE = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (do_edge) {
+        const float* ge = p.grad_edge + row * (int64_t)(D + F);
+        if (lane < D) { gt0 = ge[lane]; w0 = p.time_w[lane]; b0 = p.time_b[lane]; }
+        if (lane + kWave < D) { gt1 = ge[lane + kWave]; w1 = p.time_w[lane + kWave]; b1 = p.time_b[lane + kWave]; }
+        if (fa) gE = ld4(ge + D + lane * 4);
+    }
+    float gp[4] = {0.f, 0.f, 0.f, 0.f};
+    if (do_pe) {
+        const float* g = p.grad_pe_agg + row * (int64_t)(P + D);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + i * kWave < P) gp[i] = g[lane + i * kWave];
+    }
+
+    for (int c0 = 0; c0 < k; c0 += kWave) {
+        const int m = (k - c0) < kWave ? (k - c0) : kWave;
+        int nb = 0, ed = 0;
+        float dt = 0.f;
+        if (lane < m) {
+            const int64_t e = kfirst + c0 + lane;
+            nb = p.csr.nbr[e];
+            ed = p.csr.eid[e];
+            dt = delta_t(t, p.csr.ts[e]);
+        }
+        if (do_edge) {
+            float mine = 0.f;  // lane j keeps the dot product of slot c0 + j
+            for (int j = 0; j < m; j += 4) {
+                float4 re[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool live = (j + u) < m;
+                    const int64_t ej = bcast_i32(ed, live ? (j + u) : (m - 1));
+                    re[u] = (fa && live) ? ld4(p.edge_raw + ej * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if ((j + u) >= m) break;
+                    float part = dot4(gE, re[u]);
+                    if (bcast_i32(nb, j + u) != 0) {
+                        const float dj = bcast_f32(dt, j + u);
+                        if (lane < D) part = fmaf(gt0, time_feat(dj, w0, b0), part);
+                        if (lane + kWave < D) part = fmaf(gt1, time_feat(dj, w1, b1), part);
+                    }
+                    part = wave_sum(part);
+                    if (lane == j + u) mine = part;
+                }
+            }
+            if (lane < m) p.out_slot_dot[row * (int64_t)K + npad + c0 + lane] = mine;
+        }
+        if (do_pe) {
+            for (int j = 0; j < m; ++j) {
+                const int64_t nj = bcast_i32(nb, j);
+                if (p.slot_of != nullptr) {
+                    const int u = p.slot_of[nj];
+                    if (u >= 0) atomic_add_row(p.grad_pe_rows + (int64_t)u * P, gp, P, lane);
+                } else {
+                    atomic_add_row(p.grad_pe_rows + nj * P, gp, P, lane);
+                }
+            }
+        }
+    }
+    if (do_edge && npad > 0) {  // padding slots: time features are zero, edge row is row 0
+        float part = fa ? dot4(gE, ld4(p.edge_raw + lane * 4)) : 0.f;
+        part = wave_sum(part);
+        for (int s = lane; s < npad; s += kWave) p.out_slot_dot[row * (int64_t)K + s] = part;
+    }
+    if (p.grad_self != nullptr && p.grad_pe_rows != nullptr && in_range) {
+        float gs[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* g = p.grad_self + row * (int64_t)P;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + i * kWave < P) gs[i] = g[lane + i * kWave];
+        if (p.slot_of != nullptr) {
+            const int u = p.slot_of[node];
+            if (u >= 0) atomic_add_row(p.grad_pe_rows + (int64_t)u * P, gs, P, lane);
+        } else {
+            atomic_add_row(p.grad_pe_rows + node * P, gs, P, lane);
+        }
+    }
+}
+
+static int check_dims(const char* who, int F, int P, int D) {
+    if (F <= 0 || P <= 0 || D <= 0 || (F & 3) || (P & 3) || (D & 3) || F > 4 * kMaxRowVec || P > 4 * kMaxRowVec || D > kMaxTimeDim)
+        return set_error(LSTEP_EINVAL, "%s: unsupported widths F=%d P=%d D=%d (need multiples of 4, F,P<=256, D<=128)", who, F, P, D);
+    return LSTEP_OK;
+}
+
+}  // namespace lstep
+
+using namespace lstep;
+
+extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
+                                          int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                                          int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids,
+                                          const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap,
+                                          uint32_t branches, float* out_edge, float* out_node, float* out_pe, float* out_self,
+                                          int32_t* out_count, void* stream) {
+    if (num_neighbors <= 0 || time_gap <= 0)
+        return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
+    if (int rc = check_dims("lstep_gather_aggregate_fwd", feat_dim, pe_dim, time_dim)) return rc;
+    const bool en = branches & LSTEP_BRANCH_EDGE_NODE, pb = branches & LSTEP_BRANCH_PE;
+    if (!en && !pb) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd: no branch selected");
+    if (batch < 0) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd: negative batch");
+    if (batch == 0) return LSTEP_OK;
+    if (!csr || !csr->indptr || !csr->nbr || !csr->eid || !csr->ts || !time_w || !time_b || !node_ids || !times)
+        return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd: NULL pointer");
+    if (en && (!node_raw || !edge_raw || !edge_agg_w || !out_edge || !out_node))
+        return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd: edge/node branch needs node_raw, edge_raw, edge_agg_w, out_edge, out_node");
+    if (pb && (!pe || !out_pe || !out_self))
+        return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd: PE branch needs pe, out_pe, out_self");
+    GatherParams p{*csr, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
+                   batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, out_count};
+    const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (en && pb) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true>), grid, block, 0, s, p);
+    else if (en) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true>), grid, block, 0, s, p);
+    return check_launch("gather_aggregate_fwd_kernel");
+}
+
+extern "C" int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* edge_raw, int32_t feat_dim, int32_t pe_dim,
+                                          const float* time_w, const float* time_b, int32_t time_dim, const int64_t* node_ids,
+                                          const double* times, const int32_t* count, int64_t batch, int32_t num_neighbors,
+                                          const float* grad_edge, const float* grad_pe_agg, const float* grad_self,
+                                          const int32_t* slot_of, float* out_slot_dot, float* grad_pe_rows, void* stream) {
+    if (num_neighbors <= 0) return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
+    if (int rc = check_dims("lstep_gather_aggregate_bwd", feat_dim, pe_dim, time_dim)) return rc;
+    if (batch < 0) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: negative batch");
+    if (batch == 0) return LSTEP_OK;
+    if (!csr || !csr->indptr || !csr->nbr || !csr->eid || !csr->ts || !time_w || !time_b || !node_ids || !times || !count)
+        return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: NULL pointer");
+    if (grad_edge && (!edge_raw || !out_slot_dot)) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: grad_edge needs edge_raw and out_slot_dot");
+    if ((grad_pe_agg || grad_self) && !grad_pe_rows) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: PE gradients need grad_pe_rows");
+    GatherBwdParams p{*csr, edge_raw, feat_dim, pe_dim, time_dim, time_w, time_b, node_ids, times, count, batch, num_neighbors,
+                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows};
+    const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    hipLaunchKernelGGL(gather_aggregate_bwd_kernel, grid, block, 0, (hipStream_t)stream, p);
+    return check_launch("gather_aggregate_bwd_kernel");
+}

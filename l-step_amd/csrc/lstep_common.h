@@ -1,0 +1,74 @@
+// Shared device helpers for the L-STEP gfx950 kernels.  Wave = 64 lanes everywhere (CDNA4).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lstep_hip.h"
+
+namespace lstep {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;  // 256-thread workgroups: one wave per SIMD
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kMaxTimeDim = 128;   // two time-encoding dims per lane
+constexpr int kMaxRowVec = 64;     // one float4 per lane => rows up to 256 floats
+
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+// wave index inside the workgroup, as a scalar (the compiler cannot prove threadIdx.x >> 6 is wave-uniform)
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+__device__ __forceinline__ int bcast_i32(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+__device__ __forceinline__ float bcast_f32(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// Number of entries of the non-decreasing array ts[lo, hi) that are strictly smaller than t
+// (= np.searchsorted(ts[lo:hi], t), side 'left': reference utils/utils.py:140).  Whole wave cooperates:
+// 64 probes per round shrink the range 64x, the last <=64 candidates are compared in one ballot.
+__device__ __forceinline__ int64_t wave_count_before(const double* __restrict__ ts, int64_t lo, int64_t hi, double t, int lane) {
+    int64_t base = lo;
+    int64_t len = hi - lo;
+    while (len > kWave) {
+        const int64_t stride = (len + kWave - 1) / kWave;
+        const int64_t idx = base + (int64_t)(lane + 1) * stride - 1;
+        const bool less = (idx < base + len) ? (ts[idx] < t) : false;
+        const int c = __popcll(__ballot(less));  // probes are sorted: the 'less' lanes form a prefix
+        const int64_t nb = base + (int64_t)c * stride;
+        int64_t nl = base + len - nb;
+        if (nl > stride - 1) nl = stride - 1;  // probe c itself is >= t (or past the end)
+        if (nl < 0) nl = 0;
+        base = nb;
+        len = nl;
+    }
+    const bool less = (lane < len) ? (ts[base + lane] < t) : false;
+    return (base - lo) + __popcll(__ballot(less));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
+    acc.x = fmaf(s, v.x, acc.x);
+    acc.y = fmaf(s, v.y, acc.y);
+    acc.z = fmaf(s, v.z, acc.z);
+    acc.w = fmaf(s, v.w, acc.w);
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// float32 time delta exactly as the reference forms it: float64(t) - float64(float32(neighbour time)), then .float()
+// (utils/utils.py:166 stores neighbour times as float32; models/LSTEP.py:153,228-230 subtract in float64).
+__device__ __forceinline__ float delta_t(double t, double nbr_ts) { return (float)(t - (double)(float)nbr_ts); }
+
+// TimeEncoder element: cos(dt * w + b) in float32 (models/modules.py:37).  Full-range cosf: arguments reach 1e9.
+__device__ __forceinline__ float time_feat(float dt, float w, float b) { return cosf(fmaf(dt, w, b)); }
+
+}  // namespace lstep

@@ -1,0 +1,457 @@
+"""MI355X-backed L-STEP backbone with the reference's method surface.
+
+Drop-in for reference ``models.LSTEP.LSTEP`` (``models/LSTEP.py:28-340``) as it is used by
+``train_LSTEP_link_prediction.py:127-142,198,228-295`` and ``evaluate_model_utils.py:28,61-129``:
+
+* same constructor arguments, same parameter names / shapes / dtypes (reference checkpoints load with
+  ``load_state_dict``), still an ``nn.Module`` that can sit in ``nn.Sequential(backbone, MergeLayer)``;
+* same methods: ``set_neighbor_sampler``, ``fourier_transform_pe``, ``aggregated_node_embeddings``,
+  ``compute_neighborhood_pe``, ``combining_pe_raw_feat``, ``update_pe`` (mutates ``pe`` in place, returns it);
+* additionally ``compute_src_dst_node_temporal_embeddings`` (the DyGLib-style wrapper BASELINE.json names).
+
+The sparse / irregular work (temporal search, row gathers, time encoding, segmented message sums, the history
+stream of the FFT filter) runs in hand-written HIP kernels behind the C ABI of ``include/lstep_hip.h``; the small
+dense projections stay ``torch.nn.functional.linear`` (rocBLAS/hipBLASLt fp32).  There is no CPU fallback.
+
+Numerics: fp32 throughout, like the reference.  Two reassociations (both exact in real arithmetic, <= 1e-6 in fp32):
+``edge_agg`` is applied before ``edge_mlp_1`` (no non-linearity between them, ``models/LSTEP.py:161-164``) and the FFT
+filter is applied as its equivalent real ``[T, P]`` coefficient table (everything between the history gather and
+``fft_agg`` is linear, ``models/LSTEP.py:116-135``).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native as nat
+
+
+# ------------------------------------------------------------------------------------------------ small modules
+class TimeEncoder(nn.Module):
+    """``cos(t * w + b)``; same parameters as reference ``models/modules.py:7-39``."""
+
+    def __init__(self, time_dim: int, parameter_requires_grad: bool = True):
+        super().__init__()
+        self.time_dim = time_dim
+        self.w = nn.Linear(1, time_dim)
+        self.w.weight = nn.Parameter(torch.from_numpy(1 / 10 ** np.linspace(0, 9, time_dim, dtype=np.float32)).reshape(time_dim, -1))
+        self.w.bias = nn.Parameter(torch.zeros(time_dim))
+        if not parameter_requires_grad:
+            self.w.weight.requires_grad = False
+            self.w.bias.requires_grad = False
+
+    def forward(self, timestamps: torch.Tensor, zero_mask: torch.Tensor = None):
+        """timestamps float32 [...]; returns [..., time_dim] (HIP kernel ``lstep_time_encode``; forward only)."""
+        if not timestamps.is_cuda:
+            raise nat.LstepNativeError("TimeEncoder runs on the GPU only (no CPU fallback)")
+        dt = timestamps.contiguous().float()
+        out = torch.empty(dt.shape + (self.time_dim,), dtype=torch.float32, device=dt.device)
+        zm = None if zero_mask is None else zero_mask.to(torch.uint8).contiguous()
+        lib = nat.load_library()
+        with torch.cuda.device(dt.device):
+            nat.check(lib.lstep_time_encode(nat.ptr(dt), nat.ptr(zm), dt.numel(), nat.ptr(self.w.weight), nat.ptr(self.w.bias),
+                                            self.time_dim, nat.ptr(out), nat.current_stream()))
+        return out
+
+
+class MergeLayer(nn.Module):
+    """Link predictor ``fc2(relu(fc1(cat[a, b])))`` (reference ``models/modules.py:42-68``); dense, stays in torch."""
+
+    def __init__(self, input_dim1: int, input_dim2: int, hidden_dim: int, output_dim: int):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim1 + input_dim2, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, output_dim)
+        self.act = nn.ReLU()
+
+    def forward(self, input_1: torch.Tensor, input_2: torch.Tensor):
+        return self.fc2(self.act(self.fc1(torch.cat([input_1, input_2], dim=1))))
+
+
+# ------------------------------------------------------------------------------------------------ autograd glue
+class SplicedRows:
+    """Where the gradient of the current PE table lives during training.
+
+    The table the loss sees is ``clone(last snapshot)`` with the FFT-filtered rows of the batch nodes written in
+    (``train_LSTEP_link_prediction.py:229-230``): only those ``U`` rows carry gradient.  ``rows`` is that ``[U, P]``
+    tensor (requires grad), ``slot_of`` the int32 ``[N+1]`` map node id -> row (or -1).  With it the backward of the
+    gather stage accumulates into ``[U, P]`` instead of a dense ``[N+1, P]`` buffer.
+    """
+
+    def __init__(self, rows: torch.Tensor, slot_of: torch.Tensor):
+        self.rows = rows
+        self.slot_of = slot_of
+
+
+class _GatherAggregate(torch.autograd.Function):
+    """lstep_gather_aggregate_fwd / _bwd.  Differentiable inputs: ``pe`` (dense table) OR ``rows`` (spliced rows), ``agg_w``."""
+
+    @staticmethod
+    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of):
+        lib = nat.load_library()
+        dev = ids.device
+        B = ids.numel()
+        Fd, P, D = mod.feat_dim, mod.pe_dim, mod.time_dim
+        en, pb = bool(branches & nat.BRANCH_EDGE_NODE), bool(branches & nat.BRANCH_PE)
+        out_edge = torch.empty((B, D + Fd), dtype=torch.float32, device=dev) if en else None
+        out_node = torch.empty((B, Fd), dtype=torch.float32, device=dev) if en else None
+        out_pe = torch.empty((B, P + D), dtype=torch.float32, device=dev) if pb else None
+        out_self = torch.empty((B, P), dtype=torch.float32, device=dev) if pb else None
+        count = torch.empty((B,), dtype=torch.int32, device=dev)
+        pe_c = None
+        if pb:
+            pe_c = pe.detach()
+            if pe_c.dtype != torch.float32 or not pe_c.is_contiguous():
+                pe_c = pe_c.float().contiguous()
+        aw = agg_w.detach().contiguous() if en else None
+        tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
+        s = mod.neighbor_sampler
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_gather_aggregate_fwd(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
+                                                     Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
+                                                     int(K), int(G), int(branches), nat.ptr(out_edge), nat.ptr(out_node), nat.ptr(out_pe),
+                                                     nat.ptr(out_self), nat.ptr(count), nat.current_stream()))
+        ctx.mod, ctx.sampler, ctx.K, ctx.branches = mod, s, int(K), int(branches)
+        ctx.pe_shape = tuple(pe.shape) if pe is not None else None
+        ctx.rows_shape = tuple(rows.shape) if rows is not None else None
+        ctx.save_for_backward(ids, times, count, slot_of if slot_of is not None else torch.empty(0, device=dev))
+        ctx.has_slot = slot_of is not None
+        outs = tuple(o if o is not None else torch.empty(0, device=dev) for o in (out_edge, out_node, out_pe, out_self))
+        ctx.mark_non_differentiable(outs[1], count)
+        return outs + (count,)
+
+    @staticmethod
+    def backward(ctx, g_edge, g_node, g_pe, g_self, g_count):
+        lib = nat.load_library()
+        ids, times, count, slot_of = ctx.saved_tensors
+        mod, K = ctx.mod, ctx.K
+        dev = ids.device
+        B = ids.numel()
+        Fd, P, D = mod.feat_dim, mod.pe_dim, mod.time_dim
+        en, pb = bool(ctx.branches & nat.BRANCH_EDGE_NODE), bool(ctx.branches & nat.BRANCH_PE)
+        need_pe, need_rows, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        g_edge = g_edge.contiguous() if (en and need_w and g_edge is not None) else None
+        want_pe = pb and (need_pe or need_rows)
+        g_pe = g_pe.contiguous() if (want_pe and g_pe is not None) else None
+        g_self = g_self.contiguous() if (want_pe and g_self is not None) else None
+        slot_dot = torch.empty((B, K), dtype=torch.float32, device=dev) if g_edge is not None else None
+        grad_rows = None
+        use_slot = False
+        if want_pe:
+            if need_rows:
+                grad_rows = torch.zeros(ctx.rows_shape, dtype=torch.float32, device=dev)
+                use_slot = True
+            else:
+                grad_rows = torch.zeros(ctx.pe_shape, dtype=torch.float32, device=dev)
+        tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
+        if g_edge is not None or grad_rows is not None:
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
+                                                         nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, nat.ptr(g_edge), nat.ptr(g_pe),
+                                                         nat.ptr(g_self), nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
+                                                         nat.ptr(grad_rows), nat.current_stream()))
+        g_w = slot_dot.sum(dim=0) if slot_dot is not None else None
+        g_table = None
+        if grad_rows is not None and not use_slot:
+            if g_pe is not None:  # padding slots all read row 0: one weighted column sum instead of a hot atomic row
+                npad = (K - count.clamp(max=K)).to(torch.float32)
+                grad_rows[0] += npad @ g_pe[:, :P]
+            g_table = grad_rows
+        elif grad_rows is not None and g_pe is not None:
+            # spliced mode: row 0 only has gradient if node 0 is itself a spliced row (never in the reference data)
+            pass
+        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None)
+
+
+class _HistoryFilter(torch.autograd.Function):
+    """out[u] = sum_s coef[s] * hist[ids[u], s]  (lstep_history_filter_fwd / _bwd); gradient only w.r.t. ``coef``."""
+
+    @staticmethod
+    def forward(ctx, coef, hist_base, geom, ids):
+        lib = nat.load_library()
+        node_stride, time_stride, slots, rot, t_len, P = geom
+        U = ids.numel()
+        out = torch.empty((U, P), dtype=torch.float32, device=ids.device)
+        cc = coef.detach().contiguous()
+        with torch.cuda.device(ids.device):
+            nat.check(lib.lstep_history_filter_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(ids), U,
+                                                   nat.ptr(cc), nat.ptr(out), nat.current_stream()))
+        ctx.geom, ctx.coef_shape = geom, tuple(coef.shape)
+        # NOT save_for_backward: the device ring appends its next snapshot (a slot outside this window) in place
+        # before backward runs; the window itself is guaranteed untouched by HistoryRing (engine.py).
+        ctx.hist = hist_base
+        ctx.save_for_backward(ids)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = nat.load_library()
+        (ids,) = ctx.saved_tensors
+        hist_base = ctx.hist
+        node_stride, time_stride, slots, rot, t_len, P = ctx.geom
+        U = ids.numel()
+        g_coef = torch.zeros(ctx.coef_shape, dtype=torch.float32, device=ids.device)
+        if ctx.needs_input_grad[0] and t_len > 0 and U > 0:
+            chunks = int(lib.lstep_history_filter_bwd_chunks(U))
+            partial = torch.empty((chunks, t_len, P), dtype=torch.float32, device=ids.device)
+            g = g_out.contiguous()
+            with torch.cuda.device(ids.device):
+                nat.check(lib.lstep_history_filter_bwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(ids), U,
+                                                       nat.ptr(g), nat.ptr(partial), nat.current_stream()))
+            g_coef[:t_len] = partial.sum(dim=0)
+        return g_coef, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ backbone
+class LSTEP(nn.Module):
+    def __init__(self, node_raw_features: np.ndarray, edge_raw_features: np.ndarray, neighbor_sampler, full_neighbor_sampler=None,
+                 pe_dim: int = 172, num_neighbors: int = 20, time_feat_dim: int = 100, num_fft_batches: int = 100,
+                 use_dropout=False, dropout: float = 0.1, weighted_sum=False, concat_pe=True, device: str = "cuda"):
+        super().__init__()
+        nat.load_library()  # fail loudly: no HIP library, no model
+        if use_dropout:
+            raise NotImplementedError("use_dropout=True is never set by the reference drivers (SURVEY.md appendix A.8)")
+        if weighted_sum:
+            raise NotImplementedError("weighted_sum ablation is out of scope for the MI355X path (SURVEY.md 8f-4)")
+        edge_feat_dim = edge_raw_features.shape[-1]
+        node_feat_dim = node_raw_features.shape[-1]
+        if edge_feat_dim != node_feat_dim:
+            raise ValueError("node and edge feature widths must match (the reference pads both to 172)")
+        self.num_fft_batches = num_fft_batches
+        self.num_nodes = node_raw_features.shape[0]
+        self.pe_dim, self.feat_dim, self.time_dim = pe_dim, node_feat_dim, time_feat_dim
+        self.num_neighbors = num_neighbors
+        self.use_dropout, self.dropout, self.concat_pe, self.weighted_sum = use_dropout, dropout, concat_pe, weighted_sum
+        self.device = torch.device(device)
+
+        def table(x):
+            if isinstance(x, torch.Tensor):
+                return x.to(device=self.device, dtype=torch.float32).contiguous()
+            return torch.from_numpy(np.asarray(x).astype(np.float32, copy=False)).to(self.device).contiguous()
+
+        # plain attributes, not buffers: the reference keeps them out of state_dict too (models/LSTEP.py:45-46)
+        self.node_raw_features = table(node_raw_features)
+        self.edge_raw_features = table(edge_raw_features)
+        self.neighbor_sampler = neighbor_sampler
+        self.full_neighbor_sampler = full_neighbor_sampler
+        self.time_encoder = TimeEncoder(time_feat_dim, parameter_requires_grad=False)
+
+        c = edge_feat_dim + time_feat_dim
+        self.fft_filter = nn.Linear(pe_dim, num_fft_batches, bias=False).to(torch.complex64)
+        self.fft_dropout = nn.Dropout(p=dropout)
+        self.fft_agg = nn.Linear(num_fft_batches, 1, bias=False)
+        self.edge_mlp_1 = nn.Linear(c, c)
+        self.edge_agg = nn.Linear(num_neighbors, 1)
+        self.edge_mlp_2 = nn.Linear(c, c)
+        self.node_mlp = nn.Linear(c + node_feat_dim, node_feat_dim)
+        self.self_update_pe = nn.Linear(pe_dim, pe_dim)
+        self.pe_mlp_1 = nn.Linear(pe_dim + time_feat_dim, pe_dim)
+        self.pe_mlp_2 = nn.Linear(pe_dim, pe_dim)
+        self.self_update_neighbor_pe = nn.Linear(pe_dim, pe_dim)
+        self.pe_neighbor_mlp_1 = nn.Linear(pe_dim + time_feat_dim, pe_dim)
+        self.pe_neighbor_mlp_2 = nn.Linear(pe_dim, pe_dim)
+        self.out_node_emb = nn.Linear(pe_dim + node_feat_dim, node_feat_dim)
+        self.to(self.device)
+
+    # ---- sampler handling (models/LSTEP.py:76-85)
+    def set_neighbor_sampler(self, neighbor_sampler):
+        self.neighbor_sampler = neighbor_sampler
+        if self.neighbor_sampler.sample_neighbor_strategy in ["uniform", "time_interval_aware"]:
+            assert self.neighbor_sampler.seed is not None
+            self.neighbor_sampler.reset_random_state()
+
+    # ---- helpers
+    def _ids(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.int64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(self.device)
+
+    def _times(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.float64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    def _check_rows(self, ids_np):
+        if not isinstance(ids_np, torch.Tensor) and len(ids_np):
+            lo, hi = int(np.min(ids_np)), int(np.max(ids_np))
+            if lo < 0 or hi >= self.neighbor_sampler.num_rows or hi >= self.node_raw_features.shape[0]:
+                raise IndexError(f"node id out of range [0, {self.node_raw_features.shape[0]})")
+
+    def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None):
+        if K != self.num_neighbors and (branches & nat.BRANCH_EDGE_NODE):
+            raise RuntimeError(f"edge_agg was built for num_neighbors={self.num_neighbors}, got {K} "
+                               "(the reference fails the same way at models/LSTEP.py:164)")
+        self._check_rows(node_ids)
+        ids, times = self._ids(node_ids), self._times(node_interact_times)
+        if ids.numel() != times.numel():
+            raise ValueError("node_ids and node_interact_times must have the same length")
+        rows = spliced.rows if spliced is not None else None
+        slot_of = spliced.slot_of if spliced is not None else None
+        return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of)
+
+    def _edge_node_tail(self, x_edge, x_node):
+        """edge_mlp_1 -> edge_agg (reassociated) -> relu -> edge_mlp_2 ; node_mlp(cat[node, edge])  (models/LSTEP.py:161-170,219)."""
+        a = self.edge_agg.weight.reshape(-1)
+        h = F.linear(x_edge, self.edge_mlp_1.weight) + (a.sum() * self.edge_mlp_1.bias + self.edge_agg.bias)
+        h = self.edge_mlp_2(torch.relu(h))
+        return self.node_mlp(torch.cat([x_node, h], dim=-1))
+
+    def _pe_tail(self, x_pe, own):
+        """pe_neighbor_mlp_1/2, self_update_neighbor_pe, tanh, residual (models/LSTEP.py:240-247)."""
+        a = self.pe_neighbor_mlp_2(torch.relu(self.pe_neighbor_mlp_1(x_pe)))
+        return own + torch.tanh(self.self_update_neighbor_pe(own) + a)
+
+    # ---- A + N (models/LSTEP.py:139-220)
+    def aggregated_node_embeddings(self, node_ids, node_interact_times, num_neighbors: int = 20, time_gap: int = 2000, testing=False):
+        x_edge, x_node, _, _, _ = self._gather(None, node_ids, node_interact_times, num_neighbors, time_gap, nat.BRANCH_EDGE_NODE)
+        return self._edge_node_tail(x_edge, x_node)
+
+    # ---- C (models/LSTEP.py:222-249)
+    def compute_neighborhood_pe(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, spliced: SplicedRows = None):
+        _, _, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, 1, nat.BRANCH_PE, spliced)
+        return self._pe_tail(x_pe, own)
+
+    # ---- O (models/LSTEP.py:251-266): one fused gather launch serves A, N and C
+    def combining_pe_raw_feat(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, time_gap: int = 2000, testing=False,
+                              spliced: SplicedRows = None):
+        x_edge, x_node, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, time_gap,
+                                                    nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced)
+        h = self._edge_node_tail(x_edge, x_node)
+        q = self._pe_tail(x_pe, own)
+        return self.out_node_emb(torch.cat([h, q], dim=-1))
+
+    def compute_src_dst_node_temporal_embeddings(self, pe, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20,
+                                                 time_gap: int = 2000, spliced: SplicedRows = None):
+        """DyGLib-style convenience wrapper (shape of reference ``models/GraphMixer.py:57-75``): both endpoints in ONE launch."""
+        n = len(src_node_ids)
+        if isinstance(src_node_ids, torch.Tensor):
+            ids = torch.cat([src_node_ids, dst_node_ids])
+            ts = torch.cat([node_interact_times, node_interact_times])
+        else:
+            ids = np.concatenate([src_node_ids, dst_node_ids])
+            ts = np.concatenate([node_interact_times, node_interact_times])
+        out = self.combining_pe_raw_feat(pe, ids, ts, num_neighbors, time_gap, spliced=spliced)
+        return out[:n], out[n:]
+
+    # ---- F (models/LSTEP.py:104-137)
+    def fft_coefficients(self, t_len: int, batch_idx: int) -> torch.Tensor:
+        """Real [T, P] table c with  fourier_transform_pe(x)[u, p] = sum_s c[s, p] * x[u, s, p].
+
+        Reference pipeline: zero-pad to T, fft over time, (mask), * fft_filter.weight, (mask), ifft, (mask), real part,
+        fft_agg over time; mask = 1 on indices < batch_idx and only when fewer than T snapshots are stored
+        (models/LSTEP.py:108-113).  Everything is linear in x, so with m the mask, W the filter and a the fft_agg row,
+            c[s, p] = Re( 1/T * sum_f m[f] W[f, p] e^{-2 pi i f s / T} * sum_t a[t] m[t] e^{+2 pi i f t / T} ).
+        Built in complex128 from the live parameters, so autograd carries d(loss)/d(c) back to fft_filter and fft_agg.
+        """
+        T = self.num_fft_batches
+        dev = self.fft_agg.weight.device
+        k = torch.arange(T, device=dev, dtype=torch.float64)
+        ang = (2.0 * math.pi / T) * torch.outer(k, k)
+        e_pos = torch.polar(torch.ones_like(ang), ang)          # e^{+i 2 pi f t / T}, [f, t]
+        if t_len < T:
+            m = (k < batch_idx).to(torch.float64)
+        else:
+            m = torch.ones(T, device=dev, dtype=torch.float64)
+        a = self.fft_agg.weight.reshape(-1).to(torch.float64) * m
+        big_a = e_pos @ a.to(torch.complex128)                    # [f]
+        q = (m.unsqueeze(1) * self.fft_filter.weight.to(torch.complex128)) * big_a.unsqueeze(1) / T   # [f, P]
+        coef = (e_pos.conj().t() @ q).real                        # [s, P]: sum_f e^{-i 2 pi f s / T} q[f, p]
+        return coef.to(torch.float32)
+
+    def fourier_transform_pe(self, node_ids, pe, batch_idx, use_dropout=False, use_mixer=False):
+        """``pe`` is the PE history ``[N+1, t, P]`` (any strides with unit last stride); returns ``[U, P]``."""
+        if use_dropout:
+            raise NotImplementedError("use_dropout=True is never used by the reference drivers")
+        if pe.dim() != 3 or pe.shape[2] != self.pe_dim:
+            raise ValueError("pe history must be [N+1, t, P]")
+        t_len = int(pe.shape[1])
+        if t_len > self.num_fft_batches:
+            raise RuntimeError(f"history holds {t_len} snapshots but num_fft_batches={self.num_fft_batches} "
+                               "(the reference's filter broadcast fails the same way)")
+        if t_len == 0:
+            return torch.zeros((len(node_ids), self.pe_dim), dtype=torch.float32, device=self.device)
+        hist = pe.detach()
+        if hist.dtype != torch.float32 or hist.stride(2) != 1 or hist.stride(0) % 4 or hist.stride(1) % 4 or hist.data_ptr() % 16:
+            hist = hist.float().contiguous()
+        geom = (int(hist.stride(0)), int(hist.stride(1)), t_len, 0, t_len, self.pe_dim)
+        return self.filter_history(hist, geom, self._ids(node_ids), batch_idx)
+
+    def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int):
+        """Shared by the drop-in method above and the device ring of ``lstep_amd.engine`` (geom = strides/rotation)."""
+        coef = self.fft_coefficients(geom[4], batch_idx)
+        return _HistoryFilter.apply(coef, hist_base, geom, ids)
+
+    # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
+    # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
+    @torch.no_grad()
+    def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
+                  num_neighbors: int = 30, time_gap: int = 2000):
+        if not (pe.is_cuda and pe.dtype == torch.float32 and pe.is_contiguous()):
+            raise ValueError("update_pe needs a contiguous float32 GPU table (it is mutated in place)")
+        lib = nat.load_library()
+        dev = pe.device
+        P, D = self.pe_dim, self.time_dim
+        tw, tb = self.time_encoder.w.weight, self.time_encoder.w.bias
+        self._check_rows(node_ids)
+        bn = self._ids(node_ids)
+        src, dst = self._ids(batch_src_node_ids), self._ids(batch_dst_node_ids)
+        t = self._times(node_interact_times)
+        U, B = bn.numel(), src.numel()
+        now32 = float(np.float32(current_time))  # torch.Tensor([current_time]) rounds to float32 first (LSTEP.py:277)
+
+        def segment_sum(seg_begin, seg_end, nseg, ent_row, ent_dt, ent_valid):
+            out = torch.empty((nseg, P + D), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_segment_pe_time_sum(nat.ptr(pe), P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(seg_begin), nat.ptr(seg_end), nseg,
+                                                        nat.ptr(ent_row), nat.ptr(ent_dt), nat.ptr(ent_valid), nat.ptr(out), nat.current_stream()))
+            return out
+
+        def write_rows(ids, rows):
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_scatter_rows(nat.ptr(pe), P, nat.ptr(ids), ids.numel(), nat.ptr(rows.contiguous()), nat.current_stream()))
+
+        # ---- phase 1: every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints (LSTEP.py:277-303)
+        dt1 = (now32 - t).to(torch.float32)                       # float32 scalar - float64 -> float64 -> .float()
+        keys = torch.cat([src, dst])
+        order = torch.argsort(keys, stable=True)
+        keys_s = keys[order]
+        ent_row = torch.cat([dst, src])[order].to(torch.int32)
+        ent_dt = torch.cat([dt1, dt1])[order].contiguous()
+        seg_begin = torch.searchsorted(keys_s, bn, right=False)
+        seg_end = torch.searchsorted(keys_s, bn, right=True)
+        agg = segment_sum(seg_begin, seg_end, U, ent_row, ent_dt, None)
+        own = pe[bn]
+        msg = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg)))
+        write_rows(bn, own + torch.tanh(self.self_update_pe(own) + msg))
+
+        # ---- phase 2: push the updated PE of each batch node to its K most recent neighbours (LSTEP.py:305-339).
+        # node_ids (U rows) is zipped with the B edge times: row i uses time[i]; rows >= min(U, B) stay padding.
+        nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, num_neighbors)
+        key = nbr.reshape(-1)
+        rep = bn.unsqueeze(1).expand(U, num_neighbors).reshape(-1)
+        dt2 = (torch.tensor(now32, dtype=torch.float32, device=dev) - nt.reshape(-1))   # float32 - float32 (LSTEP.py:314)
+        pe[0] = 0.0                                                                     # (LSTEP.py:317)
+        real = key != 0
+        zeros_per_row = (nbr == 0).sum(dim=1).to(torch.float32)                         # slots that scatter into row 0
+        key_r = key[real]
+        order = torch.argsort(key_r, stable=True)
+        key_s = key_r[order]
+        touched, counts = torch.unique_consecutive(key_s, return_counts=True)
+        seg_end = torch.cumsum(counts, 0)
+        seg_begin = seg_end - counts
+        ent_row = rep[real][order].to(torch.int32)
+        ent_dt = dt2[real][order].contiguous()
+        agg2 = segment_sum(seg_begin, seg_end, touched.numel(), ent_row, ent_dt, None)
+        if bool((zeros_per_row > 0).any()):
+            # row 0 collects cat[pe[source], 0] from every padded slot: a [U] x [U, P] product instead of a hot segment
+            row0 = torch.zeros((1, P + D), dtype=torch.float32, device=dev)
+            row0[0, :P] = zeros_per_row @ pe[bn]
+            agg2 = torch.cat([row0, agg2], dim=0)
+            touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
+        own2 = pe[touched]
+        msg2 = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg2)))
+        write_rows(touched, own2 + torch.tanh(msg2))              # the self_update_pe term is dead code in the reference (:334-335)
+        return pe

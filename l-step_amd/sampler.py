@@ -1,0 +1,117 @@
+"""Device-resident temporal neighbour sampler: the host-side mirror of reference ``utils.utils.NeighborSampler``.
+
+Same public surface as the reference (``utils/utils.py:70-279``, built by ``get_neighbor_sampler`` at ``:282-301``):
+``sample_neighbor_strategy``, ``seed``, ``reset_random_state()``, ``get_historical_neighbors(node_ids,
+node_interact_times, num_neighbors) -> (int64[M, K], int64[M, K], float32[M, K])`` with numpy in / numpy out.
+What changes is where the data lives: the per-node Python lists become one time-sorted CSR in HBM
+(``int64 indptr``, ``int32 nbr``, ``int32 eid``, ``float64 ts`` -- 16 bytes per adjacency entry) and the per-row
+Python loop + ``np.searchsorted`` becomes ``lstep_sample_recent`` (one wave per row).
+
+Only the ``'recent'`` strategy runs on the device; ``'uniform'`` / ``'time_interval_aware'`` are defined by
+``np.random.RandomState.choice`` call order (``utils/utils.py:175-198``) and are a "next" row of SURVEY.md 8(f).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+def build_csr_arrays(src, dst, eid, ts, num_nodes=None):
+    """Host-side CSR build with the reference's ordering: each edge goes to both endpoints (src's list first,
+    ``utils/utils.py:297-299``); each list is stably sorted by timestamp (``:99``)."""
+    src = np.asarray(src, dtype=np.int64)
+    dst = np.asarray(dst, dtype=np.int64)
+    eid = np.asarray(eid, dtype=np.int64)
+    ts = np.asarray(ts, dtype=np.float64)
+    e = len(src)
+    top = int(max(src.max(), dst.max())) if e else 0
+    if e and (min(src.min(), dst.min()) < 0):
+        raise ValueError("negative node id")
+    rows = max(top, int(num_nodes) if num_nodes is not None else 0) + 1
+    if rows >= 2 ** 31 or (e and eid.max() >= 2 ** 31):
+        raise ValueError("node / edge ids must fit int32")
+    owner = np.empty(2 * e, dtype=np.int64)
+    owner[0::2], owner[1::2] = src, dst
+    other = np.empty(2 * e, dtype=np.int32)
+    other[0::2], other[1::2] = dst, src
+    tss = np.repeat(ts, 2)
+    # stable sort by (owner, time); ties keep insertion order = the reference's `sorted(..., key=ts)` on append order
+    order = np.lexsort((tss, owner))  # lexsort is stable: equal (owner, ts) keep their original (insertion) order
+    indptr = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(owner, minlength=rows), out=indptr[1:])
+    return indptr, other[order], np.repeat(eid, 2).astype(np.int32)[order], tss[order], rows
+
+
+class NeighborSampler:
+    def __init__(self, src_node_ids, dst_node_ids, edge_ids, node_interact_times, num_nodes=None,
+                 sample_neighbor_strategy: str = "recent", time_scaling_factor: float = 0.0, seed: int = None,
+                 device="cuda"):
+        if sample_neighbor_strategy not in ("recent", "uniform", "time_interval_aware"):
+            raise ValueError(f"Not implemented error for sample_neighbor_strategy {sample_neighbor_strategy}!")
+        if sample_neighbor_strategy != "recent":
+            raise NotImplementedError("only sample_neighbor_strategy='recent' runs on the MI355X path "
+                                      "(uniform / time_interval_aware replay numpy's RNG on the host: SURVEY.md 8f-2)")
+        nat.load_library()  # fail loudly if the HIP library is missing
+        self.sample_neighbor_strategy = sample_neighbor_strategy
+        self.time_scaling_factor = time_scaling_factor
+        self.seed = seed
+        self.device = torch.device(device)
+        indptr, nbr, eid, ts, rows = build_csr_arrays(src_node_ids, dst_node_ids, edge_ids, node_interact_times, num_nodes)
+        self.num_rows = rows
+        self.nnz = int(len(nbr))
+        self.indptr = torch.from_numpy(indptr).to(self.device)
+        self.nbr = torch.from_numpy(nbr).to(self.device)
+        self.eid = torch.from_numpy(eid).to(self.device)
+        self.ts = torch.from_numpy(ts).to(self.device)
+        if self.nnz == 0:  # keep valid device pointers for empty graphs
+            self.nbr = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.eid = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.ts = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._csr = nat.CsrStruct(self.indptr.data_ptr(), self.nbr.data_ptr(), self.eid.data_ptr(), self.ts.data_ptr(),
+                                  self.num_rows, self.nnz)
+
+    @property
+    def csr(self):
+        return self._csr
+
+    def reset_random_state(self):
+        """API parity (``utils/utils.py:274-279``); the 'recent' strategy draws no random numbers."""
+        if self.seed is not None:
+            self.random_state = np.random.RandomState(self.seed)
+
+    # ---- device-side entry point: tensors in, tensors out, no host sync
+    def sample_device(self, node_ids: torch.Tensor, times: torch.Tensor, num_neighbors: int, want_count: bool = False):
+        assert num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!"
+        node_ids = node_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        times = times.to(device=self.device, dtype=torch.float64).contiguous()
+        m = node_ids.numel()
+        nbr = torch.empty((m, num_neighbors), dtype=torch.int64, device=self.device)
+        eid = torch.empty((m, num_neighbors), dtype=torch.int64, device=self.device)
+        nt = torch.empty((m, num_neighbors), dtype=torch.float32, device=self.device)
+        cnt = torch.empty((m,), dtype=torch.int32, device=self.device) if want_count else None
+        lib = nat.load_library()
+        with torch.cuda.device(self.device):
+            nat.check(lib.lstep_sample_recent(self._csr, nat.ptr(node_ids), m, nat.ptr(times), times.numel(), int(num_neighbors),
+                                              nat.ptr(nbr), nat.ptr(eid), nat.ptr(nt), nat.ptr(cnt), nat.current_stream()))
+        return (nbr, eid, nt, cnt) if want_count else (nbr, eid, nt)
+
+    # ---- reference-shaped entry point: numpy in, numpy out (utils/utils.py:148-213)
+    def get_historical_neighbors(self, node_ids: np.ndarray, node_interact_times: np.ndarray, num_neighbors: int = 20):
+        assert num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!"
+        ids = np.ascontiguousarray(node_ids, dtype=np.int64)
+        if ids.size and (ids.min() < 0 or ids.max() >= self.num_rows):
+            raise IndexError("list index out of range")  # what the reference's list lookup raises
+        ts = np.ascontiguousarray(node_interact_times, dtype=np.float64)
+        nbr, eid, nt = self.sample_device(torch.from_numpy(ids), torch.from_numpy(ts), num_neighbors)
+        return nbr.cpu().numpy().astype(np.longlong, copy=False), eid.cpu().numpy().astype(np.longlong, copy=False), nt.cpu().numpy()
+
+
+def get_neighbor_sampler(data, sample_neighbor_strategy: str = "uniform", time_scaling_factor: float = 0.0, seed: int = None,
+                         device="cuda", num_nodes=None):
+    """Mirror of reference ``utils.utils.get_neighbor_sampler(data, ...)``: ``data`` needs ``src_node_ids``,
+    ``dst_node_ids``, ``edge_ids``, ``node_interact_times`` (``utils/DataLoader.py:68-86``)."""
+    return NeighborSampler(data.src_node_ids, data.dst_node_ids, data.edge_ids, data.node_interact_times, num_nodes=num_nodes,
+                           sample_neighbor_strategy=sample_neighbor_strategy, time_scaling_factor=time_scaling_factor, seed=seed,
+                           device=device)

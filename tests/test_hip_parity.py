@@ -1,0 +1,311 @@
+"""GPU parity tests: the HIP path (through the C ABI, via lstep_amd) against (a) the golden vectors the reference
+produced and (b) the CPU oracle on seeded inputs.  Bars: index tensors bit-exact; embeddings / PE tables / losses
+within 1e-4 abs in fp32 (BASELINE.json north_star) -- the asserted tolerance is tighter (2e-5) so drift shows early.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (GRAD_ROW_STRIDE, METHOD_K, METHOD_T, SAMPLER_GRAPHS, TRACE_B, TRACE_BATCHES, TRACE_G, TRACE_K, TRACE_START,
+                     TRACE_T, eval_batches, method_inputs, param_digest, trace_batches, trace_inputs)
+from lstep_amd import protocol, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=0, atol=2e-5)
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lstep_amd import _native
+    from lstep_amd.engine import EdgeStream, LstepEngine
+    from lstep_amd.model import LSTEP, MergeLayer, TimeEncoder
+    from lstep_amd.sampler import NeighborSampler
+    from lstep_amd.smoke import build_hip_model
+
+    _native.load_library()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.NeighborSampler, ns.LSTEP, ns.MergeLayer, ns.TimeEncoder = NeighborSampler, LSTEP, MergeLayer, TimeEncoder
+    ns.build = build_hip_model
+    ns.EdgeStream, ns.LstepEngine = EdgeStream, LstepEngine
+    return ns
+
+
+def hip_sampler(hip, g):
+    return hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=g["num_nodes"], device=DEV)
+
+
+def oracle_sampler(g):
+    from oracle.lstep_oracle import OracleNeighborSampler
+    return OracleNeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=g["num_nodes"])
+
+
+# ------------------------------------------------------------------------------------------------ S
+@pytest.mark.parametrize("name", list(SAMPLER_GRAPHS))
+def test_sampler_golden_bit_exact(hip, golden, name):
+    z = golden("sampler")
+    g = synth.make_temporal_graph(**SAMPLER_GRAPHS[name])
+    s = hip_sampler(hip, g)
+    ids, ts = z[f"{name}/ids"], z[f"{name}/ts"]
+    for k in (1, 5, 20, 32, 8):
+        nbr, eid, nt = s.get_historical_neighbors(ids, ts, k)
+        assert nbr.dtype == np.int64 and eid.dtype == np.int64 and nt.dtype == np.float32
+        np.testing.assert_array_equal(nbr, z[f"{name}/k{k}/nbr"])
+        np.testing.assert_array_equal(eid, z[f"{name}/k{k}/eid"])
+        np.testing.assert_array_equal(nt.view(np.uint32), z[f"{name}/k{k}/nt"].view(np.uint32))
+    nbr, eid, nt = s.get_historical_neighbors(ids, ts, 2000)
+    assert int((nbr[:, :-192] != 0).sum()) == 0
+    np.testing.assert_array_equal(nbr[:, -192:], z[f"{name}/k2000/nbr_tail"])
+    np.testing.assert_array_equal(eid[:, -192:], z[f"{name}/k2000/eid_tail"])
+    np.testing.assert_array_equal(nt[:, -192:].view(np.uint32), z[f"{name}/k2000/nt_tail"].view(np.uint32))
+    for tag, (a, b) in {"more_ids": (ids, ts[:9]), "more_ts": (ids[:9], ts)}.items():
+        nbr, eid, nt = s.get_historical_neighbors(a, b, 5)
+        np.testing.assert_array_equal(nbr, z[f"{name}/{tag}/nbr"])
+        np.testing.assert_array_equal(eid, z[f"{name}/{tag}/eid"])
+        np.testing.assert_array_equal(nt.view(np.uint32), z[f"{name}/{tag}/nt"].view(np.uint32))
+
+
+def test_sampler_vs_oracle_hubs_and_long_rows(hip):
+    """Power-law graph: some rows have thousands of interactions (multi-round wave search, K > 64, K = time_gap)."""
+    g = synth.make_temporal_graph(num_nodes=300, num_edges=60000, seed=77, zipf=1.3, tie_quantum=3.0)
+    hs, os_ = hip_sampler(hip, g), oracle_sampler(g)
+    rng = np.random.RandomState(3)
+    ids = rng.randint(0, 301, size=700).astype(np.int64)
+    ts = rng.uniform(g["ts"][0] - 1, g["ts"][-1] + 1, size=700)
+    ts[:200] = g["ts"][rng.randint(0, 60000, size=200)]  # exact hits on existing timestamps
+    deg = np.diff(os_.indptr)
+    assert deg.max() > 4096, "fixture must exercise the multi-round search"
+    ids[:5] = np.argsort(deg)[-5:]
+    ts[:5] = g["ts"][-1] + 1
+    for k in (1, 20, 64, 65, 200, 2000):
+        a = hs.get_historical_neighbors(ids, ts, k)
+        b = os_.get_historical_neighbors(ids, ts, k)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+    # sortedness / right alignment property at full width
+    nbr, eid, nt = a
+    filled = nbr != 0
+    assert np.all(np.diff(filled.astype(np.int8), axis=1) >= 0)  # zeros only on the left
+    assert np.all((np.diff(nt, axis=1) >= 0) | ~filled[:, 1:] | ~filled[:, :-1])
+
+
+def test_sampler_errors(hip):
+    g = synth.make_temporal_graph(num_nodes=8, num_edges=40, seed=1)
+    s = hip_sampler(hip, g)
+    with pytest.raises(AssertionError):
+        s.get_historical_neighbors(np.array([1]), np.array([1.0]), 0)
+    with pytest.raises(IndexError):
+        s.get_historical_neighbors(np.array([99]), np.array([1.0]), 3)
+    out = s.get_historical_neighbors(np.zeros(0, dtype=np.int64), np.zeros(0), 4)
+    assert out[0].shape == (0, 4)
+    with pytest.raises(NotImplementedError):
+        hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], sample_neighbor_strategy="uniform", seed=0, device=DEV)
+
+
+# ------------------------------------------------------------------------------------------------ T
+def test_time_encoder_golden(hip, golden):
+    z = golden("time_encoder")
+    enc = hip.TimeEncoder(synth.TIME_DIM, parameter_requires_grad=False).to(DEV)
+    np.testing.assert_array_equal(enc.w.weight.detach().cpu().numpy().reshape(-1), z["w"])
+    y = enc(torch.from_numpy(z["dt"]).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(y, z["enc"], rtol=0, atol=1e-6)
+    mask = torch.zeros(len(z["dt"]), dtype=torch.bool, device=DEV)
+    mask[::3] = True
+    y2 = enc(torch.from_numpy(z["dt"]).to(DEV), zero_mask=mask).cpu().numpy()
+    assert np.all(y2[::3] == 0) and np.array_equal(y2[1::3], y[1::3])
+
+
+# ------------------------------------------------------------------------------------------------ A N C O F U
+@pytest.fixture(scope="module")
+def method_setup(hip):
+    g, node_raw, edge_raw, pe0 = method_inputs()
+    return g, node_raw, edge_raw, pe0, hip_sampler(hip, g)
+
+
+@pytest.mark.parametrize("K", [METHOD_K, 20])
+def test_methods_golden(hip, golden, method_setup, K):
+    z = golden("methods")
+    g, node_raw, edge_raw, pe0, sampler = method_setup
+    model = hip.build(node_raw, edge_raw, sampler, K, METHOD_T, synth.make_state_dict(K, METHOD_T), DEV)
+    bb = model[0]
+    pe = torch.from_numpy(z[f"K{K}/pe_live"].copy()).to(DEV)
+    with torch.no_grad():
+        for tag, sl in {"mid": slice(1200, 1216), "early": slice(3, 19)}.items():
+            src, dst, t = g["src"][sl], g["dst"][sl], g["ts"][sl]
+            for G in (8, 2000):
+                np.testing.assert_allclose(bb.aggregated_node_embeddings(src, t, K, G).cpu().numpy(), z[f"K{K}/{tag}/agg_G{G}"], **TOL)
+            np.testing.assert_allclose(bb.compute_neighborhood_pe(pe, dst, t, K).cpu().numpy(), z[f"K{K}/{tag}/cpe"], **TOL)
+            np.testing.assert_allclose(bb.combining_pe_raw_feat(pe, src, t, K, 2000).cpu().numpy(), z[f"K{K}/{tag}/out_src"], **TOL)
+            np.testing.assert_allclose(bb.combining_pe_raw_feat(pe, dst, t, K, 8).cpu().numpy(), z[f"K{K}/{tag}/out_dst"], **TOL)
+            a, b = bb.compute_src_dst_node_temporal_embeddings(pe, src, dst, t, K, 2000)
+            np.testing.assert_allclose(a.cpu().numpy(), z[f"K{K}/{tag}/out_src"], **TOL)
+
+        def upd(pe_in, sl_or_idx):
+            s_, d_, t_, e_ = g["src"][sl_or_idx], g["dst"][sl_or_idx], g["ts"][sl_or_idx], g["eid"][sl_or_idx]
+            res = bb.update_pe(pe_in, protocol.unique_batch_nodes(s_, d_), e_, s_, d_, t_, t_.max(), num_neighbors=K)
+            assert res is pe_in  # mutated in place and returned (LSTEP.py:303,339,340)
+            return pe_in.cpu().numpy()
+
+        live = upd(torch.from_numpy(pe0.copy()).to(DEV), slice(40, 56))
+        np.testing.assert_allclose(live, z[f"K{K}/pe_live"], **TOL)
+        np.testing.assert_allclose(upd(pe.clone(), slice(1200, 1216)), z[f"K{K}/update_UgtB/pe_out"], **TOL)
+        np.testing.assert_allclose(upd(pe.clone(), z[f"K{K}/update_UltB/edge_pos"]), z[f"K{K}/update_UltB/pe_out"], **TOL)
+        np.testing.assert_allclose(upd(torch.from_numpy(pe0.copy()).to(DEV), slice(0, 16)), z[f"K{K}/update_first/pe_out"], **TOL)
+
+
+def test_wrong_num_neighbors_fails_like_reference(hip, method_setup):
+    g, node_raw, edge_raw, pe0, sampler = method_setup
+    model = hip.build(node_raw, edge_raw, sampler, METHOD_K, METHOD_T, None, DEV)
+    with pytest.raises(RuntimeError):
+        model[0].aggregated_node_embeddings(g["src"][:4], g["ts"][:4], METHOD_K + 1, 8)
+    with pytest.raises(AssertionError):
+        model[0].compute_neighborhood_pe(torch.zeros(65, 172, device=DEV), g["src"][:4], g["ts"][:4], 0)
+
+
+def test_fft_filter_golden(hip, golden, method_setup):
+    z = golden("methods")
+    g, node_raw, edge_raw, pe0, sampler = method_setup
+    model = hip.build(node_raw, edge_raw, sampler, METHOD_K, METHOD_T, synth.make_state_dict(METHOD_K, METHOD_T), DEV)
+    rng = np.random.RandomState(23)
+    hist = (0.1 * rng.standard_normal((g["num_nodes"] + 1, METHOD_T, synth.PE_DIM))).astype(np.float32)
+    ids = z["fft/ids"]
+    full = torch.from_numpy(hist).to(DEV)
+    with torch.no_grad():
+        for stored, bidx in ((3, 3), (METHOD_T, 9), (4, 2), (2, 0), (1, 1), (METHOD_T, 0)):
+            for h in (full[:, :stored, :].contiguous(), full[:, :stored, :]):  # contiguous and strided views
+                y = model[0].fourier_transform_pe(ids, h, bidx).cpu().numpy()
+                np.testing.assert_allclose(y, z[f"fft/stored{stored}_b{bidx}"], **TOL)
+
+
+# ------------------------------------------------------------------------------------------------ protocol traces
+def _check_grads(model, z):
+    for k, p in model.named_parameters():
+        if f"grads/{k}/none" in z.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        a = p.grad.detach().cpu().numpy()
+        a = np.stack([a.real, a.imag], -1) if np.iscomplexobj(a) else a
+        got = a[::GRAD_ROW_STRIDE] if a.size > 20000 else a
+        np.testing.assert_allclose(got, z[f"grads/{k}"], rtol=0, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(a.astype(np.float64).sum(), z[f"grads/{k}/digest"][0], rtol=0, atol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("mode", ["dropin", "engine"])
+def test_train_eval_traces_golden(hip, golden, mode):
+    """dropin: lstep_amd.protocol (the reference loop bodies) drives the HIP model through reference-shaped tensors.
+    engine: the device-resident fast harness (ring history, spliced gradients, merged launches).  Same golden trace."""
+    z = golden("traces")
+    g, node_raw, edge_raw, pe0 = trace_inputs()
+    sampler = hip_sampler(hip, g)
+    model = hip.build(node_raw, edge_raw, sampler, TRACE_K, TRACE_T, synth.make_state_dict(TRACE_K, TRACE_T), DEV)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    init = torch.from_numpy(pe0.copy()).to(DEV)
+    if mode == "dropin":
+        state = protocol.ProtocolState(history=torch.zeros(g["num_nodes"] + 1, 0, synth.PE_DIM, device=DEV), initial_pe=init)
+    else:
+        eng = hip.LstepEngine(model[0], model[1], TRACE_K, TRACE_G)
+        stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+    for b, (src, dst, t, eid, neg) in enumerate(trace_batches(g)):
+        if mode == "dropin":
+            res = protocol.train_iteration(model[0], model[1], opt, state, b, src, dst, t, eid, neg, TRACE_K, TRACE_G, TRACE_T)
+            snap = state.history[:, -1, :].cpu().numpy()
+            if res is not None:
+                losses, predicts = [res["lp_loss"], res["pe_loss"], res["loss"]], res["predicts"]
+        else:
+            lo = TRACE_START + b * TRACE_B
+            res = eng.train_iteration(opt, b, *stream.batch(lo, lo + TRACE_B), torch.from_numpy(neg).to(DEV), initial_pe=init)
+            snap = eng.ring.last().cpu().numpy()
+            if res is not None:
+                losses = [float(res["lp_loss"]), float(res["pe_loss"]), float(res["loss"])]
+                predicts = res["predicts"].cpu().numpy()
+        np.testing.assert_allclose(snap, z[f"train/b{b}/snapshot"], **TOL)
+        if res is not None:
+            np.testing.assert_allclose(losses, z[f"train/b{b}/losses"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(predicts, z[f"train/b{b}/predicts"], **TOL)
+        if b == 1:
+            _check_grads(model, z)
+        for k, v in param_digest(model).items():
+            np.testing.assert_allclose(v, z[f"train/b{b}/digest/{k}"], rtol=1e-5, atol=2e-4, err_msg=f"b{b} {k}")
+    hist = state.history.cpu().numpy() if mode == "dropin" else None
+    if mode == "dropin":
+        np.testing.assert_allclose(hist, z["train/final_history"], **TOL)
+    else:
+        np.testing.assert_allclose(eng.ring.as_reference_tensor().cpu().numpy(), z["train/final_history"][:, -TRACE_T:, :], **TOL)
+
+    model.eval()
+    with torch.no_grad():
+        if mode == "dropin":
+            ev = protocol.ProtocolState(history=state.history.clone())
+        for b, (src, dst, t, eid, neg_src, neg_dst) in enumerate(eval_batches(g)):
+            if mode == "dropin":
+                res = protocol.eval_iteration(model[0], model[1], ev, b, src, dst, t, eid, neg_src, neg_dst, TRACE_K, TRACE_G, TRACE_T)
+                loss, predicts, snap = res["loss"], res["predicts"], ev.history[:, -1, :].cpu().numpy()
+            else:
+                lo = TRACE_START + (TRACE_BATCHES + b) * TRACE_B
+                res = eng.eval_iteration(b, *stream.batch(lo, lo + TRACE_B), torch.from_numpy(neg_src).to(DEV), torch.from_numpy(neg_dst).to(DEV))
+                loss, predicts, snap = float(res["loss"]), res["predicts"].cpu().numpy(), eng.ring.last().cpu().numpy()
+            np.testing.assert_allclose(loss, z[f"eval/b{b}/loss"][0], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(predicts, z[f"eval/b{b}/predicts"], **TOL)
+            np.testing.assert_allclose(snap, z[f"eval/b{b}/snapshot"], **TOL)
+
+
+# ------------------------------------------------------------------------------------------------ oracle at larger sizes
+def test_combine_and_update_vs_oracle_larger(hip):
+    """Reddit-shaped slice (K = 32, long neighbourhoods, time_gap both below and above the history length)."""
+    from oracle.lstep_oracle import build_oracle_model
+    N, E, K, T, B = 400, 30000, 32, 8, 256
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=91, zipf=1.1)
+    node_raw, edge_raw = synth.make_features(N, E, seed=92)
+    pe_np = synth.make_initial_pe(N, seed=93)
+    pe_np[0] = 0.05  # live padding row
+    sd = synth.make_state_dict(K, T, seed=94)
+    om = build_oracle_model(node_raw, edge_raw, oracle_sampler(g), K, T, sd)
+    hm = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, sd, DEV)
+    sl = slice(20000, 20000 + B)
+    src, dst, t, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+    with torch.no_grad():
+        for G in (16, 2000):
+            ref = om[0].combining_pe_raw_feat(torch.from_numpy(pe_np), src, t, K, G).numpy()
+            got = hm[0].combining_pe_raw_feat(torch.from_numpy(pe_np).to(DEV), src, t, K, G).cpu().numpy()
+            np.testing.assert_allclose(got, ref, **TOL)
+        bn = protocol.unique_batch_nodes(src, dst)
+        ref = om[0].update_pe(torch.from_numpy(pe_np.copy()), bn, eid, src, dst, t, t.max(), num_neighbors=K).numpy()
+        got = hm[0].update_pe(torch.from_numpy(pe_np.copy()).to(DEV), bn, eid, src, dst, t, t.max(), num_neighbors=K).cpu().numpy()
+        np.testing.assert_allclose(got, ref, **TOL)
+    # gradients through a dense PE table (drop-in autograd path) vs oracle autograd
+    pe_o = torch.from_numpy(pe_np.copy()).requires_grad_(True)
+    pe_h = torch.from_numpy(pe_np.copy()).to(DEV).requires_grad_(True)
+    wgt = torch.from_numpy(np.random.RandomState(5).standard_normal((B, synth.FEAT_DIM)).astype(np.float32))
+    (om[0].combining_pe_raw_feat(pe_o, dst, t, K, 2000) * wgt).sum().backward()
+    (hm[0].combining_pe_raw_feat(pe_h, dst, t, K, 2000) * wgt.to(DEV)).sum().backward()
+    np.testing.assert_allclose(pe_h.grad.cpu().numpy(), pe_o.grad.numpy(), rtol=0, atol=5e-5)
+    for (k, po), (_, ph) in zip(om.named_parameters(), hm.named_parameters()):
+        if po.grad is None:
+            assert ph.grad is None or float(ph.grad.abs().max()) == 0
+            continue
+        np.testing.assert_allclose(ph.grad.cpu().numpy(), po.grad.numpy(), rtol=0, atol=2e-4, err_msg=k)
+
+
+def test_linearity_property_of_gather_stage(hip):
+    """Size-independent property: the PE channel of the gather stage is linear in the PE table."""
+    N, E, K, T, B = 5000, 200000, 20, 4, 4096
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=101)
+    node_raw, edge_raw = synth.make_features(N, E, seed=102)
+    hm = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, None, DEV)
+    rng = np.random.RandomState(1)
+    ids = torch.from_numpy(rng.randint(1, N + 1, size=B)).to(DEV)
+    ts = torch.from_numpy(rng.uniform(g["ts"][E // 2], g["ts"][-1], size=B)).to(DEV)
+    pa = torch.randn(N + 1, 172, device=DEV)
+    pb = torch.randn(N + 1, 172, device=DEV)
+    with torch.no_grad():
+        f = lambda p: hm[0]._gather(p, ids, ts, K, 1, 2)[2]  # noqa: E731
+        ya, yb, yab = f(pa), f(pb), f(2.0 * pa - 3.0 * pb)
+        np.testing.assert_allclose(yab[:, :172].cpu().numpy(), (2.0 * ya - 3.0 * yb)[:, :172].cpu().numpy(), rtol=0, atol=2e-4)
+        assert torch.equal(ya[:, 172:], yb[:, 172:])  # time channel does not depend on the PE table

@@ -1,0 +1,114 @@
+"""CPU-only checks of the host layer: the C-ABI library loads and exports every symbol of include/lstep_hip.h
+(no compute call: there is no GPU here), the host CSR builder reproduces the reference adjacency order, and the
+FFT-filter coefficient table is the reference's fft -> filter -> ifft -> agg pipeline."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import METHOD_K, METHOD_T, SAMPLER_GRAPHS, method_inputs
+from lstep_amd import _native as nat
+from lstep_amd import synth
+from lstep_amd.sampler import build_csr_arrays
+from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    nat.build_library()
+    return nat.load_library()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lstep_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lstep_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    names = declared_symbols()
+    assert len(names) >= 11
+    raw = ctypes.CDLL(nat.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/lstep_hip.h but not exported"
+        assert n in nat.SIGNATURES, f"{n} has no ctypes prototype"
+    assert sorted(nat.SIGNATURES) == names
+    assert lib.lstep_abi_version() == 1
+
+
+def test_abi_argument_validation_without_gpu(lib):
+    # validation happens before any HIP call, so these are safe on a CPU-only host
+    rc = lib.lstep_sample_recent(None, None, 4, None, 4, 0, None, None, None, None, None)
+    assert rc == nat.LSTEP_EINVAL and b"greater than 0" in lib.lstep_last_error()
+    with pytest.raises(AssertionError):
+        nat.check(rc)
+    csr = nat.CsrStruct(0, 0, 0, 0, 0, 0)
+    assert lib.lstep_sample_recent(ctypes.byref(csr), None, 4, None, 4, 5, None, None, None, None, None) == nat.LSTEP_EINVAL
+    assert lib.lstep_gather_aggregate_fwd(ctypes.byref(csr), None, None, None, 170, 172, None, None, 100, None, None, None, 4, 5, 8, 3,
+                                          None, None, None, None, None, None) == nat.LSTEP_EINVAL
+    assert b"unsupported widths" in lib.lstep_last_error()
+    assert lib.lstep_history_filter_bwd_chunks(0) == 0 and lib.lstep_history_filter_bwd_chunks(65) == 2
+    assert lib.lstep_sample_recent(ctypes.byref(csr), None, 0, None, 0, 5, None, None, None, None, None) == nat.LSTEP_OK  # empty batch
+
+
+@pytest.mark.parametrize("name", list(SAMPLER_GRAPHS))
+def test_csr_builder_matches_reference_order(name):
+    g = synth.make_temporal_graph(**SAMPLER_GRAPHS[name])
+    indptr, nbr, eid, ts, rows = build_csr_arrays(g["src"], g["dst"], g["eid"], g["ts"], g["num_nodes"])
+    o = OracleNeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=g["num_nodes"])
+    assert rows == o.num_rows
+    np.testing.assert_array_equal(indptr, o.indptr)
+    np.testing.assert_array_equal(nbr, o.nbr)
+    np.testing.assert_array_equal(eid, o.eid)
+    np.testing.assert_array_equal(ts, o.ts)
+    assert nbr.dtype == np.int32 and eid.dtype == np.int32 and ts.dtype == np.float64
+
+
+def test_csr_builder_edge_cases():
+    indptr, nbr, eid, ts, rows = build_csr_arrays([], [], [], [], num_nodes=3)
+    assert rows == 4 and indptr.tolist() == [0, 0, 0, 0, 0] and len(nbr) == 0
+    # self loop appears twice in its node's list; node 3 is isolated
+    indptr, nbr, eid, ts, rows = build_csr_arrays([1, 2], [1, 1], [1, 2], [5.0, 5.0], num_nodes=3)
+    assert indptr.tolist() == [0, 0, 3, 4, 4] and nbr[:3].tolist() == [1, 1, 2] and eid[:3].tolist() == [1, 1, 2]
+    with pytest.raises(ValueError):
+        build_csr_arrays([-1], [1], [1], [0.0])
+
+
+def test_fft_coefficient_table_is_the_reference_pipeline():
+    from lstep_amd.model import LSTEP
+    g, node_raw, edge_raw, pe0 = method_inputs()
+    sd = synth.make_state_dict(METHOD_K, METHOD_T)
+    oracle = build_oracle_model(node_raw, edge_raw, None, METHOD_K, METHOD_T, sd)[0]
+    bb = LSTEP(node_raw, edge_raw, None, None, num_neighbors=METHOD_K, num_fft_batches=METHOD_T, device="cpu")
+    bb.load_state_dict({k[2:]: torch.as_tensor(v) for k, v in sd.items() if k.startswith("0.")})
+    rng = np.random.RandomState(4)
+    hist = torch.from_numpy((0.1 * rng.standard_normal((g["num_nodes"] + 1, METHOD_T, synth.PE_DIM))).astype(np.float32))
+    ids = np.arange(0, 65, 7)
+    for stored, bidx in ((3, 3), (METHOD_T, 9), (4, 2), (2, 0), (1, 1), (5, 40)):
+        x = hist[:, :stored, :]
+        ref = oracle.fourier_transform_pe(ids, x, bidx)
+        coef = bb.fft_coefficients(stored, bidx)
+        got = torch.einsum("usp,sp->up", x[torch.from_numpy(ids)], coef[:stored])
+        np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=0, atol=2e-6)
+    # gradients reach fft_filter (complex) and fft_agg through the table exactly as through the FFT pipeline
+    x = hist[:, :METHOD_T, :]
+    w = torch.from_numpy(rng.standard_normal((len(ids), synth.PE_DIM)).astype(np.float32))
+    (oracle.fourier_transform_pe(ids, x, 7) * w).sum().backward()
+    (torch.einsum("usp,sp->up", x[torch.from_numpy(ids)], bb.fft_coefficients(METHOD_T, 7)) * w).sum().backward()
+    np.testing.assert_allclose(torch.view_as_real(bb.fft_filter.weight.grad).numpy(), torch.view_as_real(oracle.fft_filter.weight.grad).numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(bb.fft_agg.weight.grad.numpy(), oracle.fft_agg.weight.grad.numpy(), rtol=0, atol=2e-6)
+
+
+def test_product_path_has_no_oracle_import():
+    """The oracle is a checker: nothing under l-step_amd/ may import it, except smoke.py's checker leg."""
+    src_dir = os.path.join(ROOT, "l-step_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for fn in os.listdir(src_dir):
+        if fn.endswith(".py"):
+            hit = pat.search(open(os.path.join(src_dir, fn)).read())
+            assert (hit is None) or fn == "smoke.py", fn
