@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- processed edges/s of the L-STEP training iteration (fwd + bwd + update_pe + Adam) on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line (rank 0).  A step is one training
+iteration of the reference protocol (``train_LSTEP_link_prediction.py:204-311``: FFT splice, 3x combining_pe_raw_feat,
+link predictor, BCE + PE loss, update_pe, history append, backward, Adam) on one batch of synthetic edges, history
+window full (t = T).  Inputs are resident in HBM before the timed region.
+
+Extra objects on the line:
+  roofline      the neighbour-gather kernel (lstep_gather_aggregate_fwd): algorithmic bytes of SURVEY.md 8(d)
+                (sum over rows of 688*(2k + v + 3) + 24k + 8v, k/v counted exactly from the kernel's own per-row
+                counts) / the launch's duration from HIP events recorded on the launch stream, vs 8 TB/s HBM.
+  cpu_baseline  the CPU oracle (oracle/lstep_oracle.py, the parity-checked restatement that executes the reference's op
+                sequence) timed on this box's host cores on a bounded, scaled-down sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def gather_algorithmic_bytes(count: torch.Tensor, K: int, G: int, row_bytes: int = 688) -> float:
+    """per node-call 688*(k + k + v + 3) + 24k + 8v with k = min(c, K), v = min(c, G)."""
+    c = count.to(torch.int64)
+    k = c.clamp(max=K)
+    v = c.clamp(max=G)
+    return float((row_bytes * (2 * k + v + 3) + 24 * k + 8 * v).sum().item())
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """Oracle train iterations on a bounded sample: same degree structure (E/N = 20), K, time_gap, T; smaller N and batch."""
+    from lstep_amd import protocol, synth
+    from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model  # checker / baseline only
+
+    N, E, B, K, G, T = 50_000, 1_000_000, 512, 20, 2000, 100
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    g = synth.make_temporal_graph(N, E, seed=0)
+    node_raw, edge_raw = synth.make_features(N, E, seed=1)
+    model = build_oracle_model(node_raw, edge_raw, OracleNeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N), K, T,
+                               synth.make_state_dict(K, T))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    hist = 0.1 * torch.randn(N + 1, T, synth.PE_DIM, generator=torch.Generator().manual_seed(0))
+    state = protocol.ProtocolState(history=hist)
+    start = E // 2
+    times = []
+    it = 0
+    t_begin = time.perf_counter()
+    while True:
+        sl = slice(start + it * B, start + (it + 1) * B)
+        neg = synth.make_negatives(N, B, seed=it)
+        t0 = time.perf_counter()
+        protocol.train_iteration(model[0], model[1], opt, state, 1000 + it, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], neg, K, G, T)
+        dt = time.perf_counter() - t0
+        if it > 0:  # first iteration = warm-up
+            times.append(dt)
+        it += 1
+        if len(times) >= 2 and (time.perf_counter() - t_begin) > seconds_budget:
+            break
+        if len(times) >= 8:
+            break
+    per_iter = float(np.mean(times))
+    return {"value": B / per_iter, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (reference op sequence) train iteration, synthetic {N} nodes / {E} edges (same E/N as the GPU workload), "
+                      f"batch {B}, K={K}, time_gap={G}, T={T} history full; {len(times)} timed iterations after 1 warm-up, {per_iter * 1e3:.0f} ms each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="synth-1M-20M")
+    ap.add_argument("--time-gap", type=int, default=2000)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from lstep_amd.workload import build_workload
+
+    if world > 1:
+        import torch.distributed as dist
+        from lstep_amd.parallel import DistributedLstep  # dst-sharded engine (RCCL)
+        dist.init_process_group("nccl", device_id=dev)
+    wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0)
+    eng, model = wl.engine, wl.model
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    runner = eng if world == 1 else DistributedLstep(eng, opt)
+    B = wl.batch
+    start = wl.num_edges // 2
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+
+    def step(i):
+        lo = start + i * B * world
+        src, dst, ts, eid = wl.stream.batch(lo, lo + B * world)
+        neg = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
+        return runner.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sink = []
+    model[0].gather_event_sink = sink
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    model[0].gather_event_sink = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = [a.elapsed_time(b) for a, b, _ in sink]
+        bytes_per_launch = [gather_algorithmic_bytes(c, wl.K, wl.G) for _, _, c in sink]
+        avg_ms = float(np.mean(ms))
+        achieved = float(np.mean(bytes_per_launch)) / (avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "processed edges/sec (L-STEP fwd+bwd)",
+            "value": B * world * args.steps / elapsed,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.describe(), "global_batch": B * world, "parallelism": f"dst-sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "gather_aggregate_fwd_kernel<true,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
+                         "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise LstepNativeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the L-STEP HIP ops)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (torch/lib), our library links against
+    # the SONAME libamdhip64.so.7.  Import torch first so that SONAME resolves to the copy torch already mapped;
+    # loading /opt/rocm's copy beside it gives a second runtime that sees no device.
+    import torch  # noqa: F401
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

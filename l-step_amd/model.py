@@ -290,7 +290,16 @@ class LSTEP(nn.Module):
             raise ValueError("node_ids and node_interact_times must have the same length")
         rows = spliced.rows if spliced is not None else None
         slot_of = spliced.slot_of if spliced is not None else None
-        return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of)
+        sink = getattr(self, "gather_event_sink", None)
+        if sink is None:
+            return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of)
+        # bench.py: HIP events on the launch stream around the forward gather launch (roofline.achieved)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of)
+        e1.record()
+        sink.append((e0, e1, out[4]))
+        return out
 
     def _edge_node_tail(self, x_edge, x_node):
         """edge_mlp_1 -> edge_agg (reassociated) -> relu -> edge_mlp_2 ; node_mlp(cat[node, edge])  (models/LSTEP.py:161-170,219)."""
