@@ -85,14 +85,32 @@ class HistoryRing:
         return self.buf[idx].permute(1, 0, 2).contiguous()
 
 
+class _LookupRows(torch.autograd.Function):
+    """``table[ids]`` whose gradient flows to the spliced rows only (their values already live in ``table``).
+
+    Backward is one ``index_add_`` into ``[U + 1, P]``: ids that are not spliced rows land in the extra row U, which is
+    dropped (no data-dependent shapes, no host sync, no sort-based indexing backward on a hot duplicate index)."""
+
+    @staticmethod
+    def forward(ctx, rows, table, slot_of, ids):
+        pos = slot_of[ids].long()
+        ctx.save_for_backward(pos)
+        ctx.u = rows.shape[0]
+        return table[ids]
+
+    @staticmethod
+    def backward(ctx, g):
+        (pos,) = ctx.saved_tensors
+        u = ctx.u
+        acc = torch.zeros((u + 1, g.shape[1]), dtype=g.dtype, device=g.device)
+        acc.index_add_(0, torch.where(pos >= 0, pos, torch.full_like(pos, u)), g)
+        return acc[:u], None, None, None
+
+
 def _lookup_rows(table: torch.Tensor, spliced: SplicedRows, ids: torch.Tensor) -> torch.Tensor:
-    """``table[ids]`` whose gradient flows to the spliced rows only (values already live in ``table``)."""
-    vals = table[ids]
     if spliced is None:
-        return vals
-    pos = spliced.slot_of[ids].long()
-    has = (pos >= 0).unsqueeze(1)
-    return torch.where(has, spliced.rows[pos.clamp(min=0)], vals)
+        return table[ids]
+    return _LookupRows.apply(spliced.rows, table, spliced.slot_of, ids)
 
 
 class LstepEngine:
