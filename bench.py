@@ -45,11 +45,14 @@ def cpu_baseline(seconds_budget: float = 25.0):
     from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model  # checker / baseline only
 
     N, E, B, K, G, T = 50_000, 1_000_000, 512, 20, 2000, 100
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+    # the GPU box gives one GPU a share of 16 host cores; more torch threads than that only oversubscribes
+    # (256 threads ran this sample 20x slower than 8).  `cores` reports the threads actually used.
+    cores = max(1, min(avail, int(os.environ.get("LSTEP_CPU_BASELINE_THREADS", "16"))))
     torch.set_num_threads(cores)
     g = synth.make_temporal_graph(N, E, seed=0)
     node_raw, edge_raw = synth.make_features(N, E, seed=1)
@@ -147,6 +150,16 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        # HBM traffic per launch of the gather kernel: not measurable from inside the process; taken from the committed PMC
+        # passes of this same command (profiles/*pmc_traffic.json, made by tools/pmc_summary.py), default workload only
+        traffic, traffic_src = None, None
+        if args.workload == "synth-1M-20M" and args.batch is None and args.time_gap == 2000:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+            if cands:
+                rec = json.load(open(cands[-1])).get("lstep::gather_aggregate_fwd_kernel<true, true>")
+                if rec:
+                    traffic, traffic_src = rec["traffic_bytes"], os.path.relpath(cands[-1], ROOT)
         ms = [a.elapsed_time(b) for a, b, _ in sink]
         bytes_per_launch = [gather_algorithmic_bytes(c, wl.K, wl.G) for _, _, c in sink]
         avg_ms = float(np.mean(ms))
@@ -166,7 +179,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.describe(), "global_batch": B * world, "parallelism": f"dst-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "gather_aggregate_fwd_kernel<true,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
                          "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
         }
