@@ -108,15 +108,24 @@ def main():
 
     from lstep_amd.workload import build_workload
 
-    if world > 1:
+    # LSTEP_FORCE_DIST=1 runs the distributed engine (RCCL collectives, owner-sharded ring) even on one rank (rehearsal)
+    use_dist = world > 1 or os.environ.get("LSTEP_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
-        from lstep_amd.parallel import DistributedLstep  # dst-sharded engine (RCCL)
+        from lstep_amd.parallel import DistributedLstep  # owner-sharded engine (RCCL)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
-    wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0)
+    wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0, sharded=use_dist)
     eng, model = wl.engine, wl.model
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    runner = eng if world == 1 else DistributedLstep(eng, opt)
+    if not use_dist:
+        runner = eng
+    else:
+        from lstep_amd.workload import prefill_distributed
+        runner = DistributedLstep(eng, opt)
+        prefill_distributed(runner, seed=0)
     B = wl.batch
     start = wl.num_edges // 2
     gen = torch.Generator(device=dev)
@@ -129,7 +138,7 @@ def main():
         return runner.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +153,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     model[0].gather_event_sink = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -177,7 +186,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.describe(), "global_batch": B * world, "parallelism": f"dst-sharded x{world}" if world > 1 else "single GPU"},
+            "config": {"workload": wl.describe(), "global_batch": B * world, "parallelism": f"owner-sharded history + row-sharded batch x{world} (RCCL)" if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "gather_aggregate_fwd_kernel<true,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
@@ -186,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -115,14 +115,15 @@ def _lookup_rows(table: torch.Tensor, spliced: SplicedRows, ids: torch.Tensor) -
 
 class LstepEngine:
     def __init__(self, backbone: LSTEP, predictor: MergeLayer, num_neighbors: int, time_gap: int,
-                 pe_weight: float = 0.5, neg_sample_weight: float = 0.3):
+                 pe_weight: float = 0.5, neg_sample_weight: float = 0.3, make_ring: bool = True):
         self.backbone, self.predictor = backbone, predictor
         self.K, self.G = int(num_neighbors), int(time_gap)
         self.pe_weight, self.neg_sample_weight = pe_weight, neg_sample_weight
         dev = backbone.device
         self.device = dev
         rows = backbone.node_raw_features.shape[0]
-        self.ring = HistoryRing(rows, backbone.pe_dim, backbone.num_fft_batches, dev)
+        # make_ring=False: lstep_amd.parallel.DistributedLstep owns an owner-sharded ring instead
+        self.ring = HistoryRing(rows, backbone.pe_dim, backbone.num_fft_batches, dev) if make_ring else None
         self.slot_of = torch.full((rows,), -1, dtype=torch.int32, device=dev)
 
     # ---- shared pieces

@@ -395,56 +395,56 @@ class LSTEP(nn.Module):
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
-    @torch.no_grad()
-    def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
-                  num_neighbors: int = 30, time_gap: int = 2000):
-        if not (pe.is_cuda and pe.dtype == torch.float32 and pe.is_contiguous()):
-            raise ValueError("update_pe needs a contiguous float32 GPU table (it is mutated in place)")
+    def _segment_sum(self, pe, seg_begin, seg_end, nseg, ent_row, ent_dt):
         lib = nat.load_library()
-        dev = pe.device
         P, D = self.pe_dim, self.time_dim
-        tw, tb = self.time_encoder.w.weight, self.time_encoder.w.bias
-        self._check_rows(node_ids)
-        bn = self._ids(node_ids)
-        src, dst = self._ids(batch_src_node_ids), self._ids(batch_dst_node_ids)
-        t = self._times(node_interact_times)
-        U, B = bn.numel(), src.numel()
-        now32 = float(np.float32(current_time))  # torch.Tensor([current_time]) rounds to float32 first (LSTEP.py:277)
+        out = torch.empty((nseg, P + D), dtype=torch.float32, device=pe.device)
+        with torch.cuda.device(pe.device):
+            nat.check(lib.lstep_segment_pe_time_sum(nat.ptr(pe), P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
+                                                    nat.ptr(seg_begin), nat.ptr(seg_end), nseg, nat.ptr(ent_row), nat.ptr(ent_dt), None,
+                                                    nat.ptr(out), nat.current_stream()))
+        return out
 
-        def segment_sum(seg_begin, seg_end, nseg, ent_row, ent_dt, ent_valid):
-            out = torch.empty((nseg, P + D), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                nat.check(lib.lstep_segment_pe_time_sum(nat.ptr(pe), P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(seg_begin), nat.ptr(seg_end), nseg,
-                                                        nat.ptr(ent_row), nat.ptr(ent_dt), nat.ptr(ent_valid), nat.ptr(out), nat.current_stream()))
-            return out
+    def write_rows(self, pe, ids, rows):
+        """In-place ``pe[ids] = rows`` (models/LSTEP.py:303,339)."""
+        lib = nat.load_library()
+        with torch.cuda.device(pe.device):
+            nat.check(lib.lstep_scatter_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(rows.contiguous()), nat.current_stream()))
 
-        def write_rows(ids, rows):
-            with torch.cuda.device(dev):
-                nat.check(lib.lstep_scatter_rows(nat.ptr(pe), P, nat.ptr(ids), ids.numel(), nat.ptr(rows.contiguous()), nat.current_stream()))
-
-        # ---- phase 1: every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints (LSTEP.py:277-303)
+    @torch.no_grad()
+    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None):
+        """U1 (LSTEP.py:277-303): every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints.
+        Returns (ids, new_rows) WITHOUT writing; ``shard=(W, r)`` restricts the work to nodes with id % W == r."""
         dt1 = (now32 - t).to(torch.float32)                       # float32 scalar - float64 -> float64 -> .float()
         keys = torch.cat([src, dst])
         order = torch.argsort(keys, stable=True)
         keys_s = keys[order]
         ent_row = torch.cat([dst, src])[order].to(torch.int32)
         ent_dt = torch.cat([dt1, dt1])[order].contiguous()
-        seg_begin = torch.searchsorted(keys_s, bn, right=False)
-        seg_end = torch.searchsorted(keys_s, bn, right=True)
-        agg = segment_sum(seg_begin, seg_end, U, ent_row, ent_dt, None)
-        own = pe[bn]
+        ids = bn if shard is None else bn[(bn % shard[0]) == shard[1]]
+        seg_begin = torch.searchsorted(keys_s, ids, right=False)
+        seg_end = torch.searchsorted(keys_s, ids, right=True)
+        agg = self._segment_sum(pe, seg_begin, seg_end, ids.numel(), ent_row, ent_dt)
+        own = pe[ids]
         msg = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg)))
-        write_rows(bn, own + torch.tanh(self.self_update_pe(own) + msg))
+        return ids, own + torch.tanh(self.self_update_pe(own) + msg)
 
-        # ---- phase 2: push the updated PE of each batch node to its K most recent neighbours (LSTEP.py:305-339).
-        # node_ids (U rows) is zipped with the B edge times: row i uses time[i]; rows >= min(U, B) stay padding.
+    @torch.no_grad()
+    def update_pe_phase2(self, pe, bn, t, now32: float, num_neighbors: int, shard=None):
+        """U2 (LSTEP.py:305-339): push the updated PE of each batch node to its K most recent neighbours.
+        ``bn`` (U rows) is zipped with the B edge times: row i uses t[i]; rows >= min(U, B) stay padding.
+        Sets pe[0] = 0 (LSTEP.py:317) before reading.  Returns (touched ids, new rows) WITHOUT writing."""
+        dev = pe.device
+        P, D = self.pe_dim, self.time_dim
+        U = bn.numel()
         nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, num_neighbors)
         key = nbr.reshape(-1)
         rep = bn.unsqueeze(1).expand(U, num_neighbors).reshape(-1)
         dt2 = (torch.tensor(now32, dtype=torch.float32, device=dev) - nt.reshape(-1))   # float32 - float32 (LSTEP.py:314)
-        pe[0] = 0.0                                                                     # (LSTEP.py:317)
+        pe[0] = 0.0
         real = key != 0
-        zeros_per_row = (nbr == 0).sum(dim=1).to(torch.float32)                         # slots that scatter into row 0
+        if shard is not None:
+            real = real & ((key % shard[0]) == shard[1])
         key_r = key[real]
         order = torch.argsort(key_r, stable=True)
         key_s = key_r[order]
@@ -453,14 +453,31 @@ class LSTEP(nn.Module):
         seg_begin = seg_end - counts
         ent_row = rep[real][order].to(torch.int32)
         ent_dt = dt2[real][order].contiguous()
-        agg2 = segment_sum(seg_begin, seg_end, touched.numel(), ent_row, ent_dt, None)
-        if bool((zeros_per_row > 0).any()):
-            # row 0 collects cat[pe[source], 0] from every padded slot: a [U] x [U, P] product instead of a hot segment
-            row0 = torch.zeros((1, P + D), dtype=torch.float32, device=dev)
-            row0[0, :P] = zeros_per_row @ pe[bn]
-            agg2 = torch.cat([row0, agg2], dim=0)
-            touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
+        agg2 = self._segment_sum(pe, seg_begin, seg_end, touched.numel(), ent_row, ent_dt)
+        if shard is None or shard[1] == 0:  # row 0 belongs to shard 0
+            zeros_per_row = (nbr == 0).sum(dim=1).to(torch.float32)                     # slots that scatter into row 0
+            if bool((zeros_per_row > 0).any()):
+                # row 0 collects cat[pe[source], 0] from every padded slot: a [U] x [U, P] product instead of a hot segment
+                row0 = torch.zeros((1, P + D), dtype=torch.float32, device=dev)
+                row0[0, :P] = zeros_per_row @ pe[bn]
+                agg2 = torch.cat([row0, agg2], dim=0)
+                touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
         own2 = pe[touched]
         msg2 = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg2)))
-        write_rows(touched, own2 + torch.tanh(msg2))              # the self_update_pe term is dead code in the reference (:334-335)
+        return touched, own2 + torch.tanh(msg2)       # the self_update_pe term is dead code in the reference (:334-335)
+
+    @torch.no_grad()
+    def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
+                  num_neighbors: int = 30, time_gap: int = 2000):
+        if not (pe.is_cuda and pe.dtype == torch.float32 and pe.is_contiguous()):
+            raise ValueError("update_pe needs a contiguous float32 GPU table (it is mutated in place)")
+        self._check_rows(node_ids)
+        bn = self._ids(node_ids)
+        src, dst = self._ids(batch_src_node_ids), self._ids(batch_dst_node_ids)
+        t = self._times(node_interact_times)
+        now32 = float(np.float32(current_time))  # torch.Tensor([current_time]) rounds to float32 first (LSTEP.py:277)
+        ids, rows = self.update_pe_phase1(pe, bn, src, dst, t, now32)
+        self.write_rows(pe, ids, rows)
+        ids, rows = self.update_pe_phase2(pe, bn, t, now32, num_neighbors)
+        self.write_rows(pe, ids, rows)
         return pe

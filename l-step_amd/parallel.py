@@ -1,0 +1,216 @@
+"""Multi-GPU execution of the L-STEP per-batch protocol: one process per GPU, ``torch.distributed`` (RCCL over xGMI).
+
+The reference is single-process (no collective anywhere); this module is new design.  Within a batch the
+path is independent per destination row, across batches it is strictly sequential (the PE state evolves), so the W ranks
+cooperate on ONE global batch of ``W * B`` edges at a time (weak scaling: B per GPU fixed):
+
+  state       node n is OWNED by rank ``n % W``.  The PE history ring -- the only O(N * T) state (69 GB at 1 M nodes,
+              275 GB at 4 M) -- is sharded by owner: rank r keeps ``[T+1, ceil((N+1-r)/W), P]``.  The current PE table
+              ``[N+1, P]`` (688 MB per 1 M nodes), CSR, feature tables and weights are replicated.
+  FFT splice  rank r filters the history of the batch nodes it owns; the ``[U, P]`` filtered rows are ALL-GATHERED
+              (padded, <= 22 MB per 32 K nodes) and written into every replica of the current table.
+  combine     rank r runs the fused gather + dense tails for ITS B edges (3B rows); the loss is the mean over the
+              global batch, i.e. the mean of the rank means.
+  backward    gradients w.r.t. the spliced rows are ALL-REDUCED, each rank back-propagates its owned rows through its
+              history shard into the filter coefficients; parameter gradients are ALL-REDUCED (one flat bucket, 2.3 MB).
+  update_pe   both phases are sharded by the owner of the UPDATED row (phase 1: batch nodes; phase 2: touched
+              neighbours); the new rows are ALL-GATHERED ("updated positional encodings at snapshot boundaries",
+              BASELINE.json north_star) and written into every replica; each rank appends its owned rows to its ring.
+
+All collectives are small-to-medium one-shot gathers/reductions (no ring-pipelined bulk transfer is needed); the data
+path itself (gathers, GEMMs) has no collective inside.  Results equal the single-GPU engine on the same global batch up
+to fp32 summation order (``tests/test_parallel.py``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .engine import HistoryRing, LstepEngine, _lookup_rows
+from .model import SplicedRows
+
+
+# ---------------------------------------------------------------------------------------------- collectives
+def _staged(t: torch.Tensor, group) -> bool:
+    """gloo has no CUDA all_gather: stage through the host (tests on one GPU); RCCL works on device memory."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_var(t: torch.Tensor, group=None):
+    """All-gather of row blocks with different row counts.  Returns (concatenated rows in rank order, counts list)."""
+    w = dist.get_world_size(group)
+    dev = t.device
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device="cpu" if _staged(t, group) else dev)
+    ns = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(ns, n, group=group)
+    counts = [int(x.item()) for x in ns]
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+    pad[: t.shape[0]] = t
+    if _staged(t, group):
+        pad = pad.cpu()
+    outs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(outs, pad, group=group)
+    cat = torch.cat([o[:c] for o, c in zip(outs, counts)], dim=0)
+    return cat.to(dev), counts
+
+
+def all_reduce_sum(t: torch.Tensor, group=None):
+    if _staged(t, group):
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def all_reduce_gradients(params, group=None):
+    """One flat bucket for all parameter gradients (complex ones viewed as real); missing grads count as zero."""
+    views = []
+    for p in params:
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        views.append(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad)
+    flat = torch.cat([v.reshape(-1) for v in views])
+    all_reduce_sum(flat, group)
+    off = 0
+    for v in views:
+        n = v.numel()
+        v.copy_(flat[off:off + n].view_as(v))
+        off += n
+
+
+def owned_rows(num_rows: int, world: int, rank: int) -> int:
+    """Number of node ids in [0, num_rows) with id % world == rank."""
+    return (num_rows - rank + world - 1) // world if num_rows > rank else 0
+
+
+# ---------------------------------------------------------------------------------------------- engine
+class DistributedLstep:
+    """Drives one ``LstepEngine``'s model over a global batch shared by all ranks of ``group``."""
+
+    def __init__(self, engine: LstepEngine, optimizer=None, group=None):
+        self.eng = engine
+        self.bb, self.predictor = engine.backbone, engine.predictor
+        self.group = group
+        self.W, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.K, self.G = engine.K, engine.G
+        dev = engine.device
+        self.device = dev
+        rows = self.bb.node_raw_features.shape[0]
+        self.num_rows = rows
+        self.ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
+        self.table = torch.zeros((rows, self.bb.pe_dim), dtype=torch.float32, device=dev)  # replicated current PE
+        self.slot_of = engine.slot_of
+        engine.ring = None  # the unsharded ring is not used (and must not be allocated at scale)
+
+    # ---- state import/export (tests, checkpoints)
+    def load_history(self, history: torch.Tensor):
+        """Adopt a reference-shaped ``[N+1, t, P]`` history: this rank keeps its owned rows."""
+        self.ring.load(history[self.rank::self.W])
+        if history.shape[1]:
+            self.table.copy_(history[:, -1, :])
+
+    def _append_snapshot(self):
+        self.ring.spare().copy_(self.table[self.rank::self.W])
+        self.ring.commit()
+
+    # ---- pieces
+    def _splice(self, bn: torch.Tensor, batch_idx: int):
+        """Owner-sharded FFT filter + all-gather of the filtered rows; returns (local rows with grad, leaf of all rows, perm)."""
+        own = (bn % self.W) == self.rank
+        mine = bn[own]
+        rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx)
+        gathered, counts = all_gather_var(rows_mine.detach(), self.group)
+        # gathered is ordered by (owner rank, node id); bn is ordered by node id
+        order = torch.argsort(bn % self.W, stable=True)
+        rows_all = torch.empty_like(gathered)
+        rows_all[order] = gathered
+        self.table.index_copy_(0, bn, rows_all)
+        self.slot_of[bn] = torch.arange(bn.numel(), dtype=torch.int32, device=self.device)
+        leaf = rows_all.detach().requires_grad_(True)
+        return rows_mine, leaf, own
+
+    def _probabilities(self, a, b):
+        return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
+
+    def _update(self, bn, src, dst, ts):
+        now32 = float(np.float32(float(ts.max().item())))
+        shard = (self.W, self.rank)
+        ids, rows = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard)
+        ids_all, _ = all_gather_var(ids, self.group)
+        rows_all, _ = all_gather_var(rows, self.group)
+        self.bb.write_rows(self.table, ids_all, rows_all)
+        ids, rows = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
+        ids_all, _ = all_gather_var(ids, self.group)
+        rows_all, _ = all_gather_var(rows, self.group)
+        self.bb.write_rows(self.table, ids_all, rows_all)
+
+    # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
+    def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):
+        n_glob = src.numel()
+        assert n_glob % self.W == 0, "global batch must divide by the world size"
+        b = n_glob // self.W
+        sl = slice(self.rank * b, (self.rank + 1) * b)
+        bn = torch.unique(torch.cat([src, dst]))
+        out, loss = None, None
+        if batch_idx == 0:
+            self.table.copy_(initial_pe)
+        else:
+            rows_mine, leaf, own = self._splice(bn, batch_idx)
+            spliced = SplicedRows(leaf, self.slot_of)
+            s_, d_, n_, t_ = src[sl], dst[sl], neg_dst[sl], ts[sl]
+            emb = self.bb.combining_pe_raw_feat(self.table, torch.cat([s_, d_, n_]), torch.cat([t_, t_, t_]), self.K, self.G, spliced=spliced)
+            pos_src, pos_dst, neg_emb = emb[:b], emb[b:2 * b], emb[2 * b:]
+            p_pos = self._probabilities(pos_src, pos_dst)
+            p_neg = self._probabilities(pos_src, neg_emb)
+            predicts = torch.cat([p_pos, p_neg], dim=0)
+            labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
+            lp_loss = F.binary_cross_entropy(predicts, labels)
+            e_src = _lookup_rows(self.table, spliced, s_)
+            pe_loss = F.mse_loss(e_src, _lookup_rows(self.table, spliced, d_)) - self.eng.neg_sample_weight * F.mse_loss(e_src, _lookup_rows(self.table, spliced, n_))
+            loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
+            out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
+        self._update(bn, src, dst, ts)
+        if batch_idx == 0 and initial_pe is not None:
+            initial_pe.copy_(self.table)
+        self._append_snapshot()
+        if loss is not None:
+            optimizer.zero_grad()
+            (loss / self.W).backward()                       # global mean = mean of the rank means
+            g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+            all_reduce_sum(g_rows, self.group)               # every rank's loss touches every spliced row
+            if rows_mine.numel():
+                rows_mine.backward(g_rows[own])              # -> fft_filter / fft_agg through this rank's history shard
+            all_reduce_gradients(list(self.bb.parameters()) + list(self.predictor.parameters()), self.group)
+            optimizer.step()
+            self.slot_of[bn] = -1
+            # losses reported as global means
+            for k in ("lp_loss", "pe_loss", "loss"):
+                v = out[k].clone().reshape(1)
+                all_reduce_sum(v, self.group)
+                out[k] = (v / self.W).reshape(())
+        return out
+
+    # ---- evaluate_model_utils.py:38-142 on a global batch (call under torch.no_grad())
+    def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst):
+        n_glob = src.numel()
+        b = n_glob // self.W
+        sl = slice(self.rank * b, (self.rank + 1) * b)
+        bn = torch.unique(torch.cat([src, dst]))
+        self._splice(bn, batch_idx)
+        self.slot_of[bn] = -1
+        ids = torch.cat([src[sl], dst[sl], neg_src[sl], neg_dst[sl]])
+        emb = self.bb.combining_pe_raw_feat(self.table, ids, torch.cat([ts[sl]] * 4), self.K, self.G)
+        p_pos = self._probabilities(emb[:b], emb[b:2 * b])
+        p_neg = self._probabilities(emb[2 * b:3 * b], emb[3 * b:])
+        predicts = torch.cat([p_pos, p_neg], dim=0)
+        labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
+        self._update(bn, src, dst, ts)
+        self._append_snapshot()
+        return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

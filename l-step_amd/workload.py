@@ -45,7 +45,9 @@ class Workload:
                 f"batch_size={self.batch}, num_neighbors={self.K}, time_gap={self.G}, num_fft_batches={self.T}, recent sampling")
 
 
-def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int = 100, seed: int = 0, batch: int = None) -> Workload:
+def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int = 100, seed: int = 0, batch: int = None,
+                   sharded: bool = False) -> Workload:
+    """``sharded=True`` (multi-GPU): no full history ring is allocated; ``prefill_distributed`` fills the owner shards."""
     n, e, b, k = WORKLOADS[name]
     if batch is not None:
         b = batch
@@ -67,10 +69,24 @@ def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int
                num_fft_batches=num_fft_batches, device=dev)
     pred = MergeLayer(synth.FEAT_DIM, synth.FEAT_DIM, synth.FEAT_DIM, 1).to(dev)
     model = torch.nn.Sequential(bb, pred)
-    eng = LstepEngine(bb, pred, k, time_gap)
-    # steady state: the window already holds T snapshots
-    ring = eng.ring
-    for s in range(ring.T):
-        ring.buf[s].normal_(0.0, 0.1, generator=gen)
-    ring.start, ring.len = 0, ring.T
+    eng = LstepEngine(bb, pred, k, time_gap, make_ring=not sharded)
+    if not sharded:
+        # steady state: the window already holds T snapshots
+        ring = eng.ring
+        for s in range(ring.T):
+            ring.buf[s].normal_(0.0, 0.1, generator=gen)
+        ring.start, ring.len = 0, ring.T
     return Workload(name, n, e, b, k, time_gap, num_fft_batches, EdgeStream(src, dst, ts, eid), model, eng, sampler)
+
+
+def prefill_distributed(dl, seed: int = 0):
+    """Steady-state history for ``DistributedLstep``: identical current table on every rank, T snapshots per owner shard."""
+    gen = torch.Generator(device=dl.device)
+    gen.manual_seed(seed + 17)
+    dl.table.normal_(0.0, 0.1, generator=gen)           # same seed on every rank -> identical replicas
+    ring = dl.ring
+    gen.manual_seed(seed + 1000 + dl.rank)
+    for s in range(ring.T - 1):
+        ring.buf[s].normal_(0.0, 0.1, generator=gen)
+    ring.buf[ring.T - 1].copy_(dl.table[dl.rank::dl.W])  # newest snapshot = the current table's owned rows
+    ring.start, ring.len = 0, ring.T

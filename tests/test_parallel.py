@@ -1,0 +1,131 @@
+"""Multi-process tests of lstep_amd.parallel.
+
+* CPU (gloo, world_size 2): the collective helpers the distributed engine is built from.
+* GPU (gloo over CUDA tensors staged through the host, 2 ranks on the one GPU of the test box): the owner-sharded
+  engine must reproduce the SAME golden training / evaluation trace as the reference (tests/golden/traces.npz).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import TRACE_B, TRACE_BATCHES, TRACE_G, TRACE_K, TRACE_START, TRACE_T, eval_batches, trace_batches, trace_inputs
+from lstep_amd import synth
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _cpu_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        from lstep_amd.parallel import all_gather_var, all_reduce_gradients, all_reduce_sum, owned_rows
+        # uneven row blocks, incl. an empty one
+        t = torch.arange(rank * 3 * 4, dtype=torch.float32).reshape(rank * 3, 4) + 100 * rank
+        cat, counts = all_gather_var(t)
+        assert counts == [0, 3] and cat.shape == (3, 4) and torch.equal(cat, torch.arange(12, dtype=torch.float32).reshape(3, 4) + 100)
+        ids = torch.tensor([5, 7, 9][: rank + 1], dtype=torch.int64)
+        cat, counts = all_gather_var(ids)
+        assert cat.tolist() == [5, 5, 7] and counts == [1, 2]
+        v = torch.full((3,), float(rank + 1))
+        assert all_reduce_sum(v).tolist() == [3.0, 3.0, 3.0]
+        lin = torch.nn.Linear(3, 2)
+        cplx = torch.nn.Parameter(torch.zeros(2, 2, dtype=torch.complex64))
+        lin.weight.grad = torch.full_like(lin.weight, rank + 1.0)      # bias.grad stays None -> treated as zero
+        cplx.grad = torch.full((2, 2), complex(rank + 1.0, -rank), dtype=torch.complex64)
+        all_reduce_gradients(list(lin.parameters()) + [cplx])
+        assert torch.all(lin.weight.grad == 3.0) and torch.all(lin.bias.grad == 0.0) and torch.all(cplx.grad == complex(3.0, -1.0))
+        assert [owned_rows(65, 2, r) for r in (0, 1)] == [33, 32] and sum(owned_rows(1000001, 8, r) for r in range(8)) == 1000001
+        assert owned_rows(1, 4, 3) == 0
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def _run(worker, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_collective_helpers_gloo_world2():
+    _run(_cpu_worker, 2)
+
+
+def _gpu_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+        from lstep_amd.engine import EdgeStream, LstepEngine
+        from lstep_amd.parallel import DistributedLstep, all_gather_var
+        from lstep_amd.sampler import NeighborSampler
+        from lstep_amd.smoke import build_hip_model
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces.npz"))
+        g, node_raw, edge_raw, pe0 = trace_inputs()
+        sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=g["num_nodes"], device=dev)
+        model = build_hip_model(node_raw, edge_raw, sampler, TRACE_K, TRACE_T, synth.make_state_dict(TRACE_K, TRACE_T), dev)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        dl = DistributedLstep(LstepEngine(model[0], model[1], TRACE_K, TRACE_G, make_ring=False), opt)
+        assert dl.ring.rows == (33 if rank == 0 else 32)
+        stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], dev)
+        init = torch.from_numpy(pe0.copy()).to(dev)
+        tol = dict(rtol=0, atol=5e-5)
+        half = TRACE_B // world
+
+        def global_predicts(local):  # rank-local [pos(b), neg(b)] -> global [pos(B), neg(B)]
+            cat, _ = all_gather_var(local.reshape(2, half))   # rows: r0 pos, r0 neg, r1 pos, r1 neg
+            cat = cat.reshape(world, 2, half)
+            return torch.cat([cat[:, 0, :].reshape(-1), cat[:, 1, :].reshape(-1)]).cpu().numpy()
+
+        for b, (src, dst, t, eid, neg) in enumerate(trace_batches(g)):
+            lo = TRACE_START + b * TRACE_B
+            res = dl.train_iteration(opt, b, *stream.batch(lo, lo + TRACE_B), torch.from_numpy(neg).to(dev), initial_pe=init)
+            np.testing.assert_allclose(dl.table.cpu().numpy(), z[f"train/b{b}/snapshot"], **tol)
+            np.testing.assert_allclose(dl.ring.last().cpu().numpy(), z[f"train/b{b}/snapshot"][rank::world], **tol)
+            if res is not None:
+                got = [float(res["lp_loss"]), float(res["pe_loss"]), float(res["loss"])]
+                np.testing.assert_allclose(got, z[f"train/b{b}/losses"], rtol=0, atol=2e-5)
+                np.testing.assert_allclose(global_predicts(res["predicts"]), z[f"train/b{b}/predicts"], **tol)
+        np.testing.assert_allclose(dl.ring.as_reference_tensor().cpu().numpy(), z["train/final_history"][rank::world, -TRACE_T:, :], **tol)
+        model.eval()
+        with torch.no_grad():
+            for b, (src, dst, t, eid, neg_src, neg_dst) in enumerate(eval_batches(g)):
+                lo = TRACE_START + (TRACE_BATCHES + b) * TRACE_B
+                res = dl.eval_iteration(b, *stream.batch(lo, lo + TRACE_B), torch.from_numpy(neg_src).to(dev), torch.from_numpy(neg_dst).to(dev))
+                np.testing.assert_allclose(global_predicts(res["predicts"]), z[f"eval/b{b}/predicts"], **tol)
+                np.testing.assert_allclose(dl.table.cpu().numpy(), z[f"eval/b{b}/snapshot"], **tol)
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+def test_distributed_engine_reproduces_golden_trace_2_ranks_one_gpu():
+    assert torch.cuda.is_available()
+    _run(_gpu_worker, 2)
