@@ -131,6 +131,10 @@ int lstep_segment_pe_time_sum(const float* pe, int32_t pe_dim, const float* time
 int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* rows,
                        void* stream);
 
+/* Fused residual update + in-place write: table[ids[i], :] += tanh(z[i, :]) (models/LSTEP.py:299-303 with
+ * z = self_update_pe(own) + pe_mlp_2(...); :335-339 with z = pe_mlp_2(...)). ids must be unique. */
+int lstep_residual_tanh_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* z, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,7 @@ SIGNATURES = {
     "lstep_history_filter_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
     "lstep_segment_pe_time_sum": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
+    "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
 }
 
 

@@ -63,6 +63,20 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(float* __restrict_
     for (int c = lane; c < (W >> 2); c += kWave) st4(table + r * W + c * 4, ld4(rows + i * W + c * 4));
 }
 
+// table[ids[i], :] += tanh(z[i, :])   (residual PE update of models/LSTEP.py:299-303 and :335-339, fused with the write)
+__global__ __launch_bounds__(kBlock) void residual_tanh_rows_kernel(float* __restrict__ table, int W, const int64_t* __restrict__ ids,
+                                                                     int64_t num_ids, const float* __restrict__ z) {
+    const int lane = lane_id();
+    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (i >= num_ids) return;
+    const int64_t r = ids[i];
+    for (int c = lane; c < (W >> 2); c += kWave) {
+        const float4 a = ld4(table + r * W + c * 4);
+        const float4 b = ld4(z + i * W + c * 4);
+        st4(table + r * W + c * 4, make_float4(a.x + tanhf(b.x), a.y + tanhf(b.y), a.z + tanhf(b.z), a.w + tanhf(b.w)));
+    }
+}
+
 }  // namespace lstep
 
 using namespace lstep;
@@ -88,4 +102,13 @@ extern "C" int lstep_scatter_rows(float* table, int32_t width, const int64_t* id
     const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, ids, num_ids, rows);
     return check_launch("scatter_rows_kernel");
+}
+
+extern "C" int lstep_residual_tanh_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* z, void* stream) {
+    if (num_ids < 0 || width <= 0 || (width & 3)) return set_error(LSTEP_EINVAL, "lstep_residual_tanh_rows: bad sizes");
+    if (num_ids == 0) return LSTEP_OK;
+    if (!table || !ids || !z) return set_error(LSTEP_EINVAL, "lstep_residual_tanh_rows: NULL pointer");
+    const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(residual_tanh_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, ids, num_ids, z);
+    return check_launch("residual_tanh_rows_kernel");
 }

@@ -88,8 +88,8 @@ class HistoryRing:
 class _LookupRows(torch.autograd.Function):
     """``table[ids]`` whose gradient flows to the spliced rows only (their values already live in ``table``).
 
-    Backward is one ``index_add_`` into ``[U + 1, P]``: ids that are not spliced rows land in the extra row U, which is
-    dropped (no data-dependent shapes, no host sync, no sort-based indexing backward on a hot duplicate index)."""
+    Backward is one ``index_add_`` into ``[U + n, P]``: ids that are not spliced rows land in private dummy rows past U,
+    which are dropped (no data-dependent shapes, no host sync, no hot duplicate index for the atomics)."""
 
     @staticmethod
     def forward(ctx, rows, table, slot_of, ids):
@@ -102,8 +102,10 @@ class _LookupRows(torch.autograd.Function):
     def backward(ctx, g):
         (pos,) = ctx.saved_tensors
         u = ctx.u
-        acc = torch.zeros((u + 1, g.shape[1]), dtype=g.dtype, device=g.device)
-        acc.index_add_(0, torch.where(pos >= 0, pos, torch.full_like(pos, u)), g)
+        n = pos.numel()
+        acc = torch.zeros((u + n, g.shape[1]), dtype=g.dtype, device=g.device)
+        dump = torch.arange(u, u + n, device=g.device)        # ids that are not spliced rows: one private dummy row each
+        acc.index_add_(0, torch.where(pos >= 0, pos, dump), g)
         return acc[:u], None, None, None
 
 
@@ -140,11 +142,20 @@ class LstepEngine:
     def _probabilities(self, a, b):
         return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
 
+    @staticmethod
+    def batch_nodes_and_segments(src, dst):
+        """One stable sort of cat[src, dst] gives the sorted unique batch nodes (train:221-222) AND the per-node segments
+        of update_pe phase 1 (entries grouped by receiving endpoint)."""
+        keys_s, order = torch.sort(torch.cat([src, dst]), stable=True)
+        nodes, counts = torch.unique_consecutive(keys_s, return_counts=True)
+        seg_end = torch.cumsum(counts, 0)
+        return nodes, (order, seg_end - counts, seg_end)
+
     # ---- train:204-311
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):
         bb, ring = self.backbone, self.ring
         out, loss = None, None
-        batch_nodes = torch.unique(torch.cat([src, dst]))
+        batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)
         if batch_idx == 0:
             cur = ring.spare()
             cur.copy_(initial_pe)
@@ -164,7 +175,8 @@ class LstepEngine:
             loss = (1.0 - self.pe_weight) * lp_loss + self.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
         bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                     node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G)
+                     node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G,
+                     presorted=presorted)
         if batch_idx == 0 and initial_pe is not None:
             initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
         ring.commit()

@@ -328,9 +328,31 @@ class LSTEP(nn.Module):
                               spliced: SplicedRows = None):
         x_edge, x_node, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, time_gap,
                                                     nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced)
-        h = self._edge_node_tail(x_edge, x_node)
-        q = self._pe_tail(x_pe, own)
-        return self.out_node_emb(torch.cat([h, q], dim=-1))
+        return self._combined_tail(x_edge, x_node, x_pe, own)
+
+    def _combined_tail(self, x_edge, x_node, x_pe, own):
+        """All dense layers after the gather stage, with the purely linear stretches pre-multiplied.
+
+        After the relu of the edge channel nothing non-linear touches the A/N branch any more
+        (edge_mlp_2 -> node_mlp -> out_node_emb, models/LSTEP.py:170,219,264), so
+            out = Wo_a (Wn_a x_node + Wn_b (W2 relu(h1) + b2) + bn) + Wo_b q + bo
+                = [Wo_a Wn_a | Wo_a Wn_b W2 | Wo_b] . cat[x_node, relu(h1), q] + const
+        is ONE [616 -> 172] GEMM instead of three (272->272, 444->172, 344->172); likewise
+        self_update_neighbor_pe(own) + pe_neighbor_mlp_2(relu(p1)) is one [344 -> 172] GEMM.  The composed matrices
+        are rebuilt from the live parameters every call (25 MFLOP), so autograd yields the gradients of the original
+        parameters; state_dict is unchanged.  Exact in real arithmetic, <= 1e-6 in fp32 (golden-checked)."""
+        Fd = self.feat_dim
+        a = self.edge_agg.weight.reshape(-1)
+        h1 = torch.relu(F.linear(x_edge, self.edge_mlp_1.weight, a.sum() * self.edge_mlp_1.bias + self.edge_agg.bias))
+        p1 = torch.relu(self.pe_neighbor_mlp_1(x_pe))
+        w_q = torch.cat([self.self_update_neighbor_pe.weight, self.pe_neighbor_mlp_2.weight], dim=1)
+        q = own + torch.tanh(F.linear(torch.cat([own, p1], dim=-1), w_q, self.self_update_neighbor_pe.bias + self.pe_neighbor_mlp_2.bias))
+        wo_a, wo_b = self.out_node_emb.weight[:, :Fd], self.out_node_emb.weight[:, Fd:]
+        wn_a, wn_b = self.node_mlp.weight[:, :Fd], self.node_mlp.weight[:, Fd:]
+        wo_wnb = wo_a @ wn_b                                                   # [F, C]
+        w_all = torch.cat([wo_a @ wn_a, wo_wnb @ self.edge_mlp_2.weight, wo_b], dim=1)   # [F, F + C + P]
+        const = wo_wnb @ self.edge_mlp_2.bias + wo_a @ self.node_mlp.bias + self.out_node_emb.bias
+        return F.linear(torch.cat([x_node, h1, q], dim=-1), w_all, const)
 
     def compute_src_dst_node_temporal_embeddings(self, pe, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20,
                                                  time_gap: int = 2000, spliced: SplicedRows = None):
@@ -411,29 +433,44 @@ class LSTEP(nn.Module):
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_scatter_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(rows.contiguous()), nat.current_stream()))
 
+    def apply_residual_tanh(self, pe, ids, z):
+        """In-place ``pe[ids] += tanh(z)``: residual + tanh + row write of models/LSTEP.py:299-303 / :335-339 in one kernel."""
+        lib = nat.load_library()
+        with torch.cuda.device(pe.device):
+            nat.check(lib.lstep_residual_tanh_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(z.contiguous()), nat.current_stream()))
+
     @torch.no_grad()
-    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None):
+    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None):
         """U1 (LSTEP.py:277-303): every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints.
-        Returns (ids, new_rows) WITHOUT writing; ``shard=(W, r)`` restricts the work to nodes with id % W == r."""
+        Returns (ids, z) with the new row = pe[ids] + tanh(z), WITHOUT writing; ``shard=(W, r)`` restricts the work to
+        nodes with id % W == r; ``presorted=(order, seg_begin, seg_end)`` reuses the caller's stable sort of cat[src, dst]
+        (the engine derives the batch-node set and the segments from one sort)."""
         dt1 = (now32 - t).to(torch.float32)                       # float32 scalar - float64 -> float64 -> .float()
-        keys = torch.cat([src, dst])
-        order = torch.argsort(keys, stable=True)
-        keys_s = keys[order]
+        if presorted is None:
+            keys = torch.cat([src, dst])
+            keys_s, order = torch.sort(keys, stable=True)
+            ids = bn if shard is None else bn[(bn % shard[0]) == shard[1]]
+            seg_begin = torch.searchsorted(keys_s, ids, right=False)
+            seg_end = torch.searchsorted(keys_s, ids, right=True)
+        else:
+            order, seg_begin, seg_end = presorted
+            ids = bn
+            if shard is not None:
+                keep = (bn % shard[0]) == shard[1]
+                ids, seg_begin, seg_end = bn[keep], seg_begin[keep], seg_end[keep]
         ent_row = torch.cat([dst, src])[order].to(torch.int32)
         ent_dt = torch.cat([dt1, dt1])[order].contiguous()
-        ids = bn if shard is None else bn[(bn % shard[0]) == shard[1]]
-        seg_begin = torch.searchsorted(keys_s, ids, right=False)
-        seg_end = torch.searchsorted(keys_s, ids, right=True)
-        agg = self._segment_sum(pe, seg_begin, seg_end, ids.numel(), ent_row, ent_dt)
+        agg = self._segment_sum(pe, seg_begin.contiguous(), seg_end.contiguous(), ids.numel(), ent_row, ent_dt)
         own = pe[ids]
-        msg = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg)))
-        return ids, own + torch.tanh(self.self_update_pe(own) + msg)
+        z = self.self_update_pe(own) + self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg)))
+        return ids, z
 
     @torch.no_grad()
     def update_pe_phase2(self, pe, bn, t, now32: float, num_neighbors: int, shard=None):
         """U2 (LSTEP.py:305-339): push the updated PE of each batch node to its K most recent neighbours.
         ``bn`` (U rows) is zipped with the B edge times: row i uses t[i]; rows >= min(U, B) stay padding.
-        Sets pe[0] = 0 (LSTEP.py:317) before reading.  Returns (touched ids, new rows) WITHOUT writing."""
+        Sets pe[0] = 0 (LSTEP.py:317) before reading.  Returns (touched ids, z) with new row = pe[id] + tanh(z), WITHOUT
+        writing (the self_update_pe term is dead code in the reference, :334-335)."""
         dev = pe.device
         P, D = self.pe_dim, self.time_dim
         U = bn.numel()
@@ -446,29 +483,32 @@ class LSTEP(nn.Module):
         if shard is not None:
             real = real & ((key % shard[0]) == shard[1])
         key_r = key[real]
-        order = torch.argsort(key_r, stable=True)
-        key_s = key_r[order]
+        key_s, order = torch.sort(key_r, stable=True)
         touched, counts = torch.unique_consecutive(key_s, return_counts=True)
         seg_end = torch.cumsum(counts, 0)
         seg_begin = seg_end - counts
         ent_row = rep[real][order].to(torch.int32)
         ent_dt = dt2[real][order].contiguous()
-        agg2 = self._segment_sum(pe, seg_begin, seg_end, touched.numel(), ent_row, ent_dt)
+        nseg = touched.numel()
+        with_row0 = False
         if shard is None or shard[1] == 0:  # row 0 belongs to shard 0
-            zeros_per_row = (nbr == 0).sum(dim=1).to(torch.float32)                     # slots that scatter into row 0
-            if bool((zeros_per_row > 0).any()):
-                # row 0 collects cat[pe[source], 0] from every padded slot: a [U] x [U, P] product instead of a hot segment
-                row0 = torch.zeros((1, P + D), dtype=torch.float32, device=dev)
-                row0[0, :P] = zeros_per_row @ pe[bn]
-                agg2 = torch.cat([row0, agg2], dim=0)
-                touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
-        own2 = pe[touched]
-        msg2 = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg2)))
-        return touched, own2 + torch.tanh(msg2)       # the self_update_pe term is dead code in the reference (:334-335)
+            zeros_per_row = (nbr == 0).sum(dim=1)                                       # slots that scatter into row 0
+            with_row0 = bool((zeros_per_row > 0).any())
+        if with_row0:
+            # row 0 collects cat[pe[source], 0] from every padded slot: a weighted column sum instead of a hot segment.
+            # It goes first (ids are sorted): segment 0 is empty and its aggregate is filled in afterwards.
+            zero = torch.zeros(1, dtype=torch.int64, device=dev)
+            seg_begin, seg_end, touched = torch.cat([zero, seg_begin]), torch.cat([zero, seg_end]), torch.cat([zero, touched])
+            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg + 1, ent_row, ent_dt)
+            agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
+        else:
+            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg, ent_row, ent_dt)
+        z = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg2)))
+        return touched, z
 
     @torch.no_grad()
     def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
-                  num_neighbors: int = 30, time_gap: int = 2000):
+                  num_neighbors: int = 30, time_gap: int = 2000, presorted=None):
         if not (pe.is_cuda and pe.dtype == torch.float32 and pe.is_contiguous()):
             raise ValueError("update_pe needs a contiguous float32 GPU table (it is mutated in place)")
         self._check_rows(node_ids)
@@ -476,8 +516,8 @@ class LSTEP(nn.Module):
         src, dst = self._ids(batch_src_node_ids), self._ids(batch_dst_node_ids)
         t = self._times(node_interact_times)
         now32 = float(np.float32(current_time))  # torch.Tensor([current_time]) rounds to float32 first (LSTEP.py:277)
-        ids, rows = self.update_pe_phase1(pe, bn, src, dst, t, now32)
-        self.write_rows(pe, ids, rows)
-        ids, rows = self.update_pe_phase2(pe, bn, t, now32, num_neighbors)
-        self.write_rows(pe, ids, rows)
+        ids, z = self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted)
+        self.apply_residual_tanh(pe, ids, z)
+        ids, z = self.update_pe_phase2(pe, bn, t, now32, num_neighbors)
+        self.apply_residual_tanh(pe, ids, z)
         return pe

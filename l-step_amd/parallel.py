@@ -142,14 +142,14 @@ class DistributedLstep:
     def _update(self, bn, src, dst, ts):
         now32 = float(np.float32(float(ts.max().item())))
         shard = (self.W, self.rank)
-        ids, rows = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard)
-        ids_all, _ = all_gather_var(ids, self.group)
-        rows_all, _ = all_gather_var(rows, self.group)
-        self.bb.write_rows(self.table, ids_all, rows_all)
-        ids, rows = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
-        ids_all, _ = all_gather_var(ids, self.group)
-        rows_all, _ = all_gather_var(rows, self.group)
-        self.bb.write_rows(self.table, ids_all, rows_all)
+        for phase in (1, 2):
+            if phase == 1:
+                ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard)
+            else:
+                ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
+            ids_all, _ = all_gather_var(ids, self.group)
+            z_all, _ = all_gather_var(z, self.group)
+            self.bb.apply_residual_tanh(self.table, ids_all, z_all)   # every replica applies the same residual update
 
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):

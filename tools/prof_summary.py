@@ -46,6 +46,25 @@ def main():
     print(f"# {'us/iter':>10} {'calls/iter':>10} {'avg us':>9}  kernel")
     for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[: a.top]:
         print(f"{d / n_iter / 1e3:12.1f} {c / n_iter:10.1f} {d / c / 1e3:9.1f}  {k}")
+    cats = collections.defaultdict(lambda: [0.0, 0])
+    for k, (d, c) in agg.items():
+        if k.startswith("Cijk"):
+            g = "GEMM (hipBLASLt via torch)"
+        elif "lstep::" in k:
+            g = "lstep:" + k.split("lstep::")[1].split("(")[0]
+        elif "rocprim" in k or "sort" in k.lower():
+            g = "torch sort/scan (rocprim)"
+        elif "copyBuffer" in k or "fillBuffer" in k:
+            g = "memcpy/memset"
+        elif "multi_tensor" in k:
+            g = "Adam"
+        else:
+            g = "torch elementwise/index/reduce"
+        cats[g][0] += d
+        cats[g][1] += c
+    print("# by category")
+    for g, (d, c) in sorted(cats.items(), key=lambda kv: -kv[1][0]):
+        print(f"{d / n_iter / 1e3:12.1f} {c / n_iter:10.1f}             {g}")
 
 
 if __name__ == "__main__":
