@@ -14,11 +14,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
-LIB_PATH = os.path.join(CSRC, "liblstep_hip.so")
+LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
 SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
+ABI_VERSION = 2
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -70,15 +71,15 @@ SIGNATURES = {
     "lstep_sample_recent": (C.c_int, [C.POINTER(CsrStruct), _P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "lstep_time_encode": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P, _P]),
     "lstep_gather_aggregate_fwd": (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32,
-                                             _I32, _U32, _P, _P, _P, _P, _P, _P]),
+                                             _I32, _U32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "lstep_gather_aggregate_bwd": (C.c_int, [C.POINTER(CsrStruct), _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32, _P, _P, _P,
-                                             _P, _P, _P, _P]),
+                                             _I32, _I32, _I32, _P, _P, _P, _P]),
     "lstep_history_filter_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
     "lstep_history_filter_bwd_chunks": (_I64, [_I64]),
     "lstep_history_filter_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
-    "lstep_segment_pe_time_sum": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "lstep_segment_pe_time_sum": (C.c_int, [_P, _I32, _P, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _I32, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
-    "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
+    "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
 }
 
 
@@ -101,7 +102,7 @@ def load_library():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.lstep_abi_version() != 1:
+    if lib.lstep_abi_version() != ABI_VERSION:
         raise LstepNativeError("liblstep_hip.so ABI version mismatch; rebuild")
     _LIB = lib
     return lib

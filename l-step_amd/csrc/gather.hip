@@ -29,9 +29,17 @@ struct GatherParams {
     float* out_pe;
     float* out_self;
     int32_t* out_count;
+    int ld_edge, ld_node, ld_pe, ld_self;  // row strides (floats) of the four outputs; columns past the width are zeroed
 };
 
-constexpr int kRowsInFlight = 8;
+// zero the padding columns [width, ld) of one output row (ld - width < 64 floats, multiples of 4)
+__device__ __forceinline__ void zero_tail(float* row, int width, int ld, int lane) {
+    const int c = width + lane * 4;
+    if (c < ld) st4(row + c, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+constexpr int kRowsInFlight = 8;      // edge rows + PE rows per group (2 x 8 loads in flight per wave)
+constexpr int kNodeRowsInFlight = 8;  // node rows per group
 
 template <bool kEdgeNode, bool kPe>
 __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherParams p) {
@@ -70,37 +78,52 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             dt = delta_t(t, p.csr.ts[e]);
             if (kEdgeNode) aw = p.edge_agg_w[npad + c0 + lane];
         }
+        // Settle the slot metadata BEFORE the row loop: otherwise hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front
+        // of every v_readlane of these registers inside the loop and the row loads of a group serialise.
+        settle(nb ^ ed ^ __float_as_int(dt) ^ __float_as_int(aw));
         for (int j = 0; j < m; j += kRowsInFlight) {
-            float4 re[kRowsInFlight], rp[kRowsInFlight];
-            float wj[kRowsInFlight];
+            int64_t ej[kRowsInFlight], nj[kRowsInFlight];
+            float wj[kRowsInFlight], lj[kRowsInFlight];
 #pragma unroll
-            for (int u = 0; u < kRowsInFlight; ++u) {
+            for (int u = 0; u < kRowsInFlight; ++u) {  // tail slots re-read the last live row with weight 0 (cache hit, no branch)
                 const bool live = (j + u) < m;
                 const int jj = live ? (j + u) : (m - 1);
-                const int64_t ej = bcast_i32(ed, jj);
-                const int64_t nj = bcast_i32(nb, jj);
+                ej[u] = bcast_i32(ed, jj);
+                nj[u] = bcast_i32(nb, jj);
                 wj[u] = live ? bcast_f32(aw, jj) : 0.f;
-                re[u] = (kEdgeNode && fa && live) ? ld4(p.edge_raw + ej * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                rp[u] = (kPe && pa && live) ? ld4(p.pe + nj * P + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                lj[u] = live ? 1.f : 0.f;
             }
+            float4 re[kRowsInFlight], rp[kRowsInFlight];
+            if (kEdgeNode && fa) {
 #pragma unroll
-            for (int u = 0; u < kRowsInFlight; ++u) {
-                if (kEdgeNode) fma4(accE, wj[u], re[u]);
-                if (kPe) { accP.x += rp[u].x; accP.y += rp[u].y; accP.z += rp[u].z; accP.w += rp[u].w; }
+                for (int u = 0; u < kRowsInFlight; ++u) re[u] = ld4(p.edge_raw + ej[u] * F + lane * 4);
             }
-        }
-        // time features of the valid slots: cos(dt * w_d), zero where the neighbour id is 0 (LSTEP.py:154,231)
-        for (int j = 0; j < m; ++j) {
-            const int nj = bcast_i32(nb, j);
-            if (nj == 0) continue;
-            const float dj = bcast_f32(dt, j);
-            const float aj = bcast_f32(aw, j);
-            const float c0v = lane < D ? time_feat(dj, w0, b0) : 0.f;
-            const float c1v = lane + kWave < D ? time_feat(dj, w1, b1) : 0.f;
-            xt0 = fmaf(aj, c0v, xt0);
-            xt1 = fmaf(aj, c1v, xt1);
-            pt0 += c0v;
-            pt1 += c1v;
+            if (kPe && pa) {
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) rp[u] = ld4(p.pe + nj[u] * P + lane * 4);
+            }
+            // time features of this group's slots while its rows are in flight: cos(dt * w_d), zero where the
+            // neighbour id is 0 (LSTEP.py:154,231)
+            const int jend = (j + kRowsInFlight) < m ? (j + kRowsInFlight) : m;
+            for (int jj = j; jj < jend; ++jj) {
+                if (bcast_i32(nb, jj) == 0) continue;
+                const float dj = bcast_f32(dt, jj);
+                const float aj = bcast_f32(aw, jj);
+                const float c0v = lane < D ? time_feat(dj, w0, b0) : 0.f;
+                const float c1v = lane + kWave < D ? time_feat(dj, w1, b1) : 0.f;
+                xt0 = fmaf(aj, c0v, xt0);
+                xt1 = fmaf(aj, c1v, xt1);
+                pt0 += c0v;
+                pt1 += c1v;
+            }
+            if (kEdgeNode && fa) {
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) fma4(accE, wj[u], re[u]);
+            }
+            if (kPe && pa) {
+#pragma unroll
+                for (int u = 0; u < kRowsInFlight; ++u) fma4(accP, lj[u], rp[u]);
+            }
         }
     }
     if (npad > 0) {  // padding slots gather row 0 of the edge table and of the PE table (pe[0] is live)
@@ -114,10 +137,11 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
     }
 
     if (kEdgeNode) {
-        float* oe = p.out_edge + row * (int64_t)(D + F);
+        float* oe = p.out_edge + row * (int64_t)p.ld_edge;
         if (lane < D) oe[lane] = xt0;
         if (lane + kWave < D) oe[lane + kWave] = xt1;
         if (fa) st4(oe + D + lane * 4, accE);
+        zero_tail(oe, D + F, p.ld_edge, lane);
 
         // node channel: the last v = min(cnt, G) interactions; score 1/valid on ids > 0, then mean over G slots
         const int64_t v = cnt < p.G ? cnt : p.G;
@@ -128,17 +152,23 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             const int m = (int)((v - c0) < kWave ? (v - c0) : kWave);
             const int idx = lane < m ? p.csr.nbr[vfirst + c0 + lane] : 0;
             valid += __popcll(__ballot(idx > 0));
-            for (int j = 0; j < m; j += kRowsInFlight) {
-                float4 rn[kRowsInFlight];
+            settle(idx);
+            for (int j = 0; j < m; j += kNodeRowsInFlight) {
+                int64_t nj[kNodeRowsInFlight];
+                float lj[kNodeRowsInFlight];
 #pragma unroll
-                for (int u = 0; u < kRowsInFlight; ++u) {
+                for (int u = 0; u < kNodeRowsInFlight; ++u) {
                     const bool live = (j + u) < m;
-                    const int64_t nj = bcast_i32(idx, live ? (j + u) : (m - 1));
-                    rn[u] = (fa && live && nj > 0) ? ld4(p.node_raw + nj * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int r = bcast_i32(idx, live ? (j + u) : (m - 1));
+                    nj[u] = r > 0 ? r : 0;
+                    lj[u] = (live && r > 0) ? 1.f : 0.f;
                 }
+                if (fa) {
+                    float4 rn[kNodeRowsInFlight];
 #pragma unroll
-                for (int u = 0; u < kRowsInFlight; ++u) {
-                    accN.x += rn[u].x; accN.y += rn[u].y; accN.z += rn[u].z; accN.w += rn[u].w;
+                    for (int u = 0; u < kNodeRowsInFlight; ++u) rn[u] = ld4(p.node_raw + nj[u] * F + lane * 4);
+#pragma unroll
+                    for (int u = 0; u < kNodeRowsInFlight; ++u) fma4(accN, lj[u], rn[u]);
                 }
             }
         }
@@ -154,15 +184,18 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             }
             float4 self = make_float4(0.f, 0.f, 0.f, 0.f);
             if (in_range) self = ld4(p.node_raw + node * F + lane * 4);
-            st4(p.out_node + row * (int64_t)F + lane * 4, make_float4(r0.x + self.x, r0.y + self.y, r0.z + self.z, r0.w + self.w));
+            st4(p.out_node + row * (int64_t)p.ld_node + lane * 4, make_float4(r0.x + self.x, r0.y + self.y, r0.z + self.z, r0.w + self.w));
         }
+        zero_tail(p.out_node + row * (int64_t)p.ld_node, F, p.ld_node, lane);
     }
     if (kPe) {
-        float* op = p.out_pe + row * (int64_t)(P + D);
+        float* op = p.out_pe + row * (int64_t)p.ld_pe;
         if (pa) st4(op + lane * 4, accP);
         if (lane < D) op[P + lane] = pt0;
         if (lane + kWave < D) op[P + lane + kWave] = pt1;
-        if (pa) st4(p.out_self + row * (int64_t)P + lane * 4, in_range ? ld4(p.pe + node * P + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+        if (pa) st4(p.out_self + row * (int64_t)p.ld_self + lane * 4, in_range ? ld4(p.pe + node * P + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+        zero_tail(op, P + D, p.ld_pe, lane);
+        zero_tail(p.out_self + row * (int64_t)p.ld_self, P, p.ld_self, lane);
     }
     if (p.out_count != nullptr && lane == 0) p.out_count[row] = (int32_t)cnt;
 }
@@ -184,6 +217,7 @@ struct GatherBwdParams {
     const int32_t* slot_of;
     float* out_slot_dot;
     float* grad_pe_rows;
+    int ld_edge, ld_pe, ld_self;  // row strides (floats) of grad_edge / grad_pe_agg / grad_self
 };
 
 // atomically add a P-wide gradient row held as g[i] = elements lane + 64*i (contiguous dwords per wave-instruction)
@@ -215,14 +249,14 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
     float gt0 = 0.f, gt1 = 0.f, w0 = 0.f, b0 = 0.f, w1 = 0.f, b1 = 0.f;
     float4 gE = make_float4(0.f, 0.f, 0.f, 0.f);
     if (do_edge) {
-        const float* ge = p.grad_edge + row * (int64_t)(D + F);
+        const float* ge = p.grad_edge + row * (int64_t)p.ld_edge;
         if (lane < D) { gt0 = ge[lane]; w0 = p.time_w[lane]; b0 = p.time_b[lane]; }
         if (lane + kWave < D) { gt1 = ge[lane + kWave]; w1 = p.time_w[lane + kWave]; b1 = p.time_b[lane + kWave]; }
         if (fa) gE = ld4(ge + D + lane * 4);
     }
     float gp[4] = {0.f, 0.f, 0.f, 0.f};
     if (do_pe) {
-        const float* g = p.grad_pe_agg + row * (int64_t)(P + D);
+        const float* g = p.grad_pe_agg + row * (int64_t)p.ld_pe;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (lane + i * kWave < P) gp[i] = g[lane + i * kWave];
@@ -282,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
     }
     if (p.grad_self != nullptr && p.grad_pe_rows != nullptr && in_range) {
         float gs[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* g = p.grad_self + row * (int64_t)P;
+        const float* g = p.grad_self + row * (int64_t)p.ld_self;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (lane + i * kWave < P) gs[i] = g[lane + i * kWave];
@@ -301,6 +335,14 @@ static int check_dims(const char* who, int F, int P, int D) {
     return LSTEP_OK;
 }
 
+static int check_ld(const char* who, int a, int wa, int b, int wb, int c, int wc, int d, int wd) {
+    const int ld[4] = {a, b, c, d}, w[4] = {wa, wb, wc, wd};
+    for (int i = 0; i < 4; ++i)
+        if (ld[i] < w[i] || (ld[i] & 3) || ld[i] - w[i] > 4 * kWave)
+            return set_error(LSTEP_EINVAL, "%s: row stride %d invalid for width %d (need a multiple of 4, >= width, padding <= 256)", who, ld[i], w[i]);
+    return LSTEP_OK;
+}
+
 }  // namespace lstep
 
 using namespace lstep;
@@ -310,7 +352,8 @@ extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* n
                                           int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids,
                                           const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap,
                                           uint32_t branches, float* out_edge, float* out_node, float* out_pe, float* out_self,
-                                          int32_t* out_count, void* stream) {
+                                          int32_t ld_edge, int32_t ld_node, int32_t ld_pe, int32_t ld_self, int32_t* out_count,
+                                          void* stream) {
     if (num_neighbors <= 0 || time_gap <= 0)
         return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
     if (int rc = check_dims("lstep_gather_aggregate_fwd", feat_dim, pe_dim, time_dim)) return rc;
@@ -324,8 +367,13 @@ extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* n
         return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd: edge/node branch needs node_raw, edge_raw, edge_agg_w, out_edge, out_node");
     if (pb && (!pe || !out_pe || !out_self))
         return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd: PE branch needs pe, out_pe, out_self");
+    if (ld_edge == 0) ld_edge = time_dim + feat_dim;
+    if (ld_node == 0) ld_node = feat_dim;
+    if (ld_pe == 0) ld_pe = pe_dim + time_dim;
+    if (ld_self == 0) ld_self = pe_dim;
+    if (int rc = check_ld("lstep_gather_aggregate_fwd", ld_edge, time_dim + feat_dim, ld_node, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
     GatherParams p{*csr, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
-                   batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, out_count};
+                   batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, out_count, ld_edge, ld_node, ld_pe, ld_self};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
     if (en && pb) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true>), grid, block, 0, s, p);
@@ -338,7 +386,8 @@ extern "C" int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* e
                                           const float* time_w, const float* time_b, int32_t time_dim, const int64_t* node_ids,
                                           const double* times, const int32_t* count, int64_t batch, int32_t num_neighbors,
                                           const float* grad_edge, const float* grad_pe_agg, const float* grad_self,
-                                          const int32_t* slot_of, float* out_slot_dot, float* grad_pe_rows, void* stream) {
+                                          int32_t ld_edge, int32_t ld_pe, int32_t ld_self, const int32_t* slot_of,
+                                          float* out_slot_dot, float* grad_pe_rows, void* stream) {
     if (num_neighbors <= 0) return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
     if (int rc = check_dims("lstep_gather_aggregate_bwd", feat_dim, pe_dim, time_dim)) return rc;
     if (batch < 0) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: negative batch");
@@ -347,8 +396,12 @@ extern "C" int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* e
         return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: NULL pointer");
     if (grad_edge && (!edge_raw || !out_slot_dot)) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: grad_edge needs edge_raw and out_slot_dot");
     if ((grad_pe_agg || grad_self) && !grad_pe_rows) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: PE gradients need grad_pe_rows");
+    if (ld_edge == 0) ld_edge = time_dim + feat_dim;
+    if (ld_pe == 0) ld_pe = pe_dim + time_dim;
+    if (ld_self == 0) ld_self = pe_dim;
+    if (int rc = check_ld("lstep_gather_aggregate_bwd", ld_edge, time_dim + feat_dim, feat_dim, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
     GatherBwdParams p{*csr, edge_raw, feat_dim, pe_dim, time_dim, time_w, time_b, node_ids, times, count, batch, num_neighbors,
-                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows};
+                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows, ld_edge, ld_pe, ld_self};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
     hipLaunchKernelGGL(gather_aggregate_bwd_kernel, grid, block, 0, (hipStream_t)stream, p);
     return check_launch("gather_aggregate_bwd_kernel");

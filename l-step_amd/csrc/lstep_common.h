@@ -26,6 +26,9 @@ __device__ __forceinline__ float bcast_f32(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
+// Make the compiler wait for (and only then forget about) the loads that produced v: an empty asm that consumes it.
+__device__ __forceinline__ void settle(int v) { asm volatile("" ::"v"(v)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);

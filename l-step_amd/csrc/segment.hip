@@ -11,7 +11,7 @@ __global__ __launch_bounds__(kBlock) void segment_pe_time_sum_kernel(const float
                                                                       const float* __restrict__ tb, int D,
                                                                       const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end, int64_t num_segments,
                                                                       const int32_t* __restrict__ ent_row, const float* __restrict__ ent_dt,
-                                                                      const uint8_t* __restrict__ ent_valid, float* __restrict__ out) {
+                                                                      const uint8_t* __restrict__ ent_valid, float* __restrict__ out, int ld_out) {
     const int lane = lane_id();
     const int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (s >= num_segments) return;
@@ -48,10 +48,12 @@ __global__ __launch_bounds__(kBlock) void segment_pe_time_sum_kernel(const float
             if (lane + kWave < D) t1 += time_feat(dj, w1, b1);
         }
     }
-    float* o = out + s * (int64_t)(P + D);
+    float* o = out + s * (int64_t)ld_out;
     if (pa) st4(o + lane * 4, acc);
     if (lane < D) o[P + lane] = t0;
     if (lane + kWave < D) o[P + lane + kWave] = t1;
+    const int c = P + D + lane * 4;  // zero the padding columns
+    if (c < ld_out) st4(o + c, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(float* __restrict__ table, int W, const int64_t* __restrict__ ids,
@@ -65,14 +67,14 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(float* __restrict_
 
 // table[ids[i], :] += tanh(z[i, :])   (residual PE update of models/LSTEP.py:299-303 and :335-339, fused with the write)
 __global__ __launch_bounds__(kBlock) void residual_tanh_rows_kernel(float* __restrict__ table, int W, const int64_t* __restrict__ ids,
-                                                                     int64_t num_ids, const float* __restrict__ z) {
+                                                                     int64_t num_ids, const float* __restrict__ z, int ld_z) {
     const int lane = lane_id();
     const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (i >= num_ids) return;
     const int64_t r = ids[i];
     for (int c = lane; c < (W >> 2); c += kWave) {
         const float4 a = ld4(table + r * W + c * 4);
-        const float4 b = ld4(z + i * W + c * 4);
+        const float4 b = ld4(z + i * (int64_t)ld_z + c * 4);
         st4(table + r * W + c * 4, make_float4(a.x + tanhf(b.x), a.y + tanhf(b.y), a.z + tanhf(b.z), a.w + tanhf(b.w)));
     }
 }
@@ -83,15 +85,18 @@ using namespace lstep;
 
 extern "C" int lstep_segment_pe_time_sum(const float* pe, int32_t pe_dim, const float* time_w, const float* time_b, int32_t time_dim,
                                          const int64_t* seg_begin, const int64_t* seg_end, int64_t num_segments, const int32_t* ent_row, const float* ent_dt,
-                                         const uint8_t* ent_valid, float* out, void* stream) {
+                                         const uint8_t* ent_valid, float* out, int32_t ld_out, void* stream) {
     if (num_segments < 0) return set_error(LSTEP_EINVAL, "lstep_segment_pe_time_sum: negative count");
     if (num_segments == 0) return LSTEP_OK;
     if (pe_dim <= 0 || (pe_dim & 3) || pe_dim > 4 * kMaxRowVec || time_dim <= 0 || (time_dim & 3) || time_dim > kMaxTimeDim)
         return set_error(LSTEP_EINVAL, "lstep_segment_pe_time_sum: unsupported widths P=%d D=%d", pe_dim, time_dim);
     if (!pe || !time_w || !time_b || !seg_begin || !seg_end || !ent_row || !ent_dt || !out) return set_error(LSTEP_EINVAL, "lstep_segment_pe_time_sum: NULL pointer");
+    if (ld_out == 0) ld_out = pe_dim + time_dim;
+    if (ld_out < pe_dim + time_dim || (ld_out & 3) || ld_out - (pe_dim + time_dim) > 4 * kWave)
+        return set_error(LSTEP_EINVAL, "lstep_segment_pe_time_sum: bad output row stride %d", ld_out);
     const unsigned grid = (unsigned)((num_segments + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(segment_pe_time_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, pe, (int)pe_dim, time_w, time_b,
-                       (int)time_dim, seg_begin, seg_end, num_segments, ent_row, ent_dt, ent_valid, out);
+                       (int)time_dim, seg_begin, seg_end, num_segments, ent_row, ent_dt, ent_valid, out, (int)ld_out);
     return check_launch("segment_pe_time_sum_kernel");
 }
 
@@ -104,11 +109,14 @@ extern "C" int lstep_scatter_rows(float* table, int32_t width, const int64_t* id
     return check_launch("scatter_rows_kernel");
 }
 
-extern "C" int lstep_residual_tanh_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* z, void* stream) {
+extern "C" int lstep_residual_tanh_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* z, int32_t ld_z,
+                                        void* stream) {
     if (num_ids < 0 || width <= 0 || (width & 3)) return set_error(LSTEP_EINVAL, "lstep_residual_tanh_rows: bad sizes");
     if (num_ids == 0) return LSTEP_OK;
     if (!table || !ids || !z) return set_error(LSTEP_EINVAL, "lstep_residual_tanh_rows: NULL pointer");
+    if (ld_z == 0) ld_z = width;
+    if (ld_z < width || (ld_z & 3)) return set_error(LSTEP_EINVAL, "lstep_residual_tanh_rows: bad row stride %d", ld_z);
     const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(residual_tanh_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, ids, num_ids, z);
+    hipLaunchKernelGGL(residual_tanh_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, ids, num_ids, z, (int)ld_z);
     return check_launch("residual_tanh_rows_kernel");
 }

@@ -30,6 +30,57 @@ import torch.nn.functional as F
 from . import _native as nat
 
 
+def _round16(x: int) -> int:
+    return (x + 15) // 16 * 16
+
+
+def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """Zero-pad a weight matrix to [rows, cols] (autograd slices the gradient back)."""
+    return F.pad(w, (0, cols - w.shape[1], 0, rows - w.shape[0]))
+
+
+def _pad1(b: torch.Tensor, n: int) -> torch.Tensor:
+    return F.pad(b, (0, n - b.shape[0]))
+
+
+class _Linear(torch.autograd.Function):
+    """``x @ w.T + b`` whose weight gradient is a batched split-M GEMM.
+
+    The weight gradient ``dY^T X`` reduces over M = 3 * batch rows into a small [N, K] output; hipBLASLt's fp32 kernels for
+    that shape reach 30-60 TFLOP/s on MI355X, the same product as 32 row-chunk ``bmm`` + one ``sum`` reaches 65-105
+    (tools/gemm_dw.py).  Forward and dX are the plain library GEMMs."""
+
+    CHUNKS = 32
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w
+        if ctx.needs_input_grad[1]:
+            m = x.shape[0]
+            c = math.gcd(m, _Linear.CHUNKS)
+            if c >= 4 and m // c >= 256 and x.is_contiguous():
+                dw = torch.bmm(dy.view(c, m // c, -1).transpose(1, 2), x.view(c, m // c, -1)).sum(dim=0)
+            else:
+                dw = dy.t() @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=0)
+        return dx, dw, db
+
+
+def fast_linear(x, w, b=None):
+    return _Linear.apply(x, w, b)
+
+
 # ------------------------------------------------------------------------------------------------ small modules
 class TimeEncoder(nn.Module):
     """``cos(t * w + b)``; same parameters as reference ``models/modules.py:7-39``."""
@@ -68,7 +119,7 @@ class MergeLayer(nn.Module):
         self.act = nn.ReLU()
 
     def forward(self, input_1: torch.Tensor, input_2: torch.Tensor):
-        return self.fc2(self.act(self.fc1(torch.cat([input_1, input_2], dim=1))))
+        return self.fc2(self.act(fast_linear(torch.cat([input_1, input_2], dim=1), self.fc1.weight, self.fc1.bias)))
 
 
 # ------------------------------------------------------------------------------------------------ autograd glue
@@ -87,7 +138,9 @@ class SplicedRows:
 
 
 class _GatherAggregate(torch.autograd.Function):
-    """lstep_gather_aggregate_fwd / _bwd.  Differentiable inputs: ``pe`` (dense table) OR ``rows`` (spliced rows), ``agg_w``."""
+    """lstep_gather_aggregate_fwd / _bwd.  Differentiable inputs: ``pe`` (dense table) OR ``rows`` (spliced rows), ``agg_w``.
+    Outputs are row-padded to multiples of 16 floats (``mod.ld_*``; padding columns are zero) so every following GEMM has
+    16-aligned K: hipBLASLt runs 288/176-wide fp32 GEMMs up to 2.5x faster than 272/172-wide ones (tools/gemm_shapes.py)."""
 
     @staticmethod
     def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of):
@@ -96,10 +149,10 @@ class _GatherAggregate(torch.autograd.Function):
         B = ids.numel()
         Fd, P, D = mod.feat_dim, mod.pe_dim, mod.time_dim
         en, pb = bool(branches & nat.BRANCH_EDGE_NODE), bool(branches & nat.BRANCH_PE)
-        out_edge = torch.empty((B, D + Fd), dtype=torch.float32, device=dev) if en else None
-        out_node = torch.empty((B, Fd), dtype=torch.float32, device=dev) if en else None
-        out_pe = torch.empty((B, P + D), dtype=torch.float32, device=dev) if pb else None
-        out_self = torch.empty((B, P), dtype=torch.float32, device=dev) if pb else None
+        out_edge = torch.empty((B, mod.ld_edge), dtype=torch.float32, device=dev) if en else None
+        out_node = torch.empty((B, mod.ld_node), dtype=torch.float32, device=dev) if en else None
+        out_pe = torch.empty((B, mod.ld_pe), dtype=torch.float32, device=dev) if pb else None
+        out_self = torch.empty((B, mod.ld_self), dtype=torch.float32, device=dev) if pb else None
         count = torch.empty((B,), dtype=torch.int32, device=dev)
         pe_c = None
         if pb:
@@ -113,7 +166,8 @@ class _GatherAggregate(torch.autograd.Function):
             nat.check(lib.lstep_gather_aggregate_fwd(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
                                                      Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
                                                      int(K), int(G), int(branches), nat.ptr(out_edge), nat.ptr(out_node), nat.ptr(out_pe),
-                                                     nat.ptr(out_self), nat.ptr(count), nat.current_stream()))
+                                                     nat.ptr(out_self), mod.ld_edge, mod.ld_node, mod.ld_pe, mod.ld_self, nat.ptr(count),
+                                                     nat.current_stream()))
         ctx.mod, ctx.sampler, ctx.K, ctx.branches = mod, s, int(K), int(branches)
         ctx.pe_shape = tuple(pe.shape) if pe is not None else None
         ctx.rows_shape = tuple(rows.shape) if rows is not None else None
@@ -151,7 +205,8 @@ class _GatherAggregate(torch.autograd.Function):
             with torch.cuda.device(dev):
                 nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
                                                          nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, nat.ptr(g_edge), nat.ptr(g_pe),
-                                                         nat.ptr(g_self), nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
+                                                         nat.ptr(g_self), mod.ld_edge, mod.ld_pe, mod.ld_self,
+                                                         nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
                                                          nat.ptr(grad_rows), nat.current_stream()))
         g_w = slot_dot.sum(dim=0) if slot_dot is not None else None
         g_table = None
@@ -224,6 +279,9 @@ class LSTEP(nn.Module):
         self.num_nodes = node_raw_features.shape[0]
         self.pe_dim, self.feat_dim, self.time_dim = pe_dim, node_feat_dim, time_feat_dim
         self.num_neighbors = num_neighbors
+        # padded row strides of the gather-stage outputs / hidden activations (see _GatherAggregate)
+        self.ld_edge, self.ld_node = _round16(time_feat_dim + node_feat_dim), _round16(node_feat_dim)
+        self.ld_pe, self.ld_self = _round16(pe_dim + time_feat_dim), _round16(pe_dim)
         self.use_dropout, self.dropout, self.concat_pe, self.weighted_sum = use_dropout, dropout, concat_pe, weighted_sum
         self.device = torch.device(device)
 
@@ -316,12 +374,12 @@ class LSTEP(nn.Module):
     # ---- A + N (models/LSTEP.py:139-220)
     def aggregated_node_embeddings(self, node_ids, node_interact_times, num_neighbors: int = 20, time_gap: int = 2000, testing=False):
         x_edge, x_node, _, _, _ = self._gather(None, node_ids, node_interact_times, num_neighbors, time_gap, nat.BRANCH_EDGE_NODE)
-        return self._edge_node_tail(x_edge, x_node)
+        return self._edge_node_tail(x_edge[:, :self.time_dim + self.feat_dim], x_node[:, :self.feat_dim])
 
     # ---- C (models/LSTEP.py:222-249)
     def compute_neighborhood_pe(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, spliced: SplicedRows = None):
         _, _, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, 1, nat.BRANCH_PE, spliced)
-        return self._pe_tail(x_pe, own)
+        return self._pe_tail(x_pe[:, :self.pe_dim + self.time_dim], own[:, :self.pe_dim])
 
     # ---- O (models/LSTEP.py:251-266): one fused gather launch serves A, N and C
     def combining_pe_raw_feat(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, time_gap: int = 2000, testing=False,
@@ -340,19 +398,24 @@ class LSTEP(nn.Module):
         is ONE [616 -> 172] GEMM instead of three (272->272, 444->172, 344->172); likewise
         self_update_neighbor_pe(own) + pe_neighbor_mlp_2(relu(p1)) is one [344 -> 172] GEMM.  The composed matrices
         are rebuilt from the live parameters every call (25 MFLOP), so autograd yields the gradients of the original
-        parameters; state_dict is unchanged.  Exact in real arithmetic, <= 1e-6 in fp32 (golden-checked)."""
+        parameters; state_dict is unchanged.  Exact in real arithmetic, <= 1e-6 in fp32 (golden-checked).
+        All operands are zero-padded to 16-aligned widths (inputs by the gather kernel, weights here): the padding
+        columns stay exactly 0 through relu / tanh / residual, so results are unchanged."""
         Fd = self.feat_dim
+        Ce, Fn, Cp, Pp = self.ld_edge, self.ld_node, self.ld_pe, self.ld_self   # padded widths (288, 176, 288, 176)
         a = self.edge_agg.weight.reshape(-1)
-        h1 = torch.relu(F.linear(x_edge, self.edge_mlp_1.weight, a.sum() * self.edge_mlp_1.bias + self.edge_agg.bias))
-        p1 = torch.relu(self.pe_neighbor_mlp_1(x_pe))
-        w_q = torch.cat([self.self_update_neighbor_pe.weight, self.pe_neighbor_mlp_2.weight], dim=1)
-        q = own + torch.tanh(F.linear(torch.cat([own, p1], dim=-1), w_q, self.self_update_neighbor_pe.bias + self.pe_neighbor_mlp_2.bias))
+        b1 = a.sum() * self.edge_mlp_1.bias + self.edge_agg.bias
+        h1 = torch.relu(fast_linear(x_edge, _pad2(self.edge_mlp_1.weight, Ce, Ce), _pad1(b1, Ce)))                      # [B, Ce]
+        p1 = torch.relu(fast_linear(x_pe, _pad2(self.pe_neighbor_mlp_1.weight, Pp, Cp), _pad1(self.pe_neighbor_mlp_1.bias, Pp)))  # [B, Pp]
+        w_q = torch.cat([_pad2(self.self_update_neighbor_pe.weight, Pp, Pp), _pad2(self.pe_neighbor_mlp_2.weight, Pp, Pp)], dim=1)
+        q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), w_q,
+                                      _pad1(self.self_update_neighbor_pe.bias + self.pe_neighbor_mlp_2.bias, Pp)))     # [B, Pp]
         wo_a, wo_b = self.out_node_emb.weight[:, :Fd], self.out_node_emb.weight[:, Fd:]
         wn_a, wn_b = self.node_mlp.weight[:, :Fd], self.node_mlp.weight[:, Fd:]
         wo_wnb = wo_a @ wn_b                                                   # [F, C]
-        w_all = torch.cat([wo_a @ wn_a, wo_wnb @ self.edge_mlp_2.weight, wo_b], dim=1)   # [F, F + C + P]
+        w_all = torch.cat([_pad2(wo_a @ wn_a, Fn, Fn), _pad2(wo_wnb @ self.edge_mlp_2.weight, Fn, Ce), _pad2(wo_b, Fn, Pp)], dim=1)
         const = wo_wnb @ self.edge_mlp_2.bias + wo_a @ self.node_mlp.bias + self.out_node_emb.bias
-        return F.linear(torch.cat([x_node, h1, q], dim=-1), w_all, const)
+        return fast_linear(torch.cat([x_node, h1, q], dim=-1), w_all, _pad1(const, Fn))[:, :Fd]
 
     def compute_src_dst_node_temporal_embeddings(self, pe, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20,
                                                  time_gap: int = 2000, spliced: SplicedRows = None):
@@ -420,12 +483,18 @@ class LSTEP(nn.Module):
     def _segment_sum(self, pe, seg_begin, seg_end, nseg, ent_row, ent_dt):
         lib = nat.load_library()
         P, D = self.pe_dim, self.time_dim
-        out = torch.empty((nseg, P + D), dtype=torch.float32, device=pe.device)
+        out = torch.empty((nseg, self.ld_pe), dtype=torch.float32, device=pe.device)   # row-padded like the gather outputs
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_segment_pe_time_sum(nat.ptr(pe), P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
                                                     nat.ptr(seg_begin), nat.ptr(seg_end), nseg, nat.ptr(ent_row), nat.ptr(ent_dt), None,
-                                                    nat.ptr(out), nat.current_stream()))
+                                                    nat.ptr(out), self.ld_pe, nat.current_stream()))
         return out
+
+    def _update_mlp(self, agg):
+        """pe_mlp_2(relu(pe_mlp_1(agg))) on row-padded operands -> [n, ld_self] (padding columns 0)."""
+        Cp, Pp = self.ld_pe, self.ld_self
+        h = torch.relu(F.linear(agg, _pad2(self.pe_mlp_1.weight, Pp, Cp), _pad1(self.pe_mlp_1.bias, Pp)))
+        return F.linear(h, _pad2(self.pe_mlp_2.weight, Pp, Pp), _pad1(self.pe_mlp_2.bias, Pp))
 
     def write_rows(self, pe, ids, rows):
         """In-place ``pe[ids] = rows`` (models/LSTEP.py:303,339)."""
@@ -434,10 +503,13 @@ class LSTEP(nn.Module):
             nat.check(lib.lstep_scatter_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(rows.contiguous()), nat.current_stream()))
 
     def apply_residual_tanh(self, pe, ids, z):
-        """In-place ``pe[ids] += tanh(z)``: residual + tanh + row write of models/LSTEP.py:299-303 / :335-339 in one kernel."""
+        """In-place ``pe[ids] += tanh(z[:, :P])``: residual + tanh + row write of models/LSTEP.py:299-303 / :335-339 in one
+        kernel; ``z`` may be row-padded (its row stride is passed on)."""
         lib = nat.load_library()
+        z = z.contiguous()
         with torch.cuda.device(pe.device):
-            nat.check(lib.lstep_residual_tanh_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(z.contiguous()), nat.current_stream()))
+            nat.check(lib.lstep_residual_tanh_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(z), int(z.shape[1]),
+                                                   nat.current_stream()))
 
     @torch.no_grad()
     def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None):
@@ -462,7 +534,8 @@ class LSTEP(nn.Module):
         ent_dt = torch.cat([dt1, dt1])[order].contiguous()
         agg = self._segment_sum(pe, seg_begin.contiguous(), seg_end.contiguous(), ids.numel(), ent_row, ent_dt)
         own = pe[ids]
-        z = self.self_update_pe(own) + self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg)))
+        Pp = self.ld_self
+        z = F.linear(own, _pad2(self.self_update_pe.weight, Pp, self.pe_dim), _pad1(self.self_update_pe.bias, Pp)) + self._update_mlp(agg)
         return ids, z
 
     @torch.no_grad()
@@ -503,8 +576,7 @@ class LSTEP(nn.Module):
             agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
         else:
             agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg, ent_row, ent_dt)
-        z = self.pe_mlp_2(torch.relu(self.pe_mlp_1(agg2)))
-        return touched, z
+        return touched, self._update_mlp(agg2)
 
     @torch.no_grad()
     def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
