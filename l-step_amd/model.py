@@ -483,7 +483,9 @@ class LSTEP(nn.Module):
     def _segment_sum(self, pe, seg_begin, seg_end, nseg, ent_row, ent_dt):
         lib = nat.load_library()
         P, D = self.pe_dim, self.time_dim
-        out = torch.empty((nseg, self.ld_pe), dtype=torch.float32, device=pe.device)   # row-padded like the gather outputs
+        rows = self._bucket_rows(nseg)
+        out = torch.empty((rows, self.ld_pe), dtype=torch.float32, device=pe.device)   # row-padded like the gather outputs
+        out[nseg:].zero_()
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_segment_pe_time_sum(nat.ptr(pe), P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
                                                     nat.ptr(seg_begin), nat.ptr(seg_end), nseg, nat.ptr(ent_row), nat.ptr(ent_dt), None,
@@ -491,10 +493,18 @@ class LSTEP(nn.Module):
         return out
 
     def _update_mlp(self, agg):
-        """pe_mlp_2(relu(pe_mlp_1(agg))) on row-padded operands -> [n, ld_self] (padding columns 0)."""
+        """pe_mlp_2(relu(pe_mlp_1(agg))) on row-padded operands -> [n, ld_self] (padding columns 0).
+        ``agg`` may carry extra bucket rows (see ``_bucket_rows``); they are computed and ignored."""
         Cp, Pp = self.ld_pe, self.ld_self
         h = torch.relu(F.linear(agg, _pad2(self.pe_mlp_1.weight, Pp, Cp), _pad1(self.pe_mlp_1.bias, Pp)))
         return F.linear(h, _pad2(self.pe_mlp_2.weight, Pp, Pp), _pad1(self.pe_mlp_2.bias, Pp))
+
+    @staticmethod
+    def _bucket_rows(n: int) -> int:
+        """Row count rounded up to a coarse bucket: the number of updated rows changes every batch, and every new GEMM
+        M costs ~150 us of hipBLASLt heuristic lookup on the host; a few repeating M values avoid that."""
+        q = 1024 if n <= 65536 else 16384
+        return max(q, (n + q - 1) // q * q)
 
     def write_rows(self, pe, ids, rows):
         """In-place ``pe[ids] = rows`` (models/LSTEP.py:303,339)."""
@@ -533,10 +543,12 @@ class LSTEP(nn.Module):
         ent_row = torch.cat([dst, src])[order].to(torch.int32)
         ent_dt = torch.cat([dt1, dt1])[order].contiguous()
         agg = self._segment_sum(pe, seg_begin.contiguous(), seg_end.contiguous(), ids.numel(), ent_row, ent_dt)
-        own = pe[ids]
+        n = ids.numel()
+        own = torch.zeros((agg.shape[0], self.pe_dim), dtype=torch.float32, device=pe.device)
+        own[:n] = pe[ids]
         Pp = self.ld_self
         z = F.linear(own, _pad2(self.self_update_pe.weight, Pp, self.pe_dim), _pad1(self.self_update_pe.bias, Pp)) + self._update_mlp(agg)
-        return ids, z
+        return ids, z[:n]
 
     @torch.no_grad()
     def update_pe_phase2(self, pe, bn, t, now32: float, num_neighbors: int, shard=None):
@@ -576,7 +588,7 @@ class LSTEP(nn.Module):
             agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
         else:
             agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg, ent_row, ent_dt)
-        return touched, self._update_mlp(agg2)
+        return touched, self._update_mlp(agg2)[:touched.numel()]
 
     @torch.no_grad()
     def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
