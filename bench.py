@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--time-gap", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["train", "eval"], default="train", help="eval = evaluate_model_utils.py:38-142 iteration (4x combine, no backward)")
+    ap.add_argument("--zipf", type=float, default=None, help="power-law endpoint popularity exponent (hub-skew variant)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +118,7 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
-    wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0, sharded=use_dist)
+    wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0, sharded=use_dist, zipf=args.zipf)
     eng, model = wl.engine, wl.model
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -135,6 +137,10 @@ def main():
         lo = start + i * B * world
         src, dst, ts, eid = wl.stream.batch(lo, lo + B * world)
         neg = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
+        if args.mode == "eval":
+            neg_src = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
+            with torch.no_grad():
+                return runner.eval_iteration(1000 + i, src, dst, ts, eid, neg_src, neg)
         return runner.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg)
 
     def barrier():
@@ -174,7 +180,7 @@ def main():
         avg_ms = float(np.mean(ms))
         achieved = float(np.mean(bytes_per_launch)) / (avg_ms * 1e-3) / 1e9
         line = {
-            "metric": "processed edges/sec (L-STEP fwd+bwd)",
+            "metric": "processed edges/sec (L-STEP fwd+bwd)" if args.mode == "train" else "processed edges/sec (L-STEP eval iteration, no bwd)",
             "value": B * world * args.steps / elapsed,
             "unit": "edges/s",
             "n_gpus": world,
@@ -186,13 +192,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.describe(), "global_batch": B * world, "parallelism": f"owner-sharded history + row-sharded batch x{world} (RCCL)" if use_dist else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "gather_aggregate_fwd_kernel<true,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "config": {"workload": wl.describe() + (f", zipf {args.zipf} endpoints" if args.zipf else ""), "global_batch": B * world, "parallelism": f"owner-sharded history + row-sharded batch x{world} (RCCL)" if use_dist else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "lstep::gather_aggregate_fwd_kernel<true, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
                          "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and not args.zipf:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if use_dist:

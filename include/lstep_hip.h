@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 2
+#define LSTEP_ABI_VERSION 3
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -95,13 +95,16 @@ int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* node_raw, co
  *                       sum_b (K - min(c_b, K)) * grad_pe_agg[b, :P] to row 0 (one tiny reduction, no hot row).
  *     slot_of != NULL : int32 [num_rows] map node id -> row of the compact gradient [U, P] or -1 (no gradient);
  *                       grad_pe_rows is [U, P].  This is the training fast path: only the FFT-filtered rows of
- *                       the spliced PE carry gradient (train_LSTEP_link_prediction.py:229-230). */
+ *                       the spliced PE carry gradient (train_LSTEP_link_prediction.py:229-230).
+ *     out_hits != NULL: (needs slot_of) no atomics at all: int32 [B, K] receives slot_of[nbr_j] per slot (-1 for padding
+ *                       slots / rows without gradient); the caller groups the hits by spliced row and reduces
+ *                       grad_pe_agg rows with lstep_segment_rows_sum (contention-free on hub nodes, deterministic). */
 int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* edge_raw, int32_t feat_dim, int32_t pe_dim,
                                const float* time_w, const float* time_b, int32_t time_dim, const int64_t* node_ids,
                                const double* times, const int32_t* count, int64_t batch, int32_t num_neighbors,
                                const float* grad_edge, const float* grad_pe_agg, const float* grad_self,
                                int32_t ld_edge, int32_t ld_pe, int32_t ld_self, const int32_t* slot_of,
-                               float* out_slot_dot, float* grad_pe_rows, void* stream);
+                               float* out_slot_dot, float* grad_pe_rows, int32_t* out_hits, void* stream);
 
 /* F -- the linear core of fourier_transform_pe (models/LSTEP.py:104-137).  fft -> mask -> filter -> mask ->
  * ifft -> mask -> real part -> fft_agg is linear in the history, so for fixed weights it is a [T, P] real
@@ -121,17 +124,19 @@ int lstep_history_filter_bwd(const float* hist, int64_t node_stride, int64_t tim
                              int32_t time_rot, int32_t t_len, int32_t pe_dim, const int64_t* node_ids, int64_t num_ids,
                              const float* grad_out, float* out_partial, void* stream);
 
-/* U1/U2 message accumulation of update_pe (models/LSTEP.py:282-290, 319-322) without the dense [N+1, P+D]
- * scatter target: entries are pre-grouped by destination; segment s owns entries [seg_begin[s], seg_end[s])
- * (pass ptr and ptr + 1 of one offsets array for back-to-back segments; empty segments give zero rows).
- *   out[s, :P]    = sum_e pe[ent_row[e]]
- *   out[s, P:P+D] = sum_e (ent_valid[e] ? cos(ent_dt[e] * w + b) : 0)
- * ent_valid may be NULL (all valid).  Summation order inside a segment is the entry order (deterministic).
- * ld_out = row stride of out in floats (0 = P + D); padding columns are written as 0. */
-int lstep_segment_pe_time_sum(const float* pe, int32_t pe_dim, const float* time_w, const float* time_b,
-                              int32_t time_dim, const int64_t* seg_begin, const int64_t* seg_end, int64_t num_segments,
-                              const int32_t* ent_row, const float* ent_dt, const uint8_t* ent_valid, float* out,
-                              int32_t ld_out, void* stream);
+/* Segmented row sums.  Entries e = 0..num_entries-1 are grouped by segment (ent_seg non-decreasing; segment s owns
+ * entries [seg_begin[s], seg_end[s])); for every segment
+ *   out[s, :W]    = sum_e table[ent_row[e], :W]                       (table row stride ld_table floats)
+ *   out[s, W:W+D] = sum_e cos(ent_dt[e] * time_w + time_b)            (time_dim D may be 0: no time part, ent_dt unused)
+ * `out` (row stride ld_out) MUST be zero-initialised by the caller: segments without entries stay zero and segments
+ * longer than one 128-entry chunk are accumulated with float atomics (hub nodes), all others are plain stores in
+ * entry order (deterministic).  Uses:
+ *   update_pe U1/U2 (models/LSTEP.py:282-290, 319-322) with table = pe, D = time dim: replaces both dense [N+1, P+D]
+ *   torch_scatter targets;  gather backward: table = grad of the PE aggregate, D = 0, segment = spliced PE row. */
+int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
+                           int32_t time_dim, const int64_t* seg_begin, const int64_t* seg_end, int64_t num_segments,
+                           const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt, int64_t num_entries,
+                           float* out, int32_t ld_out, void* stream);
 
 /* In-place row write pe[ids[i], :] = rows[i, :] (models/LSTEP.py:303,339). ids must be unique. */
 int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* rows,

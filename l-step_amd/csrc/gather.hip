@@ -217,6 +217,7 @@ struct GatherBwdParams {
     const int32_t* slot_of;
     float* out_slot_dot;
     float* grad_pe_rows;
+    int32_t* out_hits;  // [B, K]: spliced-row index of every slot's neighbour (or -1); when set, no atomics are issued
     int ld_edge, ld_pe, ld_self;  // row strides (floats) of grad_edge / grad_pe_agg / grad_self
 };
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
     const int npad = K - k;
     const int64_t kfirst = lo + cnt - k;
     const bool do_edge = p.grad_edge != nullptr && p.out_slot_dot != nullptr;
-    const bool do_pe = p.grad_pe_agg != nullptr && p.grad_pe_rows != nullptr;
+    const bool do_pe = p.grad_pe_agg != nullptr && p.grad_pe_rows != nullptr && p.out_hits == nullptr;
 
     float gt0 = 0.f, gt1 = 0.f, w0 = 0.f, b0 = 0.f, w1 = 0.f, b1 = 0.f;
     float4 gE = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
             }
             if (lane < m) p.out_slot_dot[row * (int64_t)K + npad + c0 + lane] = mine;
         }
+        if (p.out_hits != nullptr && lane < m) p.out_hits[row * (int64_t)K + npad + c0 + lane] = p.slot_of[nb];
         if (do_pe) {
             for (int j = 0; j < m; ++j) {
                 const int64_t nj = bcast_i32(nb, j);
@@ -309,12 +311,14 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
             }
         }
     }
+    if (p.out_hits != nullptr)
+        for (int s2 = lane; s2 < npad; s2 += kWave) p.out_hits[row * (int64_t)K + s2] = -1;
     if (do_edge && npad > 0) {  // padding slots: time features are zero, edge row is row 0
         float part = fa ? dot4(gE, ld4(p.edge_raw + lane * 4)) : 0.f;
         part = wave_sum(part);
         for (int s = lane; s < npad; s += kWave) p.out_slot_dot[row * (int64_t)K + s] = part;
     }
-    if (p.grad_self != nullptr && p.grad_pe_rows != nullptr && in_range) {
+    if (p.grad_self != nullptr && p.grad_pe_rows != nullptr && p.out_hits == nullptr && in_range) {
         float gs[4] = {0.f, 0.f, 0.f, 0.f};
         const float* g = p.grad_self + row * (int64_t)p.ld_self;
 #pragma unroll
@@ -387,7 +391,7 @@ extern "C" int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* e
                                           const double* times, const int32_t* count, int64_t batch, int32_t num_neighbors,
                                           const float* grad_edge, const float* grad_pe_agg, const float* grad_self,
                                           int32_t ld_edge, int32_t ld_pe, int32_t ld_self, const int32_t* slot_of,
-                                          float* out_slot_dot, float* grad_pe_rows, void* stream) {
+                                          float* out_slot_dot, float* grad_pe_rows, int32_t* out_hits, void* stream) {
     if (num_neighbors <= 0) return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
     if (int rc = check_dims("lstep_gather_aggregate_bwd", feat_dim, pe_dim, time_dim)) return rc;
     if (batch < 0) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: negative batch");
@@ -395,13 +399,14 @@ extern "C" int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* e
     if (!csr || !csr->indptr || !csr->nbr || !csr->eid || !csr->ts || !time_w || !time_b || !node_ids || !times || !count)
         return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: NULL pointer");
     if (grad_edge && (!edge_raw || !out_slot_dot)) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: grad_edge needs edge_raw and out_slot_dot");
-    if ((grad_pe_agg || grad_self) && !grad_pe_rows) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: PE gradients need grad_pe_rows");
+    if ((grad_pe_agg || grad_self) && !grad_pe_rows && !out_hits) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: PE gradients need grad_pe_rows or out_hits");
+    if (out_hits && !slot_of) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_bwd: out_hits needs slot_of");
     if (ld_edge == 0) ld_edge = time_dim + feat_dim;
     if (ld_pe == 0) ld_pe = pe_dim + time_dim;
     if (ld_self == 0) ld_self = pe_dim;
     if (int rc = check_ld("lstep_gather_aggregate_bwd", ld_edge, time_dim + feat_dim, feat_dim, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
     GatherBwdParams p{*csr, edge_raw, feat_dim, pe_dim, time_dim, time_w, time_b, node_ids, times, count, batch, num_neighbors,
-                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows, ld_edge, ld_pe, ld_self};
+                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows, out_hits, ld_edge, ld_pe, ld_self};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
     hipLaunchKernelGGL(gather_aggregate_bwd_kernel, grid, block, 0, (hipStream_t)stream, p);
     return check_launch("gather_aggregate_bwd_kernel");

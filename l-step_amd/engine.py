@@ -147,9 +147,8 @@ class LstepEngine:
         """One stable sort of cat[src, dst] gives the sorted unique batch nodes (train:221-222) AND the per-node segments
         of update_pe phase 1 (entries grouped by receiving endpoint)."""
         keys_s, order = torch.sort(torch.cat([src, dst]), stable=True)
-        nodes, counts = torch.unique_consecutive(keys_s, return_counts=True)
-        seg_end = torch.cumsum(counts, 0)
-        return nodes, (order, seg_end - counts, seg_end)
+        nodes, inverse, counts = torch.unique_consecutive(keys_s, return_inverse=True, return_counts=True)
+        return nodes, (order, inverse, counts)
 
     # ---- train:204-311
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):

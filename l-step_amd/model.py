@@ -137,6 +137,43 @@ class SplicedRows:
         self.slot_of = slot_of
 
 
+def _segment_reduce_rows(mod, num_rows: int, seg_of_entry: torch.Tensor, src_row: torch.Tensor, table: torch.Tensor):
+    """out[u] = sum of table[src_row[e], :P] over the entries with seg_of_entry[e] == u (entries in any order)."""
+    lib = nat.load_library()
+    dev, P = table.device, mod.pe_dim
+    out = torch.zeros((num_rows, P), dtype=torch.float32, device=dev)
+    if seg_of_entry.numel() == 0:
+        return out
+    seg_s, order = torch.sort(seg_of_entry, stable=True)
+    counts = torch.bincount(seg_s, minlength=num_rows)
+    seg_end = torch.cumsum(counts, 0)
+    seg_begin = seg_end - counts
+    # NOTE: every tensor whose address goes to the C ABI must stay referenced until the launch has been issued: a
+    # temporary dies as soon as nat.ptr() returns and the caching allocator may hand its block to the next temporary.
+    ent_seg = seg_s.to(torch.int32)
+    ent_row = src_row[order].to(torch.int32)
+    with torch.cuda.device(dev):
+        nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, int(table.stride(0)), None, None, 0, nat.ptr(seg_begin), nat.ptr(seg_end), num_rows,
+                                             nat.ptr(ent_seg), nat.ptr(ent_row), None, seg_s.numel(), nat.ptr(out), P, nat.current_stream()))
+    return out
+
+
+def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self):
+    """Gradient of the spliced PE rows: every (row b, slot j) whose neighbour is spliced row u contributes g_pe[b, :P],
+    every row b whose own node is spliced row u contributes g_self[b].  Grouped by u with a sort and reduced by
+    lstep_segment_rows_sum: no atomics on hot (hub) rows, deterministic summation order."""
+    K = hits.shape[1]
+    total = torch.zeros((num_rows, mod.pe_dim), dtype=torch.float32, device=hits.device)
+    if g_pe is not None:
+        flat = hits.reshape(-1)
+        idx = torch.nonzero(flat >= 0).squeeze(1)
+        total = total + _segment_reduce_rows(mod, num_rows, flat[idx].long(), idx // K, g_pe)
+    if g_self is not None:
+        idx = torch.nonzero(self_slot >= 0).squeeze(1)
+        total = total + _segment_reduce_rows(mod, num_rows, self_slot[idx].long(), idx, g_self)
+    return total
+
+
 class _GatherAggregate(torch.autograd.Function):
     """lstep_gather_aggregate_fwd / _bwd.  Differentiable inputs: ``pe`` (dense table) OR ``rows`` (spliced rows), ``agg_w``.
     Outputs are row-padded to multiples of 16 floats (``mod.ld_*``; padding columns are zero) so every following GEMM has
@@ -193,21 +230,24 @@ class _GatherAggregate(torch.autograd.Function):
         g_self = g_self.contiguous() if (want_pe and g_self is not None) else None
         slot_dot = torch.empty((B, K), dtype=torch.float32, device=dev) if g_edge is not None else None
         grad_rows = None
+        hits = None
         use_slot = False
         if want_pe:
             if need_rows:
-                grad_rows = torch.zeros(ctx.rows_shape, dtype=torch.float32, device=dev)
                 use_slot = True
+                hits = torch.empty((B, K), dtype=torch.int32, device=dev)   # sort-based reduction below, no atomics
             else:
                 grad_rows = torch.zeros(ctx.pe_shape, dtype=torch.float32, device=dev)
         tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
-        if g_edge is not None or grad_rows is not None:
+        if g_edge is not None or grad_rows is not None or hits is not None:
             with torch.cuda.device(dev):
                 nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
                                                          nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, nat.ptr(g_edge), nat.ptr(g_pe),
                                                          nat.ptr(g_self), mod.ld_edge, mod.ld_pe, mod.ld_self,
                                                          nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
-                                                         nat.ptr(grad_rows), nat.current_stream()))
+                                                         nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
+        if use_slot:
+            grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self)
         g_w = slot_dot.sum(dim=0) if slot_dot is not None else None
         g_table = None
         if grad_rows is not None and not use_slot:
@@ -480,16 +520,16 @@ class LSTEP(nn.Module):
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
-    def _segment_sum(self, pe, seg_begin, seg_end, nseg, ent_row, ent_dt):
+    def _segment_sum(self, pe, seg_begin, seg_end, nseg, ent_seg, ent_row, ent_dt):
+        """out[s] = sum over the entries of segment s of cat[pe[ent_row], time_feat(ent_dt)]  (lstep_segment_rows_sum);
+        rows are bucketed (``_bucket_rows``) and row-padded like the gather outputs, everything past the data is zero."""
         lib = nat.load_library()
         P, D = self.pe_dim, self.time_dim
-        rows = self._bucket_rows(nseg)
-        out = torch.empty((rows, self.ld_pe), dtype=torch.float32, device=pe.device)   # row-padded like the gather outputs
-        out[nseg:].zero_()
+        out = torch.zeros((self._bucket_rows(nseg), self.ld_pe), dtype=torch.float32, device=pe.device)
         with torch.cuda.device(pe.device):
-            nat.check(lib.lstep_segment_pe_time_sum(nat.ptr(pe), P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
-                                                    nat.ptr(seg_begin), nat.ptr(seg_end), nseg, nat.ptr(ent_row), nat.ptr(ent_dt), None,
-                                                    nat.ptr(out), self.ld_pe, nat.current_stream()))
+            nat.check(lib.lstep_segment_rows_sum(nat.ptr(pe), P, P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
+                                                 nat.ptr(seg_begin), nat.ptr(seg_end), nseg, nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt),
+                                                 ent_row.numel(), nat.ptr(out), self.ld_pe, nat.current_stream()))
         return out
 
     def _update_mlp(self, agg):
@@ -510,7 +550,8 @@ class LSTEP(nn.Module):
         """In-place ``pe[ids] = rows`` (models/LSTEP.py:303,339)."""
         lib = nat.load_library()
         with torch.cuda.device(pe.device):
-            nat.check(lib.lstep_scatter_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(rows.contiguous()), nat.current_stream()))
+            rows = rows.contiguous()
+            nat.check(lib.lstep_scatter_rows(nat.ptr(pe), self.pe_dim, nat.ptr(ids), ids.numel(), nat.ptr(rows), nat.current_stream()))
 
     def apply_residual_tanh(self, pe, ids, z):
         """In-place ``pe[ids] += tanh(z[:, :P])``: residual + tanh + row write of models/LSTEP.py:299-303 / :335-339 in one
@@ -525,24 +566,39 @@ class LSTEP(nn.Module):
     def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None):
         """U1 (LSTEP.py:277-303): every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints.
         Returns (ids, z) with the new row = pe[ids] + tanh(z), WITHOUT writing; ``shard=(W, r)`` restricts the work to
-        nodes with id % W == r; ``presorted=(order, seg_begin, seg_end)`` reuses the caller's stable sort of cat[src, dst]
-        (the engine derives the batch-node set and the segments from one sort)."""
+        nodes with id % W == r; ``presorted=(order, inverse, counts)`` reuses the caller's stable sort of cat[src, dst]
+        (the engine derives the batch-node set and the segments from one sort; then ``bn`` must be that node set)."""
         dt1 = (now32 - t).to(torch.float32)                       # float32 scalar - float64 -> float64 -> .float()
         if presorted is None:
-            keys = torch.cat([src, dst])
-            keys_s, order = torch.sort(keys, stable=True)
-            ids = bn if shard is None else bn[(bn % shard[0]) == shard[1]]
-            seg_begin = torch.searchsorted(keys_s, ids, right=False)
-            seg_end = torch.searchsorted(keys_s, ids, right=True)
+            keys_s, order = torch.sort(torch.cat([src, dst]), stable=True)
+            nodes, inverse, counts = torch.unique_consecutive(keys_s, return_inverse=True, return_counts=True)
+            # only rows listed in bn are updated (LSTEP.py:292): map the receiving nodes onto bn, drop the others
+            bn_sorted = torch.sort(bn).values
+            pos = torch.searchsorted(bn_sorted, nodes).clamp(max=max(bn_sorted.numel() - 1, 0))
+            listed = bn_sorted[pos] == nodes if bn_sorted.numel() else torch.zeros_like(nodes, dtype=torch.bool)
+            ids = bn_sorted
+            seg_of_node = torch.where(listed, pos, torch.full_like(pos, -1))
+            cnt = torch.zeros(ids.numel(), dtype=torch.int64, device=ids.device)
+            cnt[pos[listed]] = counts[listed]
         else:
-            order, seg_begin, seg_end = presorted
-            ids = bn
-            if shard is not None:
-                keep = (bn % shard[0]) == shard[1]
-                ids, seg_begin, seg_end = bn[keep], seg_begin[keep], seg_end[keep]
-        ent_row = torch.cat([dst, src])[order].to(torch.int32)
-        ent_dt = torch.cat([dt1, dt1])[order].contiguous()
-        agg = self._segment_sum(pe, seg_begin.contiguous(), seg_end.contiguous(), ids.numel(), ent_row, ent_dt)
+            order, inverse, counts = presorted
+            ids, cnt = bn, counts
+            seg_of_node = torch.arange(bn.numel(), device=bn.device)
+        ent_seg = seg_of_node[inverse]
+        ent_row = torch.cat([dst, src])[order]
+        ent_dt = torch.cat([dt1, dt1])[order]
+        keep_e = ent_seg >= 0
+        if shard is not None:
+            mine = (ids % shard[0]) == shard[1]
+            newpos = torch.cumsum(mine, 0) - 1
+            keep_e = keep_e & mine[ent_seg.clamp(min=0)]
+            ent_seg = newpos[ent_seg.clamp(min=0)]
+            ids, cnt = ids[mine], cnt[mine]
+        if presorted is None or shard is not None:
+            ent_seg, ent_row, ent_dt = ent_seg[keep_e], ent_row[keep_e], ent_dt[keep_e]
+        seg_end = torch.cumsum(cnt, 0)
+        seg_begin = seg_end - cnt
+        agg = self._segment_sum(pe, seg_begin, seg_end, ids.numel(), ent_seg.to(torch.int32), ent_row.to(torch.int32), ent_dt.contiguous())
         n = ids.numel()
         own = torch.zeros((agg.shape[0], self.pe_dim), dtype=torch.float32, device=pe.device)
         own[:n] = pe[ids]
@@ -569,7 +625,7 @@ class LSTEP(nn.Module):
             real = real & ((key % shard[0]) == shard[1])
         key_r = key[real]
         key_s, order = torch.sort(key_r, stable=True)
-        touched, counts = torch.unique_consecutive(key_s, return_counts=True)
+        touched, inverse, counts = torch.unique_consecutive(key_s, return_inverse=True, return_counts=True)
         seg_end = torch.cumsum(counts, 0)
         seg_begin = seg_end - counts
         ent_row = rep[real][order].to(torch.int32)
@@ -584,10 +640,10 @@ class LSTEP(nn.Module):
             # It goes first (ids are sorted): segment 0 is empty and its aggregate is filled in afterwards.
             zero = torch.zeros(1, dtype=torch.int64, device=dev)
             seg_begin, seg_end, touched = torch.cat([zero, seg_begin]), torch.cat([zero, seg_end]), torch.cat([zero, touched])
-            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg + 1, ent_row, ent_dt)
+            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg + 1, (inverse + 1).to(torch.int32), ent_row, ent_dt)
             agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
         else:
-            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg, ent_row, ent_dt)
+            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg, inverse.to(torch.int32), ent_row, ent_dt)
         return touched, self._update_mlp(agg2)[:touched.numel()]
 
     @torch.no_grad()

@@ -46,7 +46,7 @@ class Workload:
 
 
 def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int = 100, seed: int = 0, batch: int = None,
-                   sharded: bool = False) -> Workload:
+                   sharded: bool = False, zipf: float = None) -> Workload:
     """``sharded=True`` (multi-GPU): no full history ring is allocated; ``prefill_distributed`` fills the owner shards."""
     n, e, b, k = WORKLOADS[name]
     if batch is not None:
@@ -54,8 +54,15 @@ def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    src = torch.randint(1, n + 1, (e,), generator=gen, device=dev)
-    dst = torch.randint(1, n + 1, (e,), generator=gen, device=dev)
+    if zipf is None:
+        src = torch.randint(1, n + 1, (e,), generator=gen, device=dev)
+        dst = torch.randint(1, n + 1, (e,), generator=gen, device=dev)
+    else:  # power-law node popularity (hub skew): P(node of rank r) ~ r^-zipf, ranks randomly assigned to ids
+        prob = torch.arange(1, n + 1, device=dev, dtype=torch.float64) ** (-zipf)
+        cdf = torch.cumsum(prob / prob.sum(), 0)
+        perm = torch.randperm(n, generator=gen, device=dev) + 1
+        draw = lambda: perm[torch.searchsorted(cdf, torch.rand(e, dtype=torch.float64, generator=gen, device=dev)).clamp(max=n - 1)]  # noqa: E731
+        src, dst = draw(), draw()
     span = 1e6 * e / 1e5
     ts = torch.sort(torch.rand(e, dtype=torch.float64, generator=gen, device=dev) * span).values
     eid = torch.arange(1, e + 1, device=dev)

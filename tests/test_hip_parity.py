@@ -313,3 +313,22 @@ def test_linearity_property_of_gather_stage(hip):
         ya, yb, yab = f(pa), f(pb), f(2.0 * pa - 3.0 * pb)
         np.testing.assert_allclose(yab[:, :172].cpu().numpy(), (2.0 * ya - 3.0 * yb)[:, :172].cpu().numpy(), rtol=0, atol=2e-4)
         assert torch.equal(ya[:, 172:], yb[:, 172:])  # time channel does not depend on the PE table
+
+
+def test_segment_rows_sum_vs_index_add(hip):
+    """lstep_segment_rows_sum (chunked, hub-safe) against torch index_add on random groupings, incl. segments far longer
+    than one 128-entry chunk (atomic path) and strided source tables."""
+    from lstep_amd.model import _segment_reduce_rows
+
+    class M:
+        pe_dim = 172
+
+    torch.manual_seed(0)
+    for (n_rows, n_ent, nsrc, ld) in ((30, 100, 48, 288), (30, 1000, 48, 176), (5, 5000, 300, 288), (1000, 200000, 49152, 288), (7, 0, 10, 172)):
+        table = torch.randn(nsrc, ld, device=DEV)
+        seg = torch.randint(0, n_rows, (n_ent,), device=DEV)
+        src = torch.randint(0, nsrc, (n_ent,), device=DEV)
+        out = _segment_reduce_rows(M, n_rows, seg, src, table)
+        ref = torch.zeros(n_rows, 172, device=DEV, dtype=torch.float64).index_add_(0, seg, table[src][:, :172].double())
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((out.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n_ent / max(n_rows, 1)) ** 0.5)
