@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 3
+#define LSTEP_ABI_VERSION 4
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -124,19 +124,18 @@ int lstep_history_filter_bwd(const float* hist, int64_t node_stride, int64_t tim
                              int32_t time_rot, int32_t t_len, int32_t pe_dim, const int64_t* node_ids, int64_t num_ids,
                              const float* grad_out, float* out_partial, void* stream);
 
-/* Segmented row sums.  Entries e = 0..num_entries-1 are grouped by segment (ent_seg non-decreasing; segment s owns
- * entries [seg_begin[s], seg_end[s])); for every segment
+/* Segmented row sums.  Entry e = 0..num_entries-1 belongs to output row ent_seg[e]; entries of one segment must be
+ * adjacent (ent_seg grouped, e.g. sorted); for every segment s that occurs
  *   out[s, :W]    = sum_e table[ent_row[e], :W]                       (table row stride ld_table floats)
  *   out[s, W:W+D] = sum_e cos(ent_dt[e] * time_w + time_b)            (time_dim D may be 0: no time part, ent_dt unused)
- * `out` (row stride ld_out) MUST be zero-initialised by the caller: segments without entries stay zero and segments
- * longer than one 128-entry chunk are accumulated with float atomics (hub nodes), all others are plain stores in
- * entry order (deterministic).  Uses:
+ * `out` (row stride ld_out) MUST be zero-initialised by the caller: rows that own no entry stay zero, and a segment that
+ * straddles a 64-entry chunk boundary is accumulated with float atomics (long segments = hub nodes); all other
+ * segments are plain stores summed in entry order (deterministic).  Uses:
  *   update_pe U1/U2 (models/LSTEP.py:282-290, 319-322) with table = pe, D = time dim: replaces both dense [N+1, P+D]
  *   torch_scatter targets;  gather backward: table = grad of the PE aggregate, D = 0, segment = spliced PE row. */
 int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
-                           int32_t time_dim, const int64_t* seg_begin, const int64_t* seg_end, int64_t num_segments,
-                           const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt, int64_t num_entries,
-                           float* out, int32_t ld_out, void* stream);
+                           int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
+                           int64_t num_entries, float* out, int32_t ld_out, void* stream);
 
 /* In-place row write pe[ids[i], :] = rows[i, :] (models/LSTEP.py:303,339). ids must be unique. */
 int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* rows,

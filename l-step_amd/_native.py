@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 3
+ABI_VERSION = 4
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -77,7 +77,7 @@ SIGNATURES = {
     "lstep_history_filter_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
     "lstep_history_filter_bwd_chunks": (_I64, [_I64]),
     "lstep_history_filter_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
-    "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _I64, _P, _P, _P, _I64, _P, _I32, _P]),
+    "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
 }

@@ -1,13 +1,13 @@
 // Segmented row sums: U1 / U2 message accumulation of update_pe without the dense [N+1, P+D] scatter target
 //   (reference models/LSTEP.py:282-290: per batch edge, both directions; :319-322: per sampled neighbour), and the
 //   sort-based PE-gradient reduction of the gather backward.  Entries are pre-grouped by destination segment; the
-//   entry array is cut into fixed 128-entry chunks (one wave each) so hub segments cannot serialise the kernel.
+//   entry array is cut into fixed 64-entry chunks (one wave each) so hub segments cannot serialise the kernel.
 #include "lstep_common.h"
 
 namespace lstep {
 
 constexpr int kSegInFlight = 8;
-constexpr int kChunk = 128;  // entries per wave: bounds the work of one wave whatever the segment-length distribution is
+constexpr int kChunk = 64;   // entries per wave: bounds the work of one wave whatever the segment-length distribution is
 
 // flush one run of a segment: plain store when this chunk holds the whole segment, float atomics (contiguous dwords
 // per wave-instruction) when the segment is split over several chunks (long segments = hub nodes)
@@ -30,11 +30,12 @@ __device__ __forceinline__ void flush_run(float* __restrict__ o, const float4& a
     }
 }
 
-// Entries are sorted by segment; wave c owns entries [c * kChunk, (c + 1) * kChunk).  Inside the chunk the wave walks the
-// runs of equal segment id, summing table rows (8 in flight) and time features, and flushes each run.
+// Entries are sorted by segment; wave c owns entries [c * kChunk, (c + 1) * kChunk).  Rows are fetched 8 at a time
+// regardless of segment boundaries (memory-level parallelism does not depend on the run lengths); the accumulation
+// walks the entries in order and flushes a run whenever the segment id changes.  Only the first / last run of a chunk
+// can belong to a segment that continues in a neighbouring chunk: those are the runs flushed with atomics.
 __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* __restrict__ table, int W, int ld_table,
                                                                    const float* __restrict__ tw, const float* __restrict__ tb, int D,
-                                                                   const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end,
                                                                    const int32_t* __restrict__ ent_seg, const int32_t* __restrict__ ent_row,
                                                                    const float* __restrict__ ent_dt, int64_t num_entries,
                                                                    float* __restrict__ out, int ld_out) {
@@ -43,6 +44,8 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
     const int64_t e0 = chunk * kChunk;
     if (e0 >= num_entries) return;
     const int64_t e1 = (e0 + kChunk < num_entries) ? e0 + kChunk : num_entries;
+    const int seg_prev = e0 > 0 ? ent_seg[e0 - 1] : -1;            // segment that may spill in from the previous chunk
+    const int seg_next = e1 < num_entries ? ent_seg[e1] : -1;      // segment that may spill over into the next chunk
     const bool wa = lane < (W >> 2);
     const float w0 = lane < D ? tw[lane] : 0.f, b0 = lane < D ? tb[lane] : 0.f;
     const float w1 = lane + kWave < D ? tw[lane + kWave] : 0.f, b1 = lane + kWave < D ? tb[lane + kWave] : 0.f;
@@ -59,47 +62,35 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
             if (D > 0) dt = ent_dt[c0 + lane];
         }
         settle(sg ^ r ^ __float_as_int(dt));
-        int j = 0;
-        while (j < m) {
-            const int sj = bcast_i32(sg, j);
-            if (sj != cur) {
-                if (cur >= 0) {
-                    const bool whole = seg_begin[cur] >= e0 && seg_end[cur] <= e1;
-                    flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, whole, lane);
-                }
-                cur = sj;
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                t0 = t1 = 0.f;
-            }
-            // length of this run inside the 64-entry window, capped at the rows-in-flight group size
-            int n = 1;
-            while (j + n < m && n < kSegInFlight && bcast_i32(sg, j + n) == sj) ++n;
+        for (int j = 0; j < m; j += kSegInFlight) {
             float4 x[kSegInFlight];
             if (wa) {
 #pragma unroll
                 for (int u = 0; u < kSegInFlight; ++u) {
-                    const int64_t rj = bcast_i32(r, (u < n) ? (j + u) : j);   // tail slots re-read the first row, weight 0
+                    const int64_t rj = bcast_i32(r, (j + u) < m ? (j + u) : (m - 1));  // tail slots re-read the last row (unused)
                     x[u] = ld4(table + rj * ld_table + lane * 4);
                 }
             }
-            if (D > 0) {
-                for (int u = 0; u < n; ++u) {
+#pragma unroll
+            for (int u = 0; u < kSegInFlight; ++u) {
+                if ((j + u) >= m) break;
+                const int sj = bcast_i32(sg, j + u);
+                if (sj != cur) {
+                    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, lane);
+                    cur = sj;
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    t0 = t1 = 0.f;
+                }
+                if (wa) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+                if (D > 0) {
                     const float dj = bcast_f32(dt, j + u);
                     if (lane < D) t0 += time_feat(dj, w0, b0);
                     if (lane + kWave < D) t1 += time_feat(dj, w1, b1);
                 }
             }
-            if (wa) {
-#pragma unroll
-                for (int u = 0; u < kSegInFlight; ++u) fma4(acc, (u < n) ? 1.f : 0.f, x[u]);
-            }
-            j += n;
         }
     }
-    if (cur >= 0) {
-        const bool whole = seg_begin[cur] >= e0 && seg_end[cur] <= e1;
-        flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, whole, lane);
-    }
+    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, lane);
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(float* __restrict__ table, int W, const int64_t* __restrict__ ids,
@@ -130,22 +121,21 @@ __global__ __launch_bounds__(kBlock) void residual_tanh_rows_kernel(float* __res
 using namespace lstep;
 
 extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
-                                      int32_t time_dim, const int64_t* seg_begin, const int64_t* seg_end, int64_t num_segments,
-                                      const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt, int64_t num_entries, float* out,
-                                      int32_t ld_out, void* stream) {
-    if (num_segments < 0 || num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: negative count");
-    if (num_segments == 0 || num_entries == 0) return LSTEP_OK;
+                                      int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
+                                      int64_t num_entries, float* out, int32_t ld_out, void* stream) {
+    if (num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: negative count");
+    if (num_entries == 0) return LSTEP_OK;
     if (ld_table == 0) ld_table = width;
     if (ld_out == 0) ld_out = width + time_dim;
     if (width <= 0 || (width & 3) || width > 4 * kMaxRowVec || time_dim < 0 || (time_dim & 3) || time_dim > kMaxTimeDim || ld_table < width ||
         (ld_table & 3) || ld_out < width + time_dim || (ld_out & 3))
         return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: unsupported widths W=%d D=%d ld_table=%d ld_out=%d", width, time_dim, ld_table, ld_out);
-    if (!table || !seg_begin || !seg_end || !ent_seg || !ent_row || !out || (time_dim > 0 && (!time_w || !time_b || !ent_dt)))
+    if (!table || !ent_seg || !ent_row || !out || (time_dim > 0 && (!time_w || !time_b || !ent_dt)))
         return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: NULL pointer");
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, seg_begin, seg_end, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out);
     return check_launch("segment_rows_sum_kernel");
 }
 

@@ -145,16 +145,13 @@ def _segment_reduce_rows(mod, num_rows: int, seg_of_entry: torch.Tensor, src_row
     if seg_of_entry.numel() == 0:
         return out
     seg_s, order = torch.sort(seg_of_entry, stable=True)
-    counts = torch.bincount(seg_s, minlength=num_rows)
-    seg_end = torch.cumsum(counts, 0)
-    seg_begin = seg_end - counts
     # NOTE: every tensor whose address goes to the C ABI must stay referenced until the launch has been issued: a
     # temporary dies as soon as nat.ptr() returns and the caching allocator may hand its block to the next temporary.
     ent_seg = seg_s.to(torch.int32)
     ent_row = src_row[order].to(torch.int32)
     with torch.cuda.device(dev):
-        nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, int(table.stride(0)), None, None, 0, nat.ptr(seg_begin), nat.ptr(seg_end), num_rows,
-                                             nat.ptr(ent_seg), nat.ptr(ent_row), None, seg_s.numel(), nat.ptr(out), P, nat.current_stream()))
+        nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, int(table.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
+                                             ent_seg.numel(), nat.ptr(out), P, nat.current_stream()))
     return out
 
 
@@ -520,7 +517,7 @@ class LSTEP(nn.Module):
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
-    def _segment_sum(self, pe, seg_begin, seg_end, nseg, ent_seg, ent_row, ent_dt):
+    def _segment_sum(self, pe, nseg, ent_seg, ent_row, ent_dt):
         """out[s] = sum over the entries of segment s of cat[pe[ent_row], time_feat(ent_dt)]  (lstep_segment_rows_sum);
         rows are bucketed (``_bucket_rows``) and row-padded like the gather outputs, everything past the data is zero."""
         lib = nat.load_library()
@@ -528,8 +525,8 @@ class LSTEP(nn.Module):
         out = torch.zeros((self._bucket_rows(nseg), self.ld_pe), dtype=torch.float32, device=pe.device)
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_segment_rows_sum(nat.ptr(pe), P, P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
-                                                 nat.ptr(seg_begin), nat.ptr(seg_end), nseg, nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt),
-                                                 ent_row.numel(), nat.ptr(out), self.ld_pe, nat.current_stream()))
+                                                 nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), ent_row.numel(), nat.ptr(out), self.ld_pe,
+                                                 nat.current_stream()))
         return out
 
     def _update_mlp(self, agg):
@@ -578,11 +575,9 @@ class LSTEP(nn.Module):
             listed = bn_sorted[pos] == nodes if bn_sorted.numel() else torch.zeros_like(nodes, dtype=torch.bool)
             ids = bn_sorted
             seg_of_node = torch.where(listed, pos, torch.full_like(pos, -1))
-            cnt = torch.zeros(ids.numel(), dtype=torch.int64, device=ids.device)
-            cnt[pos[listed]] = counts[listed]
         else:
             order, inverse, counts = presorted
-            ids, cnt = bn, counts
+            ids = bn
             seg_of_node = torch.arange(bn.numel(), device=bn.device)
         ent_seg = seg_of_node[inverse]
         ent_row = torch.cat([dst, src])[order]
@@ -593,12 +588,10 @@ class LSTEP(nn.Module):
             newpos = torch.cumsum(mine, 0) - 1
             keep_e = keep_e & mine[ent_seg.clamp(min=0)]
             ent_seg = newpos[ent_seg.clamp(min=0)]
-            ids, cnt = ids[mine], cnt[mine]
+            ids = ids[mine]
         if presorted is None or shard is not None:
             ent_seg, ent_row, ent_dt = ent_seg[keep_e], ent_row[keep_e], ent_dt[keep_e]
-        seg_end = torch.cumsum(cnt, 0)
-        seg_begin = seg_end - cnt
-        agg = self._segment_sum(pe, seg_begin, seg_end, ids.numel(), ent_seg.to(torch.int32), ent_row.to(torch.int32), ent_dt.contiguous())
+        agg = self._segment_sum(pe, ids.numel(), ent_seg.to(torch.int32), ent_row.to(torch.int32), ent_dt.contiguous())
         n = ids.numel()
         own = torch.zeros((agg.shape[0], self.pe_dim), dtype=torch.float32, device=pe.device)
         own[:n] = pe[ids]
@@ -625,9 +618,7 @@ class LSTEP(nn.Module):
             real = real & ((key % shard[0]) == shard[1])
         key_r = key[real]
         key_s, order = torch.sort(key_r, stable=True)
-        touched, inverse, counts = torch.unique_consecutive(key_s, return_inverse=True, return_counts=True)
-        seg_end = torch.cumsum(counts, 0)
-        seg_begin = seg_end - counts
+        touched, inverse = torch.unique_consecutive(key_s, return_inverse=True)
         ent_row = rep[real][order].to(torch.int32)
         ent_dt = dt2[real][order].contiguous()
         nseg = touched.numel()
@@ -637,13 +628,12 @@ class LSTEP(nn.Module):
             with_row0 = bool((zeros_per_row > 0).any())
         if with_row0:
             # row 0 collects cat[pe[source], 0] from every padded slot: a weighted column sum instead of a hot segment.
-            # It goes first (ids are sorted): segment 0 is empty and its aggregate is filled in afterwards.
-            zero = torch.zeros(1, dtype=torch.int64, device=dev)
-            seg_begin, seg_end, touched = torch.cat([zero, seg_begin]), torch.cat([zero, seg_end]), torch.cat([zero, touched])
-            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg + 1, (inverse + 1).to(torch.int32), ent_row, ent_dt)
+            # It goes first (ids are sorted): segment 0 has no entries and its aggregate is filled in afterwards.
+            touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
+            agg2 = self._segment_sum(pe, nseg + 1, (inverse + 1).to(torch.int32), ent_row, ent_dt)
             agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
         else:
-            agg2 = self._segment_sum(pe, seg_begin, seg_end, nseg, inverse.to(torch.int32), ent_row, ent_dt)
+            agg2 = self._segment_sum(pe, nseg, inverse.to(torch.int32), ent_row, ent_dt)
         return touched, self._update_mlp(agg2)[:touched.numel()]
 
     @torch.no_grad()
