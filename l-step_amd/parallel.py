@@ -11,7 +11,7 @@ cooperate on ONE global batch of ``W * B`` edges at a time (weak scaling: B per 
               (padded, <= 22 MB per 32 K nodes) and written into every replica of the current table.
   combine     rank r runs the fused gather + dense tails for ITS B edges (3B rows); the loss is the mean over the
               global batch, i.e. the mean of the rank means.
-  backward    gradients w.r.t. the spliced rows are ALL-REDUCED, each rank back-propagates its owned rows through its
+  backward    gradients w.r.t. the spliced rows are REDUCE-SCATTERED by owner, each rank back-propagates its owned rows through its
               history shard into the filter coefficients; parameter gradients are ALL-REDUCED (one flat bucket, 2.3 MB).
   update_pe   both phases are sharded by the owner of the UPDATED row (phase 1: batch nodes; phase 2: touched
               neighbours); the new rows are ALL-GATHERED ("updated positional encodings at snapshot boundaries",
@@ -38,23 +38,34 @@ def _staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def all_gather_var(t: torch.Tensor, group=None):
-    """All-gather of row blocks with different row counts.  Returns (concatenated rows in rank order, counts list)."""
+def all_gather_var(t: torch.Tensor, group=None, counts=None):
+    """All-gather of row blocks with different row counts.  Returns (concatenated rows in rank order, counts list).
+    ``counts`` (rows per rank) may be passed when every rank can derive it locally: that saves the size exchange and its
+    host sync.  RCCL path: one ``all_gather_into_tensor`` of equal padded blocks; gloo: list all_gather (CPU staging)."""
     w = dist.get_world_size(group)
     dev = t.device
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device="cpu" if _staged(t, group) else dev)
-    ns = [torch.zeros_like(n) for _ in range(w)]
-    dist.all_gather(ns, n, group=group)
-    counts = [int(x.item()) for x in ns]
+    staged = _staged(t, group)
+    if counts is None:
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device="cpu" if staged else dev)
+        ns = [torch.zeros_like(n) for _ in range(w)]
+        dist.all_gather(ns, n, group=group)
+        counts = [int(x.item()) for x in ns]
     mx = max(counts)
+    if w == 1:
+        return t, counts
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
     pad[: t.shape[0]] = t
-    if _staged(t, group):
-        pad = pad.cpu()
-    outs = [torch.empty_like(pad) for _ in range(w)]
-    dist.all_gather(outs, pad, group=group)
-    cat = torch.cat([o[:c] for o, c in zip(outs, counts)], dim=0)
-    return cat.to(dev), counts
+    if dist.get_backend(group) == "gloo":
+        if staged:
+            pad = pad.cpu()
+        outs = [torch.empty_like(pad) for _ in range(w)]
+        dist.all_gather(outs, pad, group=group)
+        return torch.cat([o[:c] for o, c in zip(outs, counts)], dim=0).to(dev), counts
+    out = torch.empty((w, mx) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if all(c == mx for c in counts):
+        return out.reshape((w * mx,) + tuple(t.shape[1:])), counts
+    return torch.cat([out[i, :c] for i, c in enumerate(counts)], dim=0), counts
 
 
 def all_reduce_sum(t: torch.Tensor, group=None):
@@ -65,6 +76,26 @@ def all_reduce_sum(t: torch.Tensor, group=None):
     else:
         dist.all_reduce(t, group=group)
     return t
+
+
+def reduce_scatter_var(t: torch.Tensor, counts, group=None):
+    """Sum ``t`` (rows ordered rank-major, ``counts[r]`` rows for rank r) over all ranks and return THIS rank's block.
+    RCCL: one reduce_scatter of equal padded blocks (each rank receives only what it owns: half the traffic of an
+    all-reduce); gloo (CPU tests / staged CUDA tensors): all_reduce + slice."""
+    w, r = dist.get_world_size(group), dist.get_rank(group)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    if dist.get_backend(group) == "gloo":
+        all_reduce_sum(t, group)
+        return t[offs[r]:offs[r + 1]]
+    mx = max(counts)
+    padded = torch.zeros((w, mx) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    for i, c in enumerate(counts):
+        padded[i, :c] = t[offs[i]:offs[i + 1]]
+    out = torch.empty((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.reduce_scatter_tensor(out, padded, group=group)
+    return out[:counts[r]]
 
 
 def all_reduce_gradients(params, group=None):
@@ -78,11 +109,20 @@ def all_reduce_gradients(params, group=None):
         views.append(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad)
     flat = torch.cat([v.reshape(-1) for v in views])
     all_reduce_sum(flat, group)
-    off = 0
-    for v in views:
-        n = v.numel()
-        v.copy_(flat[off:off + n].view_as(v))
-        off += n
+    torch._foreach_copy_(views, [c.view_as(v) for c, v in zip(torch.split(flat, [v.numel() for v in views]), views)])
+
+
+def pack_ids(z: torch.Tensor, ids: torch.Tensor, width: int) -> torch.Tensor:
+    """Hide the int64 row ids in two of z's zero padding columns (bit patterns), so ids and rows travel in ONE collective.
+    z is [n, ld] with ld >= width + 2; the residual kernel only reads the first ``width`` columns."""
+    assert z.shape[1] >= width + 2 and z.dtype == torch.float32
+    z = z.contiguous()
+    z[:, width:width + 2] = ids.to(torch.int64).view(torch.int32).view(-1, 2).view(torch.float32)
+    return z
+
+
+def unpack_ids(z: torch.Tensor, width: int) -> torch.Tensor:
+    return z[:, width:width + 2].contiguous().view(torch.int32).view(torch.int64).reshape(-1)
 
 
 def owned_rows(num_rows: int, world: int, rank: int) -> int:
@@ -123,33 +163,35 @@ class DistributedLstep:
     # ---- pieces
     def _splice(self, bn: torch.Tensor, batch_idx: int):
         """Owner-sharded FFT filter + all-gather of the filtered rows; returns (local rows with grad, leaf of all rows, perm)."""
-        own = (bn % self.W) == self.rank
-        mine = bn[own]
+        owner = bn % self.W
+        counts = torch.bincount(owner, minlength=self.W).tolist()      # every rank derives the same counts: no size exchange
+        mine = bn[owner == self.rank]
         rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx)
-        gathered, counts = all_gather_var(rows_mine.detach(), self.group)
+        gathered, _ = all_gather_var(rows_mine.detach(), self.group, counts=counts)
         # gathered is ordered by (owner rank, node id); bn is ordered by node id
-        order = torch.argsort(bn % self.W, stable=True)
+        order = torch.argsort(owner, stable=True)
         rows_all = torch.empty_like(gathered)
         rows_all[order] = gathered
         self.table.index_copy_(0, bn, rows_all)
         self.slot_of[bn] = torch.arange(bn.numel(), dtype=torch.int32, device=self.device)
         leaf = rows_all.detach().requires_grad_(True)
-        return rows_mine, leaf, own
+        return rows_mine, leaf, (order, counts)
 
     def _probabilities(self, a, b):
         return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
 
-    def _update(self, bn, src, dst, ts):
+    def _update(self, bn, src, dst, ts, presorted=None, owner_counts=None):
         now32 = float(np.float32(float(ts.max().item())))
         shard = (self.W, self.rank)
+        P = self.bb.pe_dim
         for phase in (1, 2):
             if phase == 1:
-                ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard)
+                ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
             else:
                 ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
-            ids_all, _ = all_gather_var(ids, self.group)
-            z_all, _ = all_gather_var(z, self.group)
-            self.bb.apply_residual_tanh(self.table, ids_all, z_all)   # every replica applies the same residual update
+            # ids ride in z's padding columns: one collective per phase; phase-1 row counts are known locally
+            z_all, _ = all_gather_var(pack_ids(z, ids, P), self.group, counts=owner_counts if phase == 1 else None)
+            self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)   # every replica applies the same update
 
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):
@@ -157,12 +199,13 @@ class DistributedLstep:
         assert n_glob % self.W == 0, "global batch must divide by the world size"
         b = n_glob // self.W
         sl = slice(self.rank * b, (self.rank + 1) * b)
-        bn = torch.unique(torch.cat([src, dst]))
+        bn, presorted = LstepEngine.batch_nodes_and_segments(src, dst)
         out, loss = None, None
+        owner_counts = None
         if batch_idx == 0:
             self.table.copy_(initial_pe)
         else:
-            rows_mine, leaf, own = self._splice(bn, batch_idx)
+            rows_mine, leaf, (owner_order, owner_counts) = self._splice(bn, batch_idx)
             spliced = SplicedRows(leaf, self.slot_of)
             s_, d_, n_, t_ = src[sl], dst[sl], neg_dst[sl], ts[sl]
             emb = self.bb.combining_pe_raw_feat(self.table, torch.cat([s_, d_, n_]), torch.cat([t_, t_, t_]), self.K, self.G, spliced=spliced)
@@ -176,7 +219,7 @@ class DistributedLstep:
             pe_loss = F.mse_loss(e_src, _lookup_rows(self.table, spliced, d_)) - self.eng.neg_sample_weight * F.mse_loss(e_src, _lookup_rows(self.table, spliced, n_))
             loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
-        self._update(bn, src, dst, ts)
+        self._update(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts)
         if batch_idx == 0 and initial_pe is not None:
             initial_pe.copy_(self.table)
         self._append_snapshot()
@@ -184,9 +227,10 @@ class DistributedLstep:
             optimizer.zero_grad()
             (loss / self.W).backward()                       # global mean = mean of the rank means
             g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
-            all_reduce_sum(g_rows, self.group)               # every rank's loss touches every spliced row
+            # every rank's loss touches every spliced row; each rank needs the summed gradient of the rows it owns
+            g_mine = reduce_scatter_var(g_rows[owner_order].contiguous(), owner_counts, self.group)
             if rows_mine.numel():
-                rows_mine.backward(g_rows[own])              # -> fft_filter / fft_agg through this rank's history shard
+                rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
             all_reduce_gradients(list(self.bb.parameters()) + list(self.predictor.parameters()), self.group)
             optimizer.step()
             self.slot_of[bn] = -1

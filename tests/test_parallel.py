@@ -31,7 +31,7 @@ def _init(rank, world, port):
 def _cpu_worker(rank, world, port, q):
     try:
         _init(rank, world, port)
-        from lstep_amd.parallel import all_gather_var, all_reduce_gradients, all_reduce_sum, owned_rows
+        from lstep_amd.parallel import all_gather_var, all_reduce_gradients, all_reduce_sum, owned_rows, reduce_scatter_var
         # uneven row blocks, incl. an empty one
         t = torch.arange(rank * 3 * 4, dtype=torch.float32).reshape(rank * 3, 4) + 100 * rank
         cat, counts = all_gather_var(t)
@@ -39,6 +39,8 @@ def _cpu_worker(rank, world, port, q):
         ids = torch.tensor([5, 7, 9][: rank + 1], dtype=torch.int64)
         cat, counts = all_gather_var(ids)
         assert cat.tolist() == [5, 5, 7] and counts == [1, 2]
+        blk = reduce_scatter_var(torch.arange(10, dtype=torch.float32).reshape(5, 2) * (rank + 1), [2, 3])
+        assert torch.equal(blk, (torch.arange(10, dtype=torch.float32).reshape(5, 2) * 3)[:2] if rank == 0 else (torch.arange(10, dtype=torch.float32).reshape(5, 2) * 3)[2:])
         v = torch.full((3,), float(rank + 1))
         assert all_reduce_sum(v).tolist() == [3.0, 3.0, 3.0]
         lin = torch.nn.Linear(3, 2)
