@@ -479,9 +479,13 @@ class LSTEP(nn.Module):
         """
         T = self.num_fft_batches
         dev = self.fft_agg.weight.device
-        k = torch.arange(T, device=dev, dtype=torch.float64)
-        ang = (2.0 * math.pi / T) * torch.outer(k, k)
-        e_pos = torch.polar(torch.ones_like(ang), ang)          # e^{+i 2 pi f t / T}, [f, t]
+        cache = getattr(self, "_dft_cache", None)
+        if cache is None or cache[0] != (T, dev):
+            k = torch.arange(T, device=dev, dtype=torch.float64)
+            ang = (2.0 * math.pi / T) * torch.outer(k, k)
+            e_pos = torch.polar(torch.ones_like(ang), ang)      # e^{+i 2 pi f t / T}, [f, t]
+            self._dft_cache = cache = ((T, dev), k, e_pos, e_pos.conj().t().contiguous())
+        _, k, e_pos, e_neg_t = cache
         if t_len < T:
             m = (k < batch_idx).to(torch.float64)
         else:
@@ -489,7 +493,7 @@ class LSTEP(nn.Module):
         a = self.fft_agg.weight.reshape(-1).to(torch.float64) * m
         big_a = e_pos @ a.to(torch.complex128)                    # [f]
         q = (m.unsqueeze(1) * self.fft_filter.weight.to(torch.complex128)) * big_a.unsqueeze(1) / T   # [f, P]
-        coef = (e_pos.conj().t() @ q).real                        # [s, P]: sum_f e^{-i 2 pi f s / T} q[f, p]
+        coef = (e_neg_t @ q).real                                 # [s, P]: sum_f e^{-i 2 pi f s / T} q[f, p]
         return coef.to(torch.float32)
 
     def fourier_transform_pe(self, node_ids, pe, batch_idx, use_dropout=False, use_mixer=False):

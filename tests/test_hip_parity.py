@@ -332,3 +332,40 @@ def test_segment_rows_sum_vs_index_add(hip):
         ref = torch.zeros(n_rows, 172, device=DEV, dtype=torch.float64).index_add_(0, seg, table[src][:, :172].double())
         scale = max(1.0, float(ref.abs().max()))
         assert float((out.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n_ent / max(n_rows, 1)) ** 0.5)
+
+
+def test_large_tables_64bit_addressing_vs_oracle(hip):
+    """4 M edges x 172 floats = 2.75 GB edge table: row offsets exceed 2^31 bytes, CSR built on the GPU.  A sample of rows of
+    combining_pe_raw_feat (time_gap = 2000) is checked against the CPU oracle, sampled neighbourhoods bit-exact."""
+    from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model
+    N, E, K, T, B = 200_000, 4_000_000, 20, 4, 192
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(7)
+    src = torch.randint(1, N + 1, (E,), generator=gen, device=DEV)
+    dst = torch.randint(1, N + 1, (E,), generator=gen, device=DEV)
+    ts = torch.sort(torch.rand(E, dtype=torch.float64, generator=gen, device=DEV) * 4e7).values
+    eid = torch.arange(1, E + 1, device=DEV)
+    node_raw = torch.randn((N + 1, 172), generator=gen, device=DEV)
+    edge_raw = torch.randn((E + 1, 172), generator=gen, device=DEV)
+    node_raw[0] = 0
+    edge_raw[0] = 0
+    pe = 0.1 * torch.randn((N + 1, 172), generator=gen, device=DEV)
+    hs = hip.NeighborSampler.from_device_edges(src, dst, eid, ts, N)
+    sd = synth.make_state_dict(K, T, seed=11)
+    hm = hip.build(node_raw, edge_raw, hs, K, T, sd, DEV)
+    # queries late in the stream (edge ids near E -> byte offsets > 2^31) plus hubs-free uniform nodes
+    rows = torch.arange(E - B, E, device=DEV)
+    q_ids, q_ts = dst[rows], ts[rows]
+    with torch.no_grad():
+        got = hm[0].combining_pe_raw_feat(pe, q_ids, q_ts, K, 2000).cpu().numpy()
+    nbr, eidk, nt = hs.get_historical_neighbors(q_ids.cpu().numpy(), q_ts.cpu().numpy(), K)
+    assert eidk.max() * 688 > 2 ** 31
+    osamp = OracleNeighborSampler(src.cpu().numpy(), dst.cpu().numpy(), eid.cpu().numpy(), ts.cpu().numpy(), num_nodes=N)
+    o_nbr, o_eid, o_nt = osamp.get_historical_neighbors(q_ids.cpu().numpy(), q_ts.cpu().numpy(), K)
+    np.testing.assert_array_equal(nbr, o_nbr)
+    np.testing.assert_array_equal(eidk, o_eid)
+    np.testing.assert_array_equal(nt.view(np.uint32), o_nt.view(np.uint32))
+    om = build_oracle_model(node_raw.cpu().numpy(), edge_raw.cpu().numpy(), osamp, K, T, sd)
+    with torch.no_grad():
+        ref = om[0].combining_pe_raw_feat(pe.cpu(), q_ids.cpu().numpy(), q_ts.cpu().numpy(), K, 2000).numpy()
+    np.testing.assert_allclose(got, ref, **TOL)
