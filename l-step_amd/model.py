@@ -379,6 +379,9 @@ class LSTEP(nn.Module):
         if K != self.num_neighbors and (branches & nat.BRANCH_EDGE_NODE):
             raise RuntimeError(f"edge_agg was built for num_neighbors={self.num_neighbors}, got {K} "
                                "(the reference fails the same way at models/LSTEP.py:164)")
+        if getattr(self.neighbor_sampler, "sample_neighbor_strategy", "recent") != "recent":
+            raise NotImplementedError("the fused MI355X path implements sample_neighbor_strategy='recent' (the reference default, "
+                                      "utils/load_configs.py:22); RNG-defined strategies only have the host sampler API")
         self._check_rows(node_ids)
         ids, times = self._ids(node_ids), self._times(node_interact_times)
         if ids.numel() != times.numel():

@@ -7,8 +7,9 @@ What changes is where the data lives: the per-node Python lists become one time-
 (``int64 indptr``, ``int32 nbr``, ``int32 eid``, ``float64 ts`` -- 16 bytes per adjacency entry) and the per-row
 Python loop + ``np.searchsorted`` becomes ``lstep_sample_recent`` (one wave per row).
 
-Only the ``'recent'`` strategy runs on the device; ``'uniform'`` / ``'time_interval_aware'`` are defined by
-``np.random.RandomState.choice`` call order (``utils/utils.py:175-198``) and are a "next" row of SURVEY.md 8(f).
+Only the ``'recent'`` strategy runs on the device (and only it can feed the fused LSTEP kernels); ``'uniform'`` /
+``'time_interval_aware'`` are defined by ``np.random.RandomState.choice`` call order (``utils/utils.py:175-198``) and are
+replayed on the host for API parity.
 """
 from __future__ import annotations
 
@@ -50,9 +51,6 @@ class NeighborSampler:
                  device="cuda"):
         if sample_neighbor_strategy not in ("recent", "uniform", "time_interval_aware"):
             raise ValueError(f"Not implemented error for sample_neighbor_strategy {sample_neighbor_strategy}!")
-        if sample_neighbor_strategy != "recent":
-            raise NotImplementedError("only sample_neighbor_strategy='recent' runs on the MI355X path "
-                                      "(uniform / time_interval_aware replay numpy's RNG on the host: SURVEY.md 8f-2)")
         nat.load_library()  # fail loudly if the HIP library is missing
         self.sample_neighbor_strategy = sample_neighbor_strategy
         self.time_scaling_factor = time_scaling_factor
@@ -65,6 +63,12 @@ class NeighborSampler:
         self.nbr = torch.from_numpy(nbr).to(self.device)
         self.eid = torch.from_numpy(eid).to(self.device)
         self.ts = torch.from_numpy(ts).to(self.device)
+        if sample_neighbor_strategy != "recent":
+            # uniform / time_interval_aware are DEFINED by numpy's RandomState.choice call order (utils/utils.py:175-198):
+            # they replay on the host from a host copy of the CSR; the device path serves 'recent'.
+            self._host = (indptr, nbr.astype(np.int64), eid.astype(np.int64), ts)
+            if seed is not None:
+                self.random_state = np.random.RandomState(seed)
         if self.nnz == 0:  # keep valid device pointers for empty graphs
             self.nbr = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.eid = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -131,9 +135,47 @@ class NeighborSampler:
                                               nat.ptr(nbr), nat.ptr(eid), nat.ptr(nt), nat.ptr(cnt), nat.current_stream()))
         return (nbr, eid, nt, cnt) if want_count else (nbr, eid, nt)
 
+    def _sampled_probabilities(self, times: np.ndarray) -> np.ndarray:
+        """CAWN-style time-interval-aware weights of one node's full history (utils/utils.py:111-127)."""
+        if len(times) == 0:
+            return np.array([])
+        rel = times - np.max(times)
+        w = np.exp(self.time_scaling_factor * rel)
+        p = w / np.cumsum(w)
+        p[np.isnan(p)] = -1e10
+        return p
+
+    def _sample_random_host(self, node_ids, node_interact_times, num_neighbors):
+        """'uniform' / 'time_interval_aware' (utils/utils.py:175-198): per row, in row order, one RandomState.choice over the
+        interactions strictly before the query time, then a re-sort of the sampled slots by (float32) time."""
+        indptr, nbrs, eids, tss = self._host
+        rows = len(node_ids)
+        out_n = np.zeros((rows, num_neighbors), dtype=np.longlong)
+        out_e = np.zeros((rows, num_neighbors), dtype=np.longlong)
+        out_t = np.zeros((rows, num_neighbors), dtype=np.float32)
+        rng = np.random if self.seed is None else self.random_state
+        for r, (node, t) in enumerate(zip(node_ids, node_interact_times)):
+            lo, hi = indptr[node], indptr[node + 1]
+            cnt = int(np.searchsorted(tss[lo:hi], t))
+            if cnt == 0:
+                continue
+            p = None
+            if self.sample_neighbor_strategy == "time_interval_aware":
+                p = torch.softmax(torch.from_numpy(self._sampled_probabilities(tss[lo:hi])[:cnt]).float(), dim=0).numpy()
+            pick = rng.choice(a=cnt, size=num_neighbors, p=p)
+            out_n[r, :], out_e[r, :], out_t[r, :] = nbrs[lo + pick], eids[lo + pick], tss[lo + pick]
+            order = out_t[r, :].argsort()
+            out_n[r, :], out_e[r, :], out_t[r, :] = out_n[r, :][order], out_e[r, :][order], out_t[r, :][order]
+        return out_n, out_e, out_t
+
     # ---- reference-shaped entry point: numpy in, numpy out (utils/utils.py:148-213)
     def get_historical_neighbors(self, node_ids: np.ndarray, node_interact_times: np.ndarray, num_neighbors: int = 20):
         assert num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!"
+        if self.sample_neighbor_strategy != "recent":
+            ids = np.asarray(node_ids)
+            if ids.size and (ids.min() < 0 or ids.max() >= self.num_rows):
+                raise IndexError("list index out of range")
+            return self._sample_random_host(ids, np.asarray(node_interact_times), num_neighbors)
         ids = np.ascontiguousarray(node_ids, dtype=np.int64)
         if ids.size and (ids.min() < 0 or ids.max() >= self.num_rows):
             raise IndexError("list index out of range")  # what the reference's list lookup raises

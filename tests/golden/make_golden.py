@@ -301,9 +301,63 @@ def gen_traces():
     print("traces.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------- RNG-defined sampling
+def gen_random_sampling():
+    from utils.utils import get_neighbor_sampler as ref_get
+    g = synth.make_temporal_graph(num_nodes=40, num_edges=900, seed=50, tie_quantum=5.0)
+    data = Data(g["src"], g["dst"], g["ts"], g["eid"], np.zeros(900))
+    rng = np.random.RandomState(51)
+    ids = rng.randint(0, 41, size=60).astype(np.int64)
+    ts = rng.uniform(g["ts"][0] - 1, g["ts"][-1] + 1, size=60)
+    out = {"ids": ids, "ts": ts}
+    for strat, tsf in (("uniform", 0.0), ("time_interval_aware", 1e-3)):
+        s = ref_get(data, sample_neighbor_strategy=strat, time_scaling_factor=tsf, seed=3)
+        for call in range(2):  # the RNG state carries over between calls
+            for k in (3, 10):
+                nbr, eid, nt = s.get_historical_neighbors(ids, ts, k)
+                out[f"{strat}/call{call}/k{k}/nbr"], out[f"{strat}/call{call}/k{k}/eid"], out[f"{strat}/call{call}/k{k}/nt"] = nbr, eid, nt
+        s.reset_random_state()
+        nbr, eid, nt = s.get_historical_neighbors(ids, ts, 3)
+        out[f"{strat}/reset/k3/nbr"] = nbr
+    np.savez_compressed(os.path.join(HERE, "random_sampling.npz"), **out)
+    print("random_sampling.npz", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------- data loader split
+def loader_dataset(tmp):
+    """Tiny dataset in the reference's on-disk format (regenerated identically by tests/test_data_loader.py)."""
+    from lstep_amd import data as ld
+    g = synth.make_temporal_graph(num_nodes=120, num_edges=1500, seed=40, tie_quantum=7.0)
+    rng = np.random.RandomState(41)
+    ld.write_dataset(os.path.join(tmp, "processed_data"), "tiny", g["src"], g["dst"], g["ts"], rng.randint(0, 2, size=1500),
+                     rng.standard_normal((1501, 12)), np.zeros((121, 172)))
+
+
+def gen_loader():
+    import tempfile
+    from utils.DataLoader import get_link_prediction_data
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        loader_dataset(tmp)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            res = get_link_prediction_data("tiny", 0.15, 0.15)
+        finally:
+            os.chdir(cwd)
+    out["node_shape"], out["edge_shape"] = np.asarray(res[0].shape), np.asarray(res[1].shape)
+    out["edge_digest"] = np.asarray([res[1].sum(), np.abs(res[1]).sum()])
+    for name, d in zip(("full", "train", "val", "test", "new_val", "new_test"), res[2:]):
+        out[f"{name}/edge_ids"] = d.edge_ids
+        out[f"{name}/src"] = d.src_node_ids
+        out[f"{name}/num_unique_nodes"] = np.asarray([d.num_unique_nodes])
+    np.savez_compressed(os.path.join(HERE, "loader.npz"), **out)
+    print("loader.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["sampler", "time", "methods", "traces"]
+    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling"]
     if "sampler" in which:
         gen_sampler()
     if "time" in which:
@@ -312,3 +366,7 @@ if __name__ == "__main__":
         gen_methods()
     if "traces" in which:
         gen_traces()
+    if "loader" in which:
+        gen_loader()
+    if "random_sampling" in which:
+        gen_random_sampling()

@@ -105,8 +105,13 @@ def test_sampler_errors(hip):
         s.get_historical_neighbors(np.array([99]), np.array([1.0]), 3)
     out = s.get_historical_neighbors(np.zeros(0, dtype=np.int64), np.zeros(0), 4)
     assert out[0].shape == (0, 4)
+    # RNG-defined strategies exist as a host replay (API parity) but cannot feed the fused kernels
+    u = hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], sample_neighbor_strategy="uniform", seed=0, device=DEV)
+    assert u.get_historical_neighbors(np.array([1, 2]), np.array([1e9, 1e9]), 4)[0].shape == (2, 4)
+    node_raw, edge_raw = synth.make_features(8, 40, seed=2)
+    m = hip.build(node_raw, edge_raw, u, 4, 4, None, DEV)
     with pytest.raises(NotImplementedError):
-        hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], sample_neighbor_strategy="uniform", seed=0, device=DEV)
+        m[0].aggregated_node_embeddings(np.array([1, 2]), np.array([1e9, 1e9]), 4, 8)
 
 
 # ------------------------------------------------------------------------------------------------ T

@@ -112,3 +112,21 @@ def test_product_path_has_no_oracle_import():
         if fn.endswith(".py"):
             hit = pat.search(open(os.path.join(src_dir, fn)).read())
             assert (hit is None) or fn == "smoke.py", fn
+
+
+@pytest.mark.parametrize("strategy,tsf", [("uniform", 0.0), ("time_interval_aware", 1e-3)])
+def test_rng_defined_sampling_replays_the_reference(golden, strategy, tsf):
+    """SURVEY.md 8(f) rank 2: uniform / time_interval_aware sampling are defined by numpy's RandomState.choice call order;
+    the host replay must match the reference draw for draw (incl. the RNG state carried between calls and reset)."""
+    from lstep_amd.sampler import NeighborSampler
+    z = golden("random_sampling")
+    g = synth.make_temporal_graph(num_nodes=40, num_edges=900, seed=50, tie_quantum=5.0)
+    s = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], sample_neighbor_strategy=strategy, time_scaling_factor=tsf, seed=3, device="cpu")
+    for call in range(2):
+        for k in (3, 10):
+            nbr, eid, nt = s.get_historical_neighbors(z["ids"], z["ts"], k)
+            np.testing.assert_array_equal(nbr, z[f"{strategy}/call{call}/k{k}/nbr"])
+            np.testing.assert_array_equal(eid, z[f"{strategy}/call{call}/k{k}/eid"])
+            np.testing.assert_array_equal(nt.view(np.uint32), z[f"{strategy}/call{call}/k{k}/nt"].view(np.uint32))
+    s.reset_random_state()
+    np.testing.assert_array_equal(s.get_historical_neighbors(z["ids"], z["ts"], 3)[0], z[f"{strategy}/reset/k3/nbr"])
