@@ -161,12 +161,14 @@ def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self):
     lstep_segment_rows_sum: no atomics on hot (hub) rows, deterministic summation order."""
     K = hits.shape[1]
     total = torch.zeros((num_rows, mod.pe_dim), dtype=torch.float32, device=hits.device)
-    if g_pe is not None:
-        flat = hits.reshape(-1)
-        idx = torch.nonzero(flat >= 0).squeeze(1)
+    flat = hits.reshape(-1)
+    hit, hit_self = flat >= 0, self_slot >= 0
+    n_hit, n_self = torch.stack([hit.sum(), hit_self.sum()]).tolist()     # one host sync for both sizes
+    if g_pe is not None and n_hit:
+        idx = torch.nonzero_static(hit, size=n_hit).squeeze(1)
         total = total + _segment_reduce_rows(mod, num_rows, flat[idx].long(), idx // K, g_pe)
-    if g_self is not None:
-        idx = torch.nonzero(self_slot >= 0).squeeze(1)
+    if g_self is not None and n_self:
+        idx = torch.nonzero_static(hit_self, size=n_self).squeeze(1)
         total = total + _segment_reduce_rows(mod, num_rows, self_slot[idx].long(), idx, g_self)
     return total
 
@@ -623,19 +625,20 @@ class LSTEP(nn.Module):
         real = key != 0
         if shard is not None:
             real = real & ((key % shard[0]) == shard[1])
-        key_r = key[real]
-        key_s, order = torch.sort(key_r, stable=True)
+        own_row0 = shard is None or shard[1] == 0                # row 0 belongs to shard 0
+        # one host sync for both data-dependent sizes (boolean-mask indexing would sync once per use)
+        n_real, n_zero = torch.stack([real.sum(), (key == 0).sum()]).tolist()
+        idx = torch.nonzero_static(real, size=n_real).squeeze(1)
+        key_s, order = torch.sort(key[idx], stable=True)
         touched, inverse = torch.unique_consecutive(key_s, return_inverse=True)
-        ent_row = rep[real][order].to(torch.int32)
-        ent_dt = dt2[real][order].contiguous()
+        src_e = idx[order]
+        ent_row = rep[src_e].to(torch.int32)
+        ent_dt = dt2[src_e].contiguous()
         nseg = touched.numel()
-        with_row0 = False
-        if shard is None or shard[1] == 0:  # row 0 belongs to shard 0
-            zeros_per_row = (nbr == 0).sum(dim=1)                                       # slots that scatter into row 0
-            with_row0 = bool((zeros_per_row > 0).any())
-        if with_row0:
+        if own_row0 and n_zero > 0:
             # row 0 collects cat[pe[source], 0] from every padded slot: a weighted column sum instead of a hot segment.
             # It goes first (ids are sorted): segment 0 has no entries and its aggregate is filled in afterwards.
+            zeros_per_row = (nbr == 0).sum(dim=1)                                       # slots that scatter into row 0
             touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
             agg2 = self._segment_sum(pe, nseg + 1, (inverse + 1).to(torch.int32), ent_row, ent_dt)
             agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
