@@ -15,7 +15,8 @@ cooperate on ONE global batch of ``W * B`` edges at a time (weak scaling: B per 
               history shard into the filter coefficients; parameter gradients are ALL-REDUCED (one flat bucket, 2.3 MB).
   update_pe   both phases are sharded by the owner of the UPDATED row (phase 1: batch nodes; phase 2: touched
               neighbours); the new rows are ALL-GATHERED ("updated positional encodings at snapshot boundaries",
-              BASELINE.json north_star) and written into every replica; each rank appends its owned rows to its ring.
+              BASELINE.json north_star) and applied on every replica; each rank appends its owned rows to its ring.
+              The phase-2 gather (the largest message) is asynchronous and overlaps the backward pass.
 
 All collectives are small-to-medium one-shot gathers/reductions (no ring-pipelined bulk transfer is needed); the data
 path itself (gathers, GEMMs) has no collective inside.  Results equal the single-GPU engine on the same global batch up
@@ -66,6 +67,34 @@ def all_gather_var(t: torch.Tensor, group=None, counts=None):
     if all(c == mx for c in counts):
         return out.reshape((w * mx,) + tuple(t.shape[1:])), counts
     return torch.cat([out[i, :c] for i, c in enumerate(counts)], dim=0), counts
+
+
+class PendingGather:
+    """An all-gather of row blocks that is in flight on RCCL's stream (``async_op=True``) while the caller keeps
+    enqueueing compute; ``wait()`` makes the current stream wait for it and returns the concatenated rows."""
+
+    def __init__(self, t: torch.Tensor, group=None):
+        self.group, self.work, self.done = group, None, None
+        w = dist.get_world_size(group)
+        if dist.get_backend(group) == "gloo":
+            self.done = all_gather_var(t, group)[0]          # no asynchronous CUDA collectives on gloo: finish now
+            return
+        dev = t.device
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
+        ns = torch.empty((w,), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(ns, n, group=group)
+        self.counts = ns.tolist()
+        mx = max(self.counts)
+        self.pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        self.pad[: t.shape[0]] = t
+        self.out = torch.empty((w, mx) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        self.work = dist.all_gather_into_tensor(self.out, self.pad, group=group, async_op=True)
+
+    def wait(self) -> torch.Tensor:
+        if self.done is None:
+            self.work.wait()
+            self.done = torch.cat([self.out[i, :c] for i, c in enumerate(self.counts)], dim=0)
+        return self.done
 
 
 def all_reduce_sum(t: torch.Tensor, group=None):
@@ -180,18 +209,23 @@ class DistributedLstep:
     def _probabilities(self, a, b):
         return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
 
-    def _update(self, bn, src, dst, ts, presorted=None, owner_counts=None):
+    def _update_start(self, bn, src, dst, ts, presorted=None, owner_counts=None) -> PendingGather:
+        """Phase 1 completely (its rows feed phase 2), phase 2 up to the all-gather of its rows, which is left in flight."""
         now32 = float(np.float32(float(ts.max().item())))
         shard = (self.W, self.rank)
         P = self.bb.pe_dim
-        for phase in (1, 2):
-            if phase == 1:
-                ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
-            else:
-                ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
-            # ids ride in z's padding columns: one collective per phase; phase-1 row counts are known locally
-            z_all, _ = all_gather_var(pack_ids(z, ids, P), self.group, counts=owner_counts if phase == 1 else None)
-            self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)   # every replica applies the same update
+        ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
+        # ids ride in z's padding columns: one collective per phase; phase-1 row counts are known locally
+        z_all, _ = all_gather_var(pack_ids(z, ids, P), self.group, counts=owner_counts)
+        self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)       # every replica applies the same update
+        ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
+        return PendingGather(pack_ids(z, ids, P), self.group)
+
+    def _update_finish(self, pending: PendingGather):
+        """Apply the gathered phase-2 rows on every replica and append the snapshot to this rank's ring shard."""
+        z_all = pending.wait()
+        self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, self.bb.pe_dim), z_all)
+        self._append_snapshot()
 
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):
@@ -219,10 +253,13 @@ class DistributedLstep:
             pe_loss = F.mse_loss(e_src, _lookup_rows(self.table, spliced, d_)) - self.eng.neg_sample_weight * F.mse_loss(e_src, _lookup_rows(self.table, spliced, n_))
             loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
-        self._update(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts)
-        if batch_idx == 0 and initial_pe is not None:
-            initial_pe.copy_(self.table)
-        self._append_snapshot()
+        # update_pe: the all-gather of the phase-2 rows (the largest collective, ~0.7 KB per touched node) stays in flight
+        # while the backward pass runs; neither reads what the other writes
+        pending = self._update_start(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts)
+        if loss is None:
+            self._update_finish(pending)
+            if batch_idx == 0 and initial_pe is not None:
+                initial_pe.copy_(self.table)
         if loss is not None:
             optimizer.zero_grad()
             (loss / self.W).backward()                       # global mean = mean of the rank means
@@ -232,6 +269,7 @@ class DistributedLstep:
             if rows_mine.numel():
                 rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
             all_reduce_gradients(list(self.bb.parameters()) + list(self.predictor.parameters()), self.group)
+            self._update_finish(pending)
             optimizer.step()
             self.slot_of[bn] = -1
             # losses reported as global means
@@ -255,6 +293,5 @@ class DistributedLstep:
         p_neg = self._probabilities(emb[2 * b:3 * b], emb[3 * b:])
         predicts = torch.cat([p_pos, p_neg], dim=0)
         labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
-        self._update(bn, src, dst, ts)
-        self._append_snapshot()
+        self._update_finish(self._update_start(bn, src, dst, ts))
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

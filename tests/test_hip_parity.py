@@ -374,3 +374,34 @@ def test_large_tables_64bit_addressing_vs_oracle(hip):
     with torch.no_grad():
         ref = om[0].combining_pe_raw_feat(pe.cpu(), q_ids.cpu().numpy(), q_ts.cpu().numpy(), K, 2000).numpy()
     np.testing.assert_allclose(got, ref, **TOL)
+
+
+def test_many_slots_and_degenerate_batches(hip):
+    """K > 64 (several 64-slot chunks per row), batch of one row (the reference's .squeeze() breaks there; shapes stay 2-D
+    here) and an empty batch."""
+    from oracle.lstep_oracle import build_oracle_model
+    N, E, K, T = 60, 6000, 70, 4
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=111)
+    node_raw, edge_raw = synth.make_features(N, E, seed=112)
+    pe_np = synth.make_initial_pe(N, seed=113)
+    pe_np[0] = -0.03
+    sd = synth.make_state_dict(K, T, seed=114)
+    om = build_oracle_model(node_raw, edge_raw, oracle_sampler(g), K, T, sd)
+    hm = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, sd, DEV)
+    sl = slice(5000, 5040)
+    src, t = g["src"][sl], g["ts"][sl]
+    pe_h = torch.from_numpy(pe_np).to(DEV)
+    with torch.no_grad():
+        ref = om[0].combining_pe_raw_feat(torch.from_numpy(pe_np), src, t, K, 150).numpy()
+        got = hm[0].combining_pe_raw_feat(pe_h, src, t, K, 150).cpu().numpy()
+        np.testing.assert_allclose(got, ref, **TOL)
+        one = hm[0].combining_pe_raw_feat(pe_h, src[:1], t[:1], K, 150)
+        assert tuple(one.shape) == (1, 172)
+        np.testing.assert_allclose(one.cpu().numpy(), ref[:1], **TOL)
+        none = hm[0].combining_pe_raw_feat(pe_h, src[:0], t[:0], K, 150)
+        assert tuple(none.shape) == (0, 172)
+    # gradient of edge_agg.weight over 70 slots (slot dots of the backward kernel) vs oracle autograd
+    wgt = torch.from_numpy(np.random.RandomState(6).standard_normal((40, 172)).astype(np.float32))
+    (om[0].combining_pe_raw_feat(torch.from_numpy(pe_np), src, t, K, 150) * wgt).sum().backward()
+    (hm[0].combining_pe_raw_feat(pe_h, src, t, K, 150) * wgt.to(DEV)).sum().backward()
+    np.testing.assert_allclose(hm[0].edge_agg.weight.grad.cpu().numpy(), om[0].edge_agg.weight.grad.numpy(), rtol=0, atol=2e-4)
