@@ -72,6 +72,10 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return
 __device__ __forceinline__ float delta_t(double t, double nbr_ts) { return (float)(t - (double)(float)nbr_ts); }
 
 // TimeEncoder element: cos(dt * w + b) in float32 (models/modules.py:37).  Full-range cosf: arguments reach 1e9.
+#ifdef LSTEP_ABLATE_COS  // tuning experiment only: price of the full-range cosf (never defined in product builds)
+__device__ __forceinline__ float time_feat(float dt, float w, float b) { return fmaf(dt, w, b); }
+#else
 __device__ __forceinline__ float time_feat(float dt, float w, float b) { return cosf(fmaf(dt, w, b)); }
+#endif
 
 }  // namespace lstep
