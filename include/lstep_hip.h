@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 4
+#define LSTEP_ABI_VERSION 5
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -146,6 +146,18 @@ int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t 
  * z in floats (0 = width). */
 int lstep_residual_tanh_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* z, int32_t ld_z,
                              void* stream);
+
+/* Group int32 keys on the device (stable radix sort on the low key_bits bits + head flags + scan); the plumbing behind
+ * the batch-node set (train_LSTEP_link_prediction.py:221-222), the update_pe segments (models/LSTEP.py:282-290, 319-324:
+ * what torch_scatter + torch.unique do in the reference) and the gradient segments of the gather backward.
+ *   sorted_keys[n], order[n] (original index of every sorted entry; equal keys keep their input order),
+ *   seg[n] (rank of the entry's key among the distinct keys), uniq[<= n] (distinct keys ascending),
+ *   summary[3] (device) = { number of distinct keys, number of entries with key < limit, number of distinct keys < limit }
+ * Callers give entries they want dropped a key >= limit, so the wanted entries / segments are the leading ones.
+ * workspace: lstep_group_by_key_workspace(n, key_bits) bytes of device scratch (nothing is allocated inside). */
+int64_t lstep_group_by_key_workspace(int64_t n, int32_t key_bits);
+int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bits, int32_t limit, void* workspace, int64_t workspace_bytes,
+                       int32_t* sorted_keys, int32_t* order, int32_t* seg, int32_t* uniq, int32_t* summary, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
-SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip"]
+SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 4
+ABI_VERSION = 5
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -80,6 +80,8 @@ SIGNATURES = {
     "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
+    "lstep_group_by_key_workspace": (_I64, [_I64, _I32]),
+    "lstep_group_by_key": (C.c_int, [_P, _I64, _I32, _I32, _P, _I64, _P, _P, _P, _P, _P, _P]),
 }
 
 
@@ -129,3 +131,29 @@ def current_stream():
     import torch
 
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WORKSPACES = {}
+
+
+def group_by_key(keys, key_bits: int, limit: int):
+    """``lstep_group_by_key`` on an int32 device tensor.  Returns (sorted_keys, order, seg, uniq, (n_unique, n_below, n_unique_below));
+    the three counts cost one host sync.  The scratch buffer is cached per device and grown on demand."""
+    import torch
+
+    lib = load_library()
+    n = keys.numel()
+    dev = keys.device
+    need = int(lib.lstep_group_by_key_workspace(n, key_bits))
+    ws = _WORKSPACES.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _WORKSPACES[dev] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
+    sorted_keys = torch.empty(n, dtype=torch.int32, device=dev)
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    seg = torch.empty(n, dtype=torch.int32, device=dev)
+    uniq = torch.empty(n, dtype=torch.int32, device=dev)
+    summary = torch.empty(3, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.lstep_group_by_key(ptr(keys), n, int(key_bits), int(limit), ptr(ws), ws.numel(), ptr(sorted_keys), ptr(order), ptr(seg),
+                                     ptr(uniq), ptr(summary), current_stream()))
+    return sorted_keys, order, seg, uniq, summary.tolist()

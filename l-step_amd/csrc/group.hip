@@ -1,0 +1,81 @@
+// "Group by key" on the device: the plumbing every batch needs three times
+//   (1) cat[src, dst] of the batch -> sorted unique batch nodes + per-node message segments   (train:221-222, LSTEP.py:282-290)
+//   (2) sampled neighbour ids of update_pe phase 2 -> touched rows + their message segments   (LSTEP.py:319-324)
+//   (3) spliced-row hits of the gather backward -> gradient segments
+// One stable radix sort (hipCUB) + head flags + one scan instead of ~50 small framework launches per use.
+#include <hipcub/hipcub.hpp>
+
+#include "lstep_common.h"
+
+namespace lstep {
+
+__global__ void iota_kernel(int32_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (int32_t)i;
+}
+
+__global__ void head_flag_kernel(const int32_t* __restrict__ sk, int32_t* __restrict__ flag, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        flag[i] = (i > 0 && sk[i] != sk[i - 1]) ? 1 : 0;
+}
+
+// uniq[seg] = key of the segment's first entry; begin[seg] = its position; summary = {num_unique, first index with key >= limit}
+__global__ void unique_kernel(const int32_t* __restrict__ sk, const int32_t* __restrict__ seg, int64_t n, int32_t limit,
+                              int32_t* __restrict__ uniq, int32_t* __restrict__ summary) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool head = i == 0 || sk[i] != sk[i - 1];
+        if (head) uniq[seg[i]] = sk[i];
+        if (i == n - 1) summary[0] = seg[i] + 1;
+        // boundary between keys < limit and keys >= limit (sorted): exactly one thread sees it
+        const bool below = sk[i] < limit;
+        if (below && (i == n - 1 || sk[i + 1] >= limit)) { summary[1] = (int32_t)(i + 1); summary[2] = seg[i] + 1; }
+        if (i == 0 && !below) { summary[1] = 0; summary[2] = 0; }
+    }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t cub_temp_bytes(int64_t n, int bits) {
+    size_t a = 0, b = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                       (int)n, 0, bits, (hipStream_t)0);
+    hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, (hipStream_t)0);
+    return a > b ? a : b;
+}
+
+}  // namespace lstep
+
+using namespace lstep;
+
+extern "C" int64_t lstep_group_by_key_workspace(int64_t n, int32_t key_bits) {
+    if (n <= 0) return 256;
+    return (int64_t)(2 * align256((size_t)n * 4) + align256(cub_temp_bytes(n, key_bits)) + 256);
+}
+
+extern "C" int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bits, int32_t limit, void* workspace, int64_t workspace_bytes,
+                                  int32_t* sorted_keys, int32_t* order, int32_t* seg, int32_t* uniq, int32_t* summary, void* stream) {
+    if (n < 0 || key_bits <= 0 || key_bits > 31) return set_error(LSTEP_EINVAL, "lstep_group_by_key: bad sizes");
+    if (n >= ((int64_t)1 << 31)) return set_error(LSTEP_EINVAL, "lstep_group_by_key: more than 2^31 - 1 entries");
+    if (!summary) return set_error(LSTEP_EINVAL, "lstep_group_by_key: NULL summary");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (hipMemsetAsync(summary, 0, 3 * sizeof(int32_t), s) != hipSuccess) return set_error(LSTEP_EHIP, "lstep_group_by_key: memset failed");
+        return LSTEP_OK;
+    }
+    if (!keys || !workspace || !sorted_keys || !order || !seg || !uniq) return set_error(LSTEP_EINVAL, "lstep_group_by_key: NULL pointer");
+    if (workspace_bytes < lstep_group_by_key_workspace(n, key_bits)) return set_error(LSTEP_EINVAL, "lstep_group_by_key: workspace too small");
+    char* ws = (char*)workspace;
+    int32_t* idx = (int32_t*)ws;
+    int32_t* flag = (int32_t*)(ws + align256((size_t)n * 4));
+    void* temp = ws + 2 * align256((size_t)n * 4);
+    size_t temp_bytes = cub_temp_bytes(n, key_bits);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(256), 0, s, idx, n);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, sorted_keys, idx, order, (int)n, 0, key_bits, s) != hipSuccess)
+        return set_error(LSTEP_EHIP, "lstep_group_by_key: radix sort failed");
+    hipLaunchKernelGGL(head_flag_kernel, dim3(grid), dim3(256), 0, s, sorted_keys, flag, n);
+    temp_bytes = cub_temp_bytes(n, key_bits);
+    if (hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, flag, seg, (int)n, s) != hipSuccess)
+        return set_error(LSTEP_EHIP, "lstep_group_by_key: scan failed");
+    hipLaunchKernelGGL(unique_kernel, dim3(grid), dim3(256), 0, s, sorted_keys, seg, n, limit, uniq, summary);
+    return check_launch("lstep_group_by_key");
+}

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _native as nat
 from .model import LSTEP, MergeLayer, SplicedRows
 
 
@@ -142,13 +143,13 @@ class LstepEngine:
     def _probabilities(self, a, b):
         return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
 
-    @staticmethod
-    def batch_nodes_and_segments(src, dst):
-        """One stable sort of cat[src, dst] gives the sorted unique batch nodes (train:221-222) AND the per-node segments
-        of update_pe phase 1 (entries grouped by receiving endpoint)."""
-        keys_s, order = torch.sort(torch.cat([src, dst]), stable=True)
-        nodes, inverse, counts = torch.unique_consecutive(keys_s, return_inverse=True, return_counts=True)
-        return nodes, (order, inverse, counts)
+    def batch_nodes_and_segments(self, src, dst):
+        """One native group-by-key of cat[src, dst] (``lstep_group_by_key``) gives the sorted unique batch nodes
+        (train:221-222) AND the per-node segments of update_pe phase 1 (entries grouped by receiving endpoint)."""
+        rows = self.backbone.node_raw_features.shape[0]
+        keys = torch.cat([src, dst]).to(torch.int32)
+        _, order, seg, uniq, (n_unique, _, _) = nat.group_by_key(keys, max(1, int(rows).bit_length()), rows)
+        return uniq[:n_unique].long(), (order.long(), seg.long(), None)
 
     # ---- train:204-311
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):

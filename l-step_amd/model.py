@@ -137,39 +137,38 @@ class SplicedRows:
         self.slot_of = slot_of
 
 
-def _segment_reduce_rows(mod, num_rows: int, seg_of_entry: torch.Tensor, src_row: torch.Tensor, table: torch.Tensor):
-    """out[u] = sum of table[src_row[e], :P] over the entries with seg_of_entry[e] == u (entries in any order)."""
+def _segment_reduce_rows(mod, num_rows: int, seg_of_entry: torch.Tensor, src_row_of, table: torch.Tensor):
+    """out[u] = sum of table[src_row, :P] over the entries with seg_of_entry == u; entries with a negative segment are
+    dropped.  ``seg_of_entry`` int32 [n]; ``src_row_of(order)`` maps original entry indices to table rows."""
     lib = nat.load_library()
     dev, P = table.device, mod.pe_dim
     out = torch.zeros((num_rows, P), dtype=torch.float32, device=dev)
     if seg_of_entry.numel() == 0:
         return out
-    seg_s, order = torch.sort(seg_of_entry, stable=True)
+    keys = torch.where(seg_of_entry < 0, torch.full_like(seg_of_entry, num_rows), seg_of_entry)
+    sorted_keys, order, _, _, (_, n_hit, _) = nat.group_by_key(keys, max(1, int(num_rows + 1).bit_length()), num_rows)
+    if n_hit == 0:
+        return out
     # NOTE: every tensor whose address goes to the C ABI must stay referenced until the launch has been issued: a
     # temporary dies as soon as nat.ptr() returns and the caching allocator may hand its block to the next temporary.
-    ent_seg = seg_s.to(torch.int32)
-    ent_row = src_row[order].to(torch.int32)
+    ent_seg = sorted_keys[:n_hit]
+    ent_row = src_row_of(order[:n_hit])
     with torch.cuda.device(dev):
         nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, int(table.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
-                                             ent_seg.numel(), nat.ptr(out), P, nat.current_stream()))
+                                             n_hit, nat.ptr(out), P, nat.current_stream()))
     return out
 
 
 def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self):
     """Gradient of the spliced PE rows: every (row b, slot j) whose neighbour is spliced row u contributes g_pe[b, :P],
-    every row b whose own node is spliced row u contributes g_self[b].  Grouped by u with a sort and reduced by
-    lstep_segment_rows_sum: no atomics on hot (hub) rows, deterministic summation order."""
+    every row b whose own node is spliced row u contributes g_self[b].  Grouped by u (``lstep_group_by_key``) and reduced
+    by ``lstep_segment_rows_sum``: no atomics on hot (hub) rows, deterministic summation order."""
     K = hits.shape[1]
     total = torch.zeros((num_rows, mod.pe_dim), dtype=torch.float32, device=hits.device)
-    flat = hits.reshape(-1)
-    hit, hit_self = flat >= 0, self_slot >= 0
-    n_hit, n_self = torch.stack([hit.sum(), hit_self.sum()]).tolist()     # one host sync for both sizes
-    if g_pe is not None and n_hit:
-        idx = torch.nonzero_static(hit, size=n_hit).squeeze(1)
-        total = total + _segment_reduce_rows(mod, num_rows, flat[idx].long(), idx // K, g_pe)
-    if g_self is not None and n_self:
-        idx = torch.nonzero_static(hit_self, size=n_self).squeeze(1)
-        total = total + _segment_reduce_rows(mod, num_rows, self_slot[idx].long(), idx, g_self)
+    if g_pe is not None:
+        total = total + _segment_reduce_rows(mod, num_rows, hits.reshape(-1), lambda o: (o // K).contiguous(), g_pe)
+    if g_self is not None:
+        total = total + _segment_reduce_rows(mod, num_rows, self_slot.to(torch.int32), lambda o: o.contiguous(), g_self)
     return total
 
 
@@ -619,31 +618,32 @@ class LSTEP(nn.Module):
         U = bn.numel()
         nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, num_neighbors)
         key = nbr.reshape(-1)
-        rep = bn.unsqueeze(1).expand(U, num_neighbors).reshape(-1)
-        dt2 = (torch.tensor(now32, dtype=torch.float32, device=dev) - nt.reshape(-1))   # float32 - float32 (LSTEP.py:314)
+        rows = pe.shape[0]
         pe[0] = 0.0
         real = key != 0
         if shard is not None:
             real = real & ((key % shard[0]) == shard[1])
         own_row0 = shard is None or shard[1] == 0                # row 0 belongs to shard 0
-        # one host sync for both data-dependent sizes (boolean-mask indexing would sync once per use)
-        n_real, n_zero = torch.stack([real.sum(), (key == 0).sum()]).tolist()
-        idx = torch.nonzero_static(real, size=n_real).squeeze(1)
-        key_s, order = torch.sort(key[idx], stable=True)
-        touched, inverse = torch.unique_consecutive(key_s, return_inverse=True)
-        src_e = idx[order]
-        ent_row = rep[src_e].to(torch.int32)
-        ent_dt = dt2[src_e].contiguous()
+        # group the real entries by touched row: dropped entries get the sentinel key `rows` and sort to the end
+        keys32 = torch.where(real, key, torch.full_like(key, rows)).to(torch.int32)
+        _, order, seg, uniq, (_, n_real, nseg) = nat.group_by_key(keys32, max(1, int(rows + 1).bit_length()), rows)
+        n_zero = (key.numel() - n_real) if shard is None else (int((key == 0).sum()) if own_row0 else 0)
+        src_e = order[:n_real].long()
+        inverse = seg[:n_real]
+        touched = uniq[:nseg].long()
+        ent_row = bn[src_e // num_neighbors].to(torch.int32)
+        now_t = torch.tensor(now32, dtype=torch.float32, device=dev)
+        ent_dt = now_t - nt.reshape(-1)[src_e]                   # float32 - float32 (LSTEP.py:314)
         nseg = touched.numel()
         if own_row0 and n_zero > 0:
             # row 0 collects cat[pe[source], 0] from every padded slot: a weighted column sum instead of a hot segment.
             # It goes first (ids are sorted): segment 0 has no entries and its aggregate is filled in afterwards.
             zeros_per_row = (nbr == 0).sum(dim=1)                                       # slots that scatter into row 0
             touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
-            agg2 = self._segment_sum(pe, nseg + 1, (inverse + 1).to(torch.int32), ent_row, ent_dt)
+            agg2 = self._segment_sum(pe, nseg + 1, inverse + 1, ent_row, ent_dt)
             agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
         else:
-            agg2 = self._segment_sum(pe, nseg, inverse.to(torch.int32), ent_row, ent_dt)
+            agg2 = self._segment_sum(pe, nseg, inverse, ent_row, ent_dt)
         return touched, self._update_mlp(agg2)[:touched.numel()]
 
     @torch.no_grad()

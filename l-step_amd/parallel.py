@@ -233,7 +233,7 @@ class DistributedLstep:
         assert n_glob % self.W == 0, "global batch must divide by the world size"
         b = n_glob // self.W
         sl = slice(self.rank * b, (self.rank + 1) * b)
-        bn, presorted = LstepEngine.batch_nodes_and_segments(src, dst)
+        bn, presorted = self.eng.batch_nodes_and_segments(src, dst)
         out, loss = None, None
         owner_counts = None
         if batch_idx == 0:

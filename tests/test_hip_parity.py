@@ -331,10 +331,11 @@ def test_segment_rows_sum_vs_index_add(hip):
     torch.manual_seed(0)
     for (n_rows, n_ent, nsrc, ld) in ((30, 100, 48, 288), (30, 1000, 48, 176), (5, 5000, 300, 288), (1000, 200000, 49152, 288), (7, 0, 10, 172)):
         table = torch.randn(nsrc, ld, device=DEV)
-        seg = torch.randint(0, n_rows, (n_ent,), device=DEV)
+        seg = torch.randint(-2, n_rows, (n_ent,), device=DEV)          # negative segment = entry to drop
         src = torch.randint(0, nsrc, (n_ent,), device=DEV)
-        out = _segment_reduce_rows(M, n_rows, seg, src, table)
-        ref = torch.zeros(n_rows, 172, device=DEV, dtype=torch.float64).index_add_(0, seg, table[src][:, :172].double())
+        out = _segment_reduce_rows(M, n_rows, seg.to(torch.int32), lambda o: src.to(torch.int32)[o.long()].contiguous(), table)
+        keep = seg >= 0
+        ref = torch.zeros(n_rows, 172, device=DEV, dtype=torch.float64).index_add_(0, seg[keep], table[src[keep]][:, :172].double())
         scale = max(1.0, float(ref.abs().max()))
         assert float((out.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n_ent / max(n_rows, 1)) ** 0.5)
 
@@ -405,3 +406,21 @@ def test_many_slots_and_degenerate_batches(hip):
     (om[0].combining_pe_raw_feat(torch.from_numpy(pe_np), src, t, K, 150) * wgt).sum().backward()
     (hm[0].combining_pe_raw_feat(pe_h, src, t, K, 150) * wgt.to(DEV)).sum().backward()
     np.testing.assert_allclose(hm[0].edge_agg.weight.grad.cpu().numpy(), om[0].edge_agg.weight.grad.numpy(), rtol=0, atol=2e-4)
+
+
+def test_group_by_key_vs_torch(hip):
+    """lstep_group_by_key (hipCUB radix sort + head flags + scan) against torch.sort / unique_consecutive."""
+    from lstep_amd import _native as nat
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    for n, hi, limit in ((1, 5, 5), (1000, 17, 10), (655360, 1_000_001, 1_000_001), (70000, 300, 300), (5000, 50, 0)):
+        keys = torch.randint(0, hi + 1, (n,), generator=gen, device=DEV, dtype=torch.int32)
+        bits = max(1, int(hi).bit_length())
+        sk, order, seg, uniq, (nu, n_below, nu_below) = nat.group_by_key(keys, bits, limit)
+        ref_sk, ref_order = torch.sort(keys.long(), stable=True)
+        assert torch.equal(sk.long(), ref_sk) and torch.equal(order.long(), ref_order)          # stable: equal keys keep input order
+        ref_u, ref_inv = torch.unique_consecutive(ref_sk, return_inverse=True)
+        assert nu == ref_u.numel() and torch.equal(uniq[:nu].long(), ref_u) and torch.equal(seg.long(), ref_inv)
+        assert n_below == int((keys < limit).sum()) and nu_below == int((ref_u < limit).sum())
+    sk, order, seg, uniq, summary = nat.group_by_key(torch.empty(0, dtype=torch.int32, device=DEV), 4, 3)
+    assert summary == [0, 0, 0]

@@ -32,13 +32,13 @@ def declared_symbols():
 
 def test_abi_exports_every_declared_symbol(lib):
     names = declared_symbols()
-    assert len(names) >= 12
+    assert len(names) >= 14
     raw = ctypes.CDLL(nat.LIB_PATH)
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/lstep_hip.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes prototype"
     assert sorted(nat.SIGNATURES) == names
-    assert lib.lstep_abi_version() == 4
+    assert lib.lstep_abi_version() == 5
 
 
 def test_abi_argument_validation_without_gpu(lib):
