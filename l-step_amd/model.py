@@ -537,18 +537,27 @@ class LSTEP(nn.Module):
                                                  nat.current_stream()))
         return out
 
+    MLP_ROW_BLOCK = 65536   # hipBLASLt's fp32 rate for these skinny GEMMs swings 50-115 TFLOP/s with M; 65536-row blocks sit at ~100 (tools/gemm_m.py)
+
     def _update_mlp(self, agg):
         """pe_mlp_2(relu(pe_mlp_1(agg))) on row-padded operands -> [n, ld_self] (padding columns 0).
         ``agg`` may carry extra bucket rows (see ``_bucket_rows``); they are computed and ignored."""
         Cp, Pp = self.ld_pe, self.ld_self
-        h = torch.relu(F.linear(agg, _pad2(self.pe_mlp_1.weight, Pp, Cp), _pad1(self.pe_mlp_1.bias, Pp)))
-        return F.linear(h, _pad2(self.pe_mlp_2.weight, Pp, Pp), _pad1(self.pe_mlp_2.bias, Pp))
+        w1, b1 = _pad2(self.pe_mlp_1.weight, Pp, Cp), _pad1(self.pe_mlp_1.bias, Pp)
+        w2, b2 = _pad2(self.pe_mlp_2.weight, Pp, Pp), _pad1(self.pe_mlp_2.bias, Pp)
+        n, blk = agg.shape[0], self.MLP_ROW_BLOCK
+        if n <= blk:
+            return F.linear(torch.relu_(F.linear(agg, w1, b1)), w2, b2)
+        out = torch.empty((n, Pp), dtype=torch.float32, device=agg.device)
+        for i in range(0, n, blk):
+            torch.addmm(b2, torch.relu_(F.linear(agg[i:i + blk], w1, b1)), w2.t(), out=out[i:i + blk])
+        return out
 
-    @staticmethod
-    def _bucket_rows(n: int) -> int:
+    @classmethod
+    def _bucket_rows(cls, n: int) -> int:
         """Row count rounded up to a coarse bucket: the number of updated rows changes every batch, and every new GEMM
         M costs ~150 us of hipBLASLt heuristic lookup on the host; a few repeating M values avoid that."""
-        q = 1024 if n <= 65536 else 16384
+        q = 1024 if n <= cls.MLP_ROW_BLOCK else cls.MLP_ROW_BLOCK
         return max(q, (n + q - 1) // q * q)
 
     def write_rows(self, pe, ids, rows):
