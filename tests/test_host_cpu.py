@@ -130,3 +130,17 @@ def test_rng_defined_sampling_replays_the_reference(golden, strategy, tsf):
             np.testing.assert_array_equal(nt.view(np.uint32), z[f"{strategy}/call{call}/k{k}/nt"].view(np.uint32))
     s.reset_random_state()
     np.testing.assert_array_equal(s.get_historical_neighbors(z["ids"], z["ts"], 3)[0], z[f"{strategy}/reset/k3/nbr"])
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: with the shared library absent, loading (and therefore every op and both model classes) raises."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from lstep_amd import _native as nat\n"
+            "try:\n    nat.load_library()\nexcept nat.LstepNativeError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n"
+            "try:\n    from lstep_amd.sampler import NeighborSampler\n    NeighborSampler([1], [2], [1], [0.5], device='cpu')\n"
+            "except nat.LstepNativeError:\n    print('SAMPLER RAISED')\n") % ROOT
+    env = dict(os.environ, LSTEP_LIB=os.path.join(tmp_path, "does_not_exist.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout
+    assert "RAISED True" in out and "SAMPLER RAISED" in out, out
