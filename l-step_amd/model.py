@@ -387,8 +387,16 @@ class LSTEP(nn.Module):
         ids, times = self._ids(node_ids), self._times(node_interact_times)
         if ids.numel() != times.numel():
             raise ValueError("node_ids and node_interact_times must have the same length")
+        if branches & nat.BRANCH_PE:
+            # the kernels index pe[neighbour id]: a short table would be an out-of-bounds read on the GPU
+            if pe is None or pe.dim() != 2 or pe.shape[1] != self.pe_dim or pe.shape[0] < self.neighbor_sampler.num_rows:
+                raise ValueError(f"pe must be [>= {self.neighbor_sampler.num_rows}, {self.pe_dim}] (one row per node id, row 0 = padding)")
+            if not pe.is_cuda:
+                raise nat.LstepNativeError("pe must live on the GPU (no CPU fallback)")
         rows = spliced.rows if spliced is not None else None
         slot_of = spliced.slot_of if spliced is not None else None
+        if slot_of is not None and (slot_of.dtype != torch.int32 or slot_of.numel() < self.neighbor_sampler.num_rows):
+            raise ValueError("slot_of must be an int32 map with one entry per node id")
         sink = getattr(self, "gather_event_sink", None)
         if sink is None:
             return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of)
@@ -660,6 +668,8 @@ class LSTEP(nn.Module):
                   num_neighbors: int = 30, time_gap: int = 2000, presorted=None):
         if not (pe.is_cuda and pe.dtype == torch.float32 and pe.is_contiguous()):
             raise ValueError("update_pe needs a contiguous float32 GPU table (it is mutated in place)")
+        if pe.dim() != 2 or pe.shape[1] != self.pe_dim or pe.shape[0] < self.neighbor_sampler.num_rows:
+            raise ValueError(f"pe must be [>= {self.neighbor_sampler.num_rows}, {self.pe_dim}]")
         self._check_rows(node_ids)
         bn = self._ids(node_ids)
         src, dst = self._ids(batch_src_node_ids), self._ids(batch_dst_node_ids)
