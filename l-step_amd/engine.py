@@ -6,7 +6,8 @@ state in HBM and never builds the reference's per-batch dense temporaries:
 
 * the PE history is a slot-major ring ``[T+1, N+1, P]`` (one snapshot = one contiguous block; the spare slot receives the
   next snapshot, so the T-snapshot window the FFT filter and its backward read is never overwritten) instead of
-  ``torch.cat`` + ``.cpu()`` of the whole ``[N+1, t, P]`` tensor every batch (``train:205,301,306``);
+  ``torch.cat`` + ``.cpu()`` of the whole ``[N+1, t, P]`` tensor every batch (``train:205,301,306``); a second spare
+  slot lets the next batch's base copy (``train:229``) run on a copy stream underneath the backward pass;
 * the "current PE" (``clone(last snapshot)`` with the FFT-filtered batch rows spliced in, ``train:229-230``) is
   materialised directly in the spare ring slot, where ``update_pe`` then turns it into the next snapshot in place;
 * gradients w.r.t. the current PE exist only for the spliced rows: the gather backward scatters into ``[U, P]`` through an
@@ -17,6 +18,7 @@ Edge streams live on the device (``EdgeStream``); a batch is a slice, no host ro
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -45,44 +47,75 @@ class EdgeStream:
 
 
 class HistoryRing:
-    """Last-T PE snapshots, slot-major, plus one spare slot for the snapshot being built."""
+    """Last-T PE snapshots, slot-major, plus two spare slots: one for the snapshot being built and one so that the NEXT
+    snapshot's base copy can be prefetched (on a side stream, under the backward pass) without touching the window the
+    pending FFT-filter backward still reads."""
 
     def __init__(self, num_rows: int, pe_dim: int, num_fft_batches: int, device="cuda"):
         self.T = int(num_fft_batches)
+        self.S = self.T + 2
         self.rows, self.P = int(num_rows), int(pe_dim)
-        self.buf = torch.zeros((self.T + 1, self.rows, self.P), dtype=torch.float32, device=device)
+        self.buf = torch.zeros((self.S, self.rows, self.P), dtype=torch.float32, device=device)
         self.start = 0   # physical slot of the oldest snapshot in the window
         self.len = 0     # snapshots in the window (<= T)
+        self._copy_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self._prefetched = None  # (slot index, event) of a base copy issued ahead of time
 
     def geom(self):
         """(node_stride, time_stride, slots, rot, t_len, P) for ``lstep_history_filter_*`` (element strides)."""
-        return (self.P, self.rows * self.P, self.T + 1, self.start, self.len, self.P)
+        return (self.P, self.rows * self.P, self.S, self.start, self.len, self.P)
 
     def last(self) -> torch.Tensor:
         assert self.len > 0
-        return self.buf[(self.start + self.len - 1) % (self.T + 1)]
+        return self.buf[(self.start + self.len - 1) % self.S]
 
     def spare(self) -> torch.Tensor:
-        return self.buf[(self.start + self.len) % (self.T + 1)]
+        return self.buf[(self.start + self.len) % self.S]
 
     def commit(self):
         """The spare slot now holds the newest snapshot (``train:301`` append + ``train:224-225`` trim)."""
         if self.len < self.T:
             self.len += 1
         else:
-            self.start = (self.start + 1) % (self.T + 1)
+            self.start = (self.start + 1) % self.S
+
+    def prefetch_base(self):
+        """Start copying the newest snapshot into the next spare slot on the copy stream (call right after ``commit``)."""
+        if self._copy_stream is None or self.len == 0 or os.environ.get("LSTEP_NO_PREFETCH") == "1":
+            return
+        slot = (self.start + self.len) % self.S
+        main = torch.cuda.current_stream(self.buf.device)
+        self._copy_stream.wait_stream(main)
+        with torch.cuda.stream(self._copy_stream):
+            self.buf[slot].copy_(self.last(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        self._prefetched = (slot, ev)
+
+    def base_for_next(self) -> torch.Tensor:
+        """The spare slot holding a copy of the newest snapshot (``torch.clone(positional_encoding[:, -1, :])``, train:229):
+        the prefetched one if ``prefetch_base`` ran for this slot, otherwise copied now."""
+        slot = (self.start + self.len) % self.S
+        cur = self.buf[slot]
+        if self._prefetched is not None and self._prefetched[0] == slot:
+            torch.cuda.current_stream(self.buf.device).wait_event(self._prefetched[1])
+        else:
+            cur.copy_(self.last())
+        self._prefetched = None
+        return cur
 
     def load(self, history: torch.Tensor):
         """Adopt a reference-shaped history ``[N+1, t, P]`` (keeps the last T snapshots)."""
         t = history.shape[1]
         keep = min(t, self.T)
         self.start, self.len = 0, keep
+        self._prefetched = None
         if keep:
             self.buf[:keep].copy_(history[:, t - keep:, :].permute(1, 0, 2))
 
     def as_reference_tensor(self) -> torch.Tensor:
         """``[N+1, t, P]`` copy of the window, oldest first (tests / checkpoint parity with ``EarlyStopping.save_pe``)."""
-        idx = [(self.start + i) % (self.T + 1) for i in range(self.len)]
+        idx = [(self.start + i) % self.S for i in range(self.len)]
         return self.buf[idx].permute(1, 0, 2).contiguous()
 
 
@@ -134,8 +167,7 @@ class LstepEngine:
         """FFT-filter the batch rows over the ring window and build the current PE in the spare slot (train:224-230)."""
         ring = self.ring
         rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx)
-        cur = ring.spare()
-        cur.copy_(ring.last())
+        cur = ring.base_for_next()
         cur.index_copy_(0, batch_nodes, rows.detach())
         self.slot_of[batch_nodes] = torch.arange(batch_nodes.numel(), dtype=torch.int32, device=self.device)
         return cur, SplicedRows(rows, self.slot_of)
@@ -180,6 +212,7 @@ class LstepEngine:
         if batch_idx == 0 and initial_pe is not None:
             initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
         ring.commit()
+        ring.prefetch_base()      # next iteration's clone of this snapshot runs on the copy stream under the backward pass
         if loss is not None:
             optimizer.zero_grad()
             loss.backward()
