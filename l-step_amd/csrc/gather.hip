@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             float4 re[kRowsInFlight], rp[kRowsInFlight];
             if (kEdgeNode && fa) {
 #pragma unroll
-                for (int u = 0; u < kRowsInFlight; ++u) re[u] = ld4(p.edge_raw + ej[u] * F + lane * 4);
+                for (int u = 0; u < kRowsInFlight; ++u) re[u] = ld4_stream(p.edge_raw + ej[u] * F + lane * 4);
             }
             if (kPe && pa) {
 #pragma unroll
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
                 for (int u = 0; u < 4; ++u) {
                     const bool live = (j + u) < m;
                     const int64_t ej = bcast_i32(ed, live ? (j + u) : (m - 1));
-                    re[u] = (fa && live) ? ld4(p.edge_raw + ej * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    re[u] = (fa && live) ? ld4_stream(p.edge_raw + ej * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

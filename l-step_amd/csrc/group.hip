@@ -36,9 +36,9 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t cub_temp_bytes(int64_t n, int bits) {
     size_t a = 0, b = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
                                        (int)n, 0, bits, (hipStream_t)0);
-    hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, (hipStream_t)0);
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, (hipStream_t)0);
     return a > b ? a : b;
 }
 

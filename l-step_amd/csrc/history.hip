@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void history_filter_fwd_kernel(HistView h, 
 #pragma unroll
         for (int i = 0; i < kHistInFlight; ++i) {
             const bool live = s + i < t_len;
-            x[i] = live ? ld4(h.row(node, s + i) + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[i] = live ? ld4_stream(h.row(node, s + i) + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             c[i] = live ? ld4(coef + (int64_t)(s + i) * P + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void history_filter_bwd_kernel(HistView h, 
         float4 x[kBwdTimeGroup];
 #pragma unroll
         for (int i = 0; i < kBwdTimeGroup; ++i)
-            x[i] = (s0 + i < t_len) ? ld4(h.row(node, s0 + i) + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[i] = (s0 + i < t_len) ? ld4_stream(h.row(node, s0 + i) + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < kBwdTimeGroup; ++i) {
             acc[i].x = fmaf(g.x, x[i].x, acc[i].x);

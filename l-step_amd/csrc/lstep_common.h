@@ -58,6 +58,17 @@ __device__ __forceinline__ int64_t wave_count_before(const double* __restrict__ 
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// read-once streams (history rows, edge-feature rows): non-temporal load, so they do not evict the re-used tables
+// (CSR, node features, PE table) from L2 / Infinity Cache.  LSTEP_NO_NT builds (tuning A/B only) fall back to plain loads.
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+#ifdef LSTEP_NO_NT
+    return ld4(p);
+#else
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
     acc.x = fmaf(s, v.x, acc.x);
