@@ -81,6 +81,79 @@ def fast_linear(x, w, b=None):
     return _Linear.apply(x, w, b)
 
 
+class _TailWeights(torch.autograd.Function):
+    """Padded / pre-multiplied weights of the dense tail in ~15 launches forward and ~25 backward.
+
+    Built from the raw parameters every call (they change every optimiser step):
+        W1p  [Ce, Ce]  = edge_mlp_1.weight                      b1p  = (sum a) * edge_mlp_1.bias + edge_agg.bias
+        Wn1p [Pp, Cp]  = pe_neighbor_mlp_1.weight               bn1p = pe_neighbor_mlp_1.bias
+        Wq   [Pp, 2Pp] = [self_update_neighbor_pe.weight | pe_neighbor_mlp_2.weight]     bq = sum of their biases
+        Wall [Fn, Fn+Ce+Pp] = [Wo_a Wn_a | Wo_a Wn_b W2 | Wo_b]  const = Wo_a Wn_b b2 + Wo_a bn + bo
+    (Wo = out_node_emb.weight = [Wo_a | Wo_b], Wn = node_mlp.weight = [Wn_a | Wn_b], W2/b2 = edge_mlp_2), all zero-padded
+    to the 16-aligned widths.  The same thing written with F.pad / cat / matmul costs ~45 launches forward and ~60 in
+    autograd's backward; here the backward is the hand-derived chain rule of the products above."""
+
+    @staticmethod
+    def forward(ctx, dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2):
+        Fd, C, P, CP, Ce, Fn, Cp, Pp = dims   # F, D+F, P, P+D and their 16-aligned paddings
+        dev = W1.device
+        sizes = [Ce * Ce, Ce, Pp * Cp, Pp, Pp * 2 * Pp, Pp, Fn * (Fn + Ce + Pp), Fn]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        parts = torch.split(flat, sizes)
+        W1p, b1p, Wn1p, bn1p = parts[0].view(Ce, Ce), parts[1], parts[2].view(Pp, Cp), parts[3]
+        Wq, bq, Wall, constp = parts[4].view(Pp, 2 * Pp), parts[5], parts[6].view(Fn, Fn + Ce + Pp), parts[7]
+        a_sum = aw.sum()
+        W1p[:C, :C] = W1
+        torch.addcmul(ab.expand(C), a_sum.expand(C), b1, out=b1p[:C])
+        Wn1p[:P, :CP] = Wn1
+        bn1p[:P] = bn1
+        Wq[:P, :P] = Ws
+        Wq[:P, Pp:Pp + P] = Wn2
+        torch.add(bs, bn2, out=bq[:P])
+        wo_a, wo_b = Wo[:, :Fd], Wo[:, Fd:]
+        wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
+        M = wo_a @ wn_b                                           # [F, C]
+        Wall[:Fd, :Fd] = wo_a @ wn_a
+        Wall[:Fd, Fn:Fn + C] = M @ W2
+        Wall[:Fd, Fn + Ce:Fn + Ce + P] = wo_b
+        constp[:Fd] = torch.addmv(torch.addmv(bo, M, b2), wo_a, bn)
+        ctx.dims = dims
+        ctx.save_for_backward(b1, a_sum, W2, b2, Wn, bn, Wo, M)
+        ctx.K = aw.numel()
+        return W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp
+
+    @staticmethod
+    def backward(ctx, gW1p, gb1p, gWn1p, gbn1p, gWq, gbq, gWall, gconst):
+        Fd, C, P, CP, Ce, Fn, Cp, Pp = ctx.dims
+        b1, a_sum, W2, b2, Wn, bn, Wo, M = ctx.saved_tensors
+        dev = b1.device
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        gW1p = gW1p if gW1p is not None else z(Ce, Ce)
+        gb1p = gb1p if gb1p is not None else z(Ce)
+        gWn1p = gWn1p if gWn1p is not None else z(Pp, Cp)
+        gbn1p = gbn1p if gbn1p is not None else z(Pp)
+        gWq = gWq if gWq is not None else z(Pp, 2 * Pp)
+        gbq = gbq if gbq is not None else z(Pp)
+        gWall = gWall if gWall is not None else z(Fn, Fn + Ce + Pp)
+        gconst = gconst if gconst is not None else z(Fn)
+        db1e = gb1p[:C]
+        d_b1 = a_sum * db1e
+        d_aw = torch.dot(db1e, b1).expand(1, ctx.K)
+        d_ab = db1e.sum().reshape(1)
+        wo_a = Wo[:, :Fd]
+        wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
+        dA1, dA2, dWo_b, dc = gWall[:Fd, :Fd], gWall[:Fd, Fn:Fn + C], gWall[:Fd, Fn + Ce:Fn + Ce + P], gconst[:Fd]
+        dM = torch.addr(dA2 @ W2.t(), dc, b2)                     # from A2 = M W2 and const = M b2 + ...
+        d_W2 = M.t() @ dA2
+        d_b2 = M.t() @ dc
+        dWo_a = torch.addr(dA1 @ wn_a.t() + dM @ wn_b.t(), dc, bn)
+        d_Wn = torch.cat([wo_a.t() @ dA1, wo_a.t() @ dM], dim=1)
+        d_bn = wo_a.t() @ dc
+        d_Wo = torch.cat([dWo_a, dWo_b], dim=1)
+        return (None, gW1p[:C, :C], d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, dc, gWq[:P, :P], gbq[:P], gWn1p[:P, :CP],
+                gbn1p[:P], gWq[:P, Pp:Pp + P], gbq[:P])
+
+
 # ------------------------------------------------------------------------------------------------ small modules
 class TimeEncoder(nn.Module):
     """``cos(t * w + b)``; same parameters as reference ``models/modules.py:7-39``."""
@@ -450,21 +523,17 @@ class LSTEP(nn.Module):
         parameters; state_dict is unchanged.  Exact in real arithmetic, <= 1e-6 in fp32 (golden-checked).
         All operands are zero-padded to 16-aligned widths (inputs by the gather kernel, weights here): the padding
         columns stay exactly 0 through relu / tanh / residual, so results are unchanged."""
-        Fd = self.feat_dim
+        Fd, P, D = self.feat_dim, self.pe_dim, self.time_dim
         Ce, Fn, Cp, Pp = self.ld_edge, self.ld_node, self.ld_pe, self.ld_self   # padded widths (288, 176, 288, 176)
-        a = self.edge_agg.weight.reshape(-1)
-        b1 = a.sum() * self.edge_mlp_1.bias + self.edge_agg.bias
-        h1 = torch.relu(fast_linear(x_edge, _pad2(self.edge_mlp_1.weight, Ce, Ce), _pad1(b1, Ce)))                      # [B, Ce]
-        p1 = torch.relu(fast_linear(x_pe, _pad2(self.pe_neighbor_mlp_1.weight, Pp, Cp), _pad1(self.pe_neighbor_mlp_1.bias, Pp)))  # [B, Pp]
-        w_q = torch.cat([_pad2(self.self_update_neighbor_pe.weight, Pp, Pp), _pad2(self.pe_neighbor_mlp_2.weight, Pp, Pp)], dim=1)
-        q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), w_q,
-                                      _pad1(self.self_update_neighbor_pe.bias + self.pe_neighbor_mlp_2.bias, Pp)))     # [B, Pp]
-        wo_a, wo_b = self.out_node_emb.weight[:, :Fd], self.out_node_emb.weight[:, Fd:]
-        wn_a, wn_b = self.node_mlp.weight[:, :Fd], self.node_mlp.weight[:, Fd:]
-        wo_wnb = wo_a @ wn_b                                                   # [F, C]
-        w_all = torch.cat([_pad2(wo_a @ wn_a, Fn, Fn), _pad2(wo_wnb @ self.edge_mlp_2.weight, Fn, Ce), _pad2(wo_b, Fn, Pp)], dim=1)
-        const = wo_wnb @ self.edge_mlp_2.bias + wo_a @ self.node_mlp.bias + self.out_node_emb.bias
-        return fast_linear(torch.cat([x_node, h1, q], dim=-1), w_all, _pad1(const, Fn))[:, :Fd]
+        W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp = _TailWeights.apply(
+            (Fd, D + Fd, P, P + D, Ce, Fn, Cp, Pp), self.edge_mlp_1.weight, self.edge_mlp_1.bias, self.edge_agg.weight, self.edge_agg.bias,
+            self.edge_mlp_2.weight, self.edge_mlp_2.bias, self.node_mlp.weight, self.node_mlp.bias, self.out_node_emb.weight,
+            self.out_node_emb.bias, self.self_update_neighbor_pe.weight, self.self_update_neighbor_pe.bias,
+            self.pe_neighbor_mlp_1.weight, self.pe_neighbor_mlp_1.bias, self.pe_neighbor_mlp_2.weight, self.pe_neighbor_mlp_2.bias)
+        h1 = torch.relu(fast_linear(x_edge, W1p, b1p))                                         # [B, Ce]
+        p1 = torch.relu(fast_linear(x_pe, Wn1p, bn1p))                                         # [B, Pp]
+        q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), Wq, bq))                # [B, Pp]
+        return fast_linear(torch.cat([x_node, h1, q], dim=-1), Wall, constp)[:, :Fd]
 
     def compute_src_dst_node_temporal_embeddings(self, pe, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20,
                                                  time_gap: int = 2000, spliced: SplicedRows = None):

@@ -144,3 +144,32 @@ def test_missing_library_fails_loudly(tmp_path):
     env = dict(os.environ, LSTEP_LIB=os.path.join(tmp_path, "does_not_exist.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout
     assert "RAISED True" in out and "SAMPLER RAISED" in out, out
+
+
+def test_tail_weight_composition_matches_autograd():
+    """model._TailWeights (hand-derived backward of the padded / pre-multiplied dense-tail weights) against the same
+    composition written with F.pad / cat / matmul and differentiated by autograd."""
+    from lstep_amd.model import _TailWeights, _pad1, _pad2
+    torch.manual_seed(0)
+    Fd, D, P, K = 172, 100, 172, 7
+    C, CP, Ce, Fn, Cp, Pp = D + Fd, P + D, 288, 176, 288, 176
+    mk = lambda *s: (0.1 * torch.randn(*s)).requires_grad_(True)  # noqa: E731
+    W1, b1, aw, ab, W2, b2 = mk(C, C), mk(C), mk(1, K), mk(1), mk(C, C), mk(C)
+    Wn, bn, Wo, bo = mk(Fd, C + Fd), mk(Fd), mk(Fd, P + Fd), mk(Fd)
+    Ws, bs, Wn1, bn1, Wn2, bn2 = mk(P, P), mk(P), mk(P, CP), mk(P), mk(P, P), mk(P)
+    params = [W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2]
+    a = aw.reshape(-1)
+    wo_a, wo_b, wn_a, wn_b = Wo[:, :Fd], Wo[:, Fd:], Wn[:, :Fd], Wn[:, Fd:]
+    M = wo_a @ wn_b
+    ref = (_pad2(W1, Ce, Ce), _pad1(a.sum() * b1 + ab, Ce), _pad2(Wn1, Pp, Cp), _pad1(bn1, Pp),
+           torch.cat([_pad2(Ws, Pp, Pp), _pad2(Wn2, Pp, Pp)], 1), _pad1(bs + bn2, Pp),
+           torch.cat([_pad2(wo_a @ wn_a, Fn, Fn), _pad2(M @ W2, Fn, Ce), _pad2(wo_b, Fn, Pp)], 1), _pad1(M @ b2 + wo_a @ bn + bo, Fn))
+    got = _TailWeights.apply((Fd, C, P, CP, Ce, Fn, Cp, Pp), *params)
+    for x, y in zip(got, ref):
+        np.testing.assert_allclose(x.detach().numpy(), y.detach().numpy(), rtol=0, atol=1e-6)
+    ws = [torch.randn_like(o) for o in ref]
+    g_ref = torch.autograd.grad(sum((o * w).sum() for o, w in zip(ref, ws)), params)
+    g_got = torch.autograd.grad(sum((o * w).sum() for o, w in zip(got, ws)), params)
+    for i, (x, y) in enumerate(zip(g_got, g_ref)):
+        assert x.shape == y.shape, i
+        np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-4, atol=2e-5, err_msg=str(i))
