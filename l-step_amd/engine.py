@@ -175,6 +175,13 @@ class LstepEngine:
     def _probabilities(self, a, b):
         return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
 
+    def _labels(self, n: int) -> torch.Tensor:
+        """[1]*n + [0]*n (train:263), cached per batch size."""
+        lab = getattr(self, "_label_cache", None)
+        if lab is None or lab.numel() != 2 * n:
+            lab = self._label_cache = torch.cat([torch.ones(n, device=self.device), torch.zeros(n, device=self.device)])
+        return lab
+
     def batch_nodes_and_segments(self, src, dst):
         """One native group-by-key of cat[src, dst] (``lstep_group_by_key``) gives the sorted unique batch nodes
         (train:221-222) AND the per-node segments of update_pe phase 1 (entries grouped by receiving endpoint)."""
@@ -196,14 +203,14 @@ class LstepEngine:
             cur, spliced = self._splice(batch_nodes, batch_idx)
             n = src.numel()
             emb = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_dst]), torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced)
-            pos_src, pos_dst, neg_emb = emb[:n], emb[n:2 * n], emb[2 * n:]
-            p_pos = self._probabilities(pos_src, pos_dst)
-            p_neg = self._probabilities(pos_src, neg_emb)          # neg_src = pos_src (train:245)
-            predicts = torch.cat([p_pos, p_neg], dim=0)
-            labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
+            pos_src = emb[:n]
+            # both predictor calls of train:254-255 in one launch: rows [pos_src | pos_dst] and [pos_src | neg_dst] (neg_src = pos_src, train:245)
+            predicts = self._probabilities(torch.cat([pos_src, pos_src], dim=0), emb[n:])
+            labels = self._labels(n)
             lp_loss = F.binary_cross_entropy(predicts, labels)
-            e_src = _lookup_rows(cur, spliced, src)
-            pe_loss = F.mse_loss(e_src, _lookup_rows(cur, spliced, dst)) - self.neg_sample_weight * F.mse_loss(e_src, _lookup_rows(cur, spliced, neg_dst))
+            e_all = _lookup_rows(cur, spliced, torch.cat([src, dst, neg_dst]))      # one gather / one scatter for the three PE lookups
+            e_src = e_all[:n]
+            pe_loss = F.mse_loss(e_src, e_all[n:2 * n]) - self.neg_sample_weight * F.mse_loss(e_src, e_all[2 * n:])
             loss = (1.0 - self.pe_weight) * lp_loss + self.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
         bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
