@@ -272,11 +272,10 @@ class DistributedLstep:
             self._update_finish(pending)
             optimizer.step()
             self.slot_of[bn] = -1
-            # losses reported as global means
-            for k in ("lp_loss", "pe_loss", "loss"):
-                v = out[k].clone().reshape(1)
-                all_reduce_sum(v, self.group)
-                out[k] = (v / self.W).reshape(())
+            # losses reported as global means (one collective for the three scalars)
+            v = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
+            all_reduce_sum(v, self.group)
+            out["lp_loss"], out["pe_loss"], out["loss"] = (v / self.W).unbind(0)
         return out
 
     # ---- evaluate_model_utils.py:38-142 on a global batch (call under torch.no_grad())
