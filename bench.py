@@ -105,6 +105,8 @@ def main():
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if os.environ.get("LSTEP_SINGLE_DEVICE") == "1":   # rehearsal of the N > 1 plumbing on a one-GPU box (with LSTEP_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -117,7 +119,11 @@ def main():
         from lstep_amd.parallel import DistributedLstep  # owner-sharded engine (RCCL)
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("LSTEP_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0, sharded=use_dist, zipf=args.zipf)
     eng, model = wl.engine, wl.model
     model.train()
