@@ -135,7 +135,10 @@ def main():
         runner = DistributedLstep(eng, opt)
         prefill_distributed(runner, seed=0)
     B = wl.batch
-    start = wl.num_edges // 2
+    need = (args.warmup + args.steps) * B * world
+    if need > wl.num_edges:
+        raise SystemExit(f"{args.warmup + args.steps} batches of {B * world} edges do not fit the {wl.num_edges}-edge stream of workload {args.workload}")
+    start = min(wl.num_edges // 2, wl.num_edges - need)   # from the middle of the stream when it fits
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)
 

@@ -623,11 +623,12 @@ class LSTEP(nn.Module):
         w1, b1 = _pad2(self.pe_mlp_1.weight, Pp, Cp), _pad1(self.pe_mlp_1.bias, Pp)
         w2, b2 = _pad2(self.pe_mlp_2.weight, Pp, Pp), _pad1(self.pe_mlp_2.bias, Pp)
         n, blk = agg.shape[0], self.MLP_ROW_BLOCK
+        w1t, w2t = w1.t(), w2.t()
         if n <= blk:
-            return F.linear(torch.relu_(F.linear(agg, w1, b1)), w2, b2)
+            return torch.addmm(b2, torch._addmm_activation(b1, agg, w1t), w2t)         # relu runs in the GEMM epilogue
         out = torch.empty((n, Pp), dtype=torch.float32, device=agg.device)
         for i in range(0, n, blk):
-            torch.addmm(b2, torch.relu_(F.linear(agg[i:i + blk], w1, b1)), w2.t(), out=out[i:i + blk])
+            torch.addmm(b2, torch._addmm_activation(b1, agg[i:i + blk], w1t), w2t, out=out[i:i + blk])
         return out
 
     @classmethod
