@@ -53,15 +53,24 @@ class _Linear(torch.autograd.Function):
     CHUNKS = 32
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, b, relu):
         ctx.has_bias = b is not None
+        ctx.relu = bool(relu)
+        if ctx.relu:  # relu in the GEMM epilogue (hipBLASLt), one launch instead of two
+            y = torch._addmm_activation(b, x, w.t())
+            ctx.save_for_backward(x, w, y)
+            return y
+        ctx.save_for_backward(x, w)
         return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
+        if ctx.relu:
+            x, w, y = ctx.saved_tensors
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)
+        else:
+            x, w = ctx.saved_tensors
+            dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = dy @ w
@@ -74,11 +83,12 @@ class _Linear(torch.autograd.Function):
                 dw = dy.t() @ x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def fast_linear(x, w, b=None):
-    return _Linear.apply(x, w, b)
+def fast_linear(x, w, b=None, relu=False):
+    """``relu(x @ w.T + b)`` if ``relu`` else ``x @ w.T + b`` (``relu`` needs a bias)."""
+    return _Linear.apply(x, w, b, relu)
 
 
 class _TailWeights(torch.autograd.Function):
@@ -192,7 +202,7 @@ class MergeLayer(nn.Module):
         self.act = nn.ReLU()
 
     def forward(self, input_1: torch.Tensor, input_2: torch.Tensor):
-        return self.fc2(self.act(fast_linear(torch.cat([input_1, input_2], dim=1), self.fc1.weight, self.fc1.bias)))
+        return self.fc2(fast_linear(torch.cat([input_1, input_2], dim=1), self.fc1.weight, self.fc1.bias, relu=True))
 
 
 # ------------------------------------------------------------------------------------------------ autograd glue
@@ -530,8 +540,8 @@ class LSTEP(nn.Module):
             self.edge_mlp_2.weight, self.edge_mlp_2.bias, self.node_mlp.weight, self.node_mlp.bias, self.out_node_emb.weight,
             self.out_node_emb.bias, self.self_update_neighbor_pe.weight, self.self_update_neighbor_pe.bias,
             self.pe_neighbor_mlp_1.weight, self.pe_neighbor_mlp_1.bias, self.pe_neighbor_mlp_2.weight, self.pe_neighbor_mlp_2.bias)
-        h1 = torch.relu(fast_linear(x_edge, W1p, b1p))                                         # [B, Ce]
-        p1 = torch.relu(fast_linear(x_pe, Wn1p, bn1p))                                         # [B, Pp]
+        h1 = fast_linear(x_edge, W1p, b1p, relu=True)                                          # [B, Ce]
+        p1 = fast_linear(x_pe, Wn1p, bn1p, relu=True)                                          # [B, Pp]
         q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), Wq, bq))                # [B, Pp]
         return fast_linear(torch.cat([x_node, h1, q], dim=-1), Wall, constp)[:, :Fd]
 
