@@ -43,6 +43,12 @@ def _pad1(b: torch.Tensor, n: int) -> torch.Tensor:
     return F.pad(b, (0, n - b.shape[0]))
 
 
+def _addmm_relu(b, x, wt):
+    """relu(x @ wt + b) with the relu in the GEMM epilogue when this torch build exposes it."""
+    fused = getattr(torch, "_addmm_activation", None)
+    return fused(b, x, wt) if fused is not None else torch.relu_(torch.addmm(b, x, wt))
+
+
 class _Linear(torch.autograd.Function):
     """``x @ w.T + b`` whose weight gradient is a batched split-M GEMM.
 
@@ -57,7 +63,7 @@ class _Linear(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.relu = bool(relu)
         if ctx.relu:  # relu in the GEMM epilogue (hipBLASLt), one launch instead of two
-            y = torch._addmm_activation(b, x, w.t())
+            y = _addmm_relu(b, x, w.t())
             ctx.save_for_backward(x, w, y)
             return y
         ctx.save_for_backward(x, w)
@@ -635,10 +641,10 @@ class LSTEP(nn.Module):
         n, blk = agg.shape[0], self.MLP_ROW_BLOCK
         w1t, w2t = w1.t(), w2.t()
         if n <= blk:
-            return torch.addmm(b2, torch._addmm_activation(b1, agg, w1t), w2t)         # relu runs in the GEMM epilogue
+            return torch.addmm(b2, _addmm_relu(b1, agg, w1t), w2t)                     # relu runs in the GEMM epilogue
         out = torch.empty((n, Pp), dtype=torch.float32, device=agg.device)
         for i in range(0, n, blk):
-            torch.addmm(b2, torch._addmm_activation(b1, agg[i:i + blk], w1t), w2t, out=out[i:i + blk])
+            torch.addmm(b2, _addmm_relu(b1, agg[i:i + blk], w1t), w2t, out=out[i:i + blk])
         return out
 
     @classmethod
