@@ -424,3 +424,36 @@ def test_group_by_key_vs_torch(hip):
         assert n_below == int((keys < limit).sum()) and nu_below == int((ref_u < limit).sum())
     sk, order, seg, uniq, summary = nat.group_by_key(torch.empty(0, dtype=torch.int32, device=DEV), 4, 3)
     assert summary == [0, 0, 0]
+
+
+def test_engine_iteration_on_hub_graph_vs_oracle(hip):
+    """Power-law graph, batch of 256: hub nodes appear in hundreds of neighbourhoods, so the update_pe segments and the
+    spliced-gradient segments are far longer than one 64-entry chunk (atomic path of lstep_segment_rows_sum) and the
+    gather backward's hit lists are dominated by a few rows.  Two training iterations, engine vs oracle protocol."""
+    from oracle.lstep_oracle import build_oracle_model
+    N, E, K, T, B, G = 300, 40000, 16, 6, 256, 2000
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=131, zipf=1.3)
+    node_raw, edge_raw = synth.make_features(N, E, seed=132)
+    pe0 = synth.make_initial_pe(N, seed=133)
+    sd = synth.make_state_dict(K, T, seed=134)
+    om = build_oracle_model(node_raw, edge_raw, oracle_sampler(g), K, T, sd)
+    hm = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, sd, DEV)
+    oo, ho = torch.optim.Adam(om.parameters(), lr=1e-4), torch.optim.Adam(hm.parameters(), lr=1e-4)
+    st = protocol.ProtocolState(history=torch.zeros(N + 1, 0, 172), initial_pe=torch.from_numpy(pe0.copy()))
+    eng = hip.LstepEngine(hm[0], hm[1], K, G)
+    stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+    init = torch.from_numpy(pe0.copy()).to(DEV)
+    for b in range(3):
+        lo = 30000 + b * B
+        sl = slice(lo, lo + B)
+        neg = synth.make_negatives(N, B, seed=140 + b)
+        ro = protocol.train_iteration(om[0], om[1], oo, st, b, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], neg, K, G, T)
+        rh = eng.train_iteration(ho, b, *stream.batch(lo, lo + B), torch.from_numpy(neg).to(DEV), initial_pe=init)
+        np.testing.assert_allclose(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), rtol=0, atol=1e-4)
+        if ro is not None:
+            np.testing.assert_allclose(rh["predicts"].cpu().numpy(), ro["predicts"], **TOL)
+            np.testing.assert_allclose(float(rh["loss"]), ro["loss"], rtol=0, atol=2e-5)
+            for (k, po), (_, ph) in zip(om.named_parameters(), hm.named_parameters()):
+                if po.grad is None:
+                    continue
+                np.testing.assert_allclose(ph.grad.cpu().numpy(), po.grad.numpy(), rtol=0, atol=3e-5, err_msg=f"b{b} {k}")
