@@ -145,9 +145,12 @@ def group_by_key(keys, key_bits: int, limit: int):
     n = keys.numel()
     dev = keys.device
     need = int(lib.lstep_group_by_key_workspace(n, key_bits))
-    ws = _WORKSPACES.get(dev)
+    # one scratch buffer per (device, stream): the engine runs update_pe on a side stream (its own host thread) while the
+    # backward pass groups gradient hits on the main stream
+    wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WORKSPACES.get(wkey)
     if ws is None or ws.numel() < need:
-        ws = _WORKSPACES[dev] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
+        ws = _WORKSPACES[wkey] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
     sorted_keys = torch.empty(n, dtype=torch.int32, device=dev)
     order = torch.empty(n, dtype=torch.int32, device=dev)
     seg = torch.empty(n, dtype=torch.int32, device=dev)

@@ -19,6 +19,7 @@ Edge streams live on the device (``EdgeStream``); a batch is a slice, no host ro
 from __future__ import annotations
 
 import os
+import threading
 from dataclasses import dataclass
 
 import numpy as np
@@ -160,6 +161,9 @@ class LstepEngine:
         rows = backbone.node_raw_features.shape[0]
         # make_ring=False: lstep_amd.parallel.DistributedLstep owns an owner-sharded ring instead
         self.ring = HistoryRing(rows, backbone.pe_dim, backbone.num_fft_batches, dev) if make_ring else None
+        # update_pe on a side stream underneath the backward pass (LSTEP_NO_OVERLAP=1 runs the reference order serially)
+        self.overlap_update = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_OVERLAP") != "1"
+        self._update_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
         self.slot_of = torch.full((rows,), -1, dtype=torch.int32, device=dev)
 
     # ---- shared pieces
@@ -213,18 +217,49 @@ class LstepEngine:
             pe_loss = F.mse_loss(e_src, e_all[n:2 * n]) - self.neg_sample_weight * F.mse_loss(e_src, e_all[2 * n:])
             loss = (1.0 - self.pe_weight) * lp_loss + self.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
-        bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                     node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G,
-                     presorted=presorted)
-        if batch_idx == 0 and initial_pe is not None:
-            initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
-        ring.commit()
-        ring.prefetch_base()      # next iteration's clone of this snapshot runs on the copy stream under the backward pass
-        if loss is not None:
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
-            self.slot_of[batch_nodes] = -1
+        def update_and_append():
+            bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
+                         node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G,
+                         presorted=presorted)
+            if batch_idx == 0 and initial_pe is not None:
+                initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
+            ring.commit()
+            ring.prefetch_base()  # next iteration's clone of this snapshot runs on the copy stream
+
+        if loss is None or not self.overlap_update:
+            update_and_append()
+            if loss is not None:
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                self.slot_of[batch_nodes] = -1
+            return out
+
+        # update_pe (forward-only, reads and writes only the current PE table) and the backward pass (never reads that table)
+        # are independent: update_pe runs on a side stream, driven by its own host thread because it needs a few host syncs
+        # for data-dependent sizes, while this thread runs the backward pass on the main stream.
+        main = torch.cuda.current_stream(self.device)
+        side = self._update_stream
+        side.wait_stream(main)
+        err = []
+
+        def worker():
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(side):
+                    update_and_append()
+            except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
+                err.append(e)
+
+        th = threading.Thread(target=worker, name="lstep-update-pe")
+        th.start()
+        optimizer.zero_grad()
+        loss.backward()
+        th.join()
+        if err:
+            raise err[0]
+        main.wait_stream(side)
+        optimizer.step()      # after update_pe has read its weights
+        self.slot_of[batch_nodes] = -1
         return out
 
     # ---- evaluate_model_utils.py:38-142 (call under torch.no_grad())
