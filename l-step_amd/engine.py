@@ -4,7 +4,7 @@ It executes the same per-batch contract as the reference loops (``train_LSTEP_li
 ``evaluate_model_utils.py:38-142``; restated for reference-shaped tensors in ``lstep_amd/protocol.py``) but keeps all
 state in HBM and never builds the reference's per-batch dense temporaries:
 
-* the PE history is a slot-major ring ``[T+1, N+1, P]`` (one snapshot = one contiguous block; the spare slot receives the
+* the PE history is a slot-major ring ``[T+2, N+1, P]`` (one snapshot = one contiguous block; a spare slot receives the
   next snapshot, so the T-snapshot window the FFT filter and its backward read is never overwritten) instead of
   ``torch.cat`` + ``.cpu()`` of the whole ``[N+1, t, P]`` tensor every batch (``train:205,301,306``); a second spare
   slot lets the next batch's base copy (``train:229``) run on a copy stream underneath the backward pass;

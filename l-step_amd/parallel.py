@@ -5,7 +5,7 @@ path is independent per destination row, across batches it is strictly sequentia
 cooperate on ONE global batch of ``W * B`` edges at a time (weak scaling: B per GPU fixed):
 
   state       node n is OWNED by rank ``n % W``.  The PE history ring -- the only O(N * T) state (69 GB at 1 M nodes,
-              275 GB at 4 M) -- is sharded by owner: rank r keeps ``[T+1, ceil((N+1-r)/W), P]``.  The current PE table
+              275 GB at 4 M) -- is sharded by owner: rank r keeps ``[T+2, ceil((N+1-r)/W), P]``.  The current PE table
               ``[N+1, P]`` (688 MB per 1 M nodes), CSR, feature tables and weights are replicated.
   FFT splice  rank r filters the history of the batch nodes it owns; the ``[U, P]`` filtered rows are ALL-GATHERED
               (padded, <= 22 MB per 32 K nodes) and written into every replica of the current table.
