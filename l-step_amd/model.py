@@ -21,6 +21,7 @@ filter is applied as its equivalent real ``[T, P]`` coefficient table (everythin
 from __future__ import annotations
 
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -425,7 +426,9 @@ class LSTEP(nn.Module):
         self.time_encoder = TimeEncoder(time_feat_dim, parameter_requires_grad=False)
 
         c = edge_feat_dim + time_feat_dim
-        self.fft_filter = nn.Linear(pe_dim, num_fft_batches, bias=False).to(torch.complex64)
+        with warnings.catch_warnings():  # "Complex modules are a new feature": the reference builds the same complex Linear
+            warnings.simplefilter("ignore", UserWarning)
+            self.fft_filter = nn.Linear(pe_dim, num_fft_batches, bias=False).to(torch.complex64)
         self.fft_dropout = nn.Dropout(p=dropout)
         self.fft_agg = nn.Linear(num_fft_batches, 1, bias=False)
         self.edge_mlp_1 = nn.Linear(c, c)

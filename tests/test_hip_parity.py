@@ -457,3 +457,26 @@ def test_engine_iteration_on_hub_graph_vs_oracle(hip):
                 if po.grad is None:
                     continue
                 np.testing.assert_allclose(ph.grad.cpu().numpy(), po.grad.numpy(), rtol=0, atol=3e-5, err_msg=f"b{b} {k}")
+
+
+@pytest.mark.parametrize("K,G", [(1, 1), (2, 3), (64, 64)])
+def test_extreme_neighbour_counts_vs_oracle(hip, K, G):
+    """num_neighbors = 1 (edge_agg over a single slot), time_gap = 1, and exactly one full 64-slot chunk."""
+    from oracle.lstep_oracle import build_oracle_model
+    N, E, T = 50, 3000, 3
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=151, tie_quantum=2.0)
+    node_raw, edge_raw = synth.make_features(N, E, seed=152)
+    pe_np = synth.make_initial_pe(N, seed=153)
+    sd = synth.make_state_dict(K, T, seed=154)
+    om = build_oracle_model(node_raw, edge_raw, oracle_sampler(g), K, T, sd)
+    hm = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, sd, DEV)
+    sl = slice(2000, 2024)
+    src, dst, t, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+    with torch.no_grad():
+        ref = om[0].combining_pe_raw_feat(torch.from_numpy(pe_np), src, t, K, G).numpy()
+        got = hm[0].combining_pe_raw_feat(torch.from_numpy(pe_np).to(DEV), src, t, K, G).cpu().numpy()
+        np.testing.assert_allclose(got, ref, **TOL)
+        bn = protocol.unique_batch_nodes(src, dst)
+        ref = om[0].update_pe(torch.from_numpy(pe_np.copy()), bn, eid, src, dst, t, t.max(), num_neighbors=K).numpy()
+        got = hm[0].update_pe(torch.from_numpy(pe_np.copy()).to(DEV), bn, eid, src, dst, t, t.max(), num_neighbors=K).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4)
