@@ -131,3 +131,22 @@ def _gpu_worker(rank, world, port, q):
 def test_distributed_engine_reproduces_golden_trace_2_ranks_one_gpu():
     assert torch.cuda.is_available()
     _run(_gpu_worker, 2)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_plumbing_gloo_two_ranks_one_gpu():
+    """`bench.py --gpus 2` under torch.distributed.run (the driver's launch line), rehearsed on one GPU with gloo: the JSON
+    line must come out with n_gpus = 2 and a global batch of 2 x B."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = dict(os.environ, LSTEP_SINGLE_DEVICE="1", LSTEP_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "tiny", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["value"] > 0
+    assert line["roofline"]["rows_per_launch"] == 3 * 256
