@@ -21,6 +21,7 @@ filter is applied as its equivalent real ``[T, P]`` coefficient table (everythin
 from __future__ import annotations
 
 import math
+import os
 import warnings
 
 import numpy as np
@@ -57,7 +58,7 @@ class _Linear(torch.autograd.Function):
     that shape reach 30-60 TFLOP/s on MI355X, the same product as 32 row-chunk ``bmm`` + one ``sum`` reaches 65-105
     (tools/gemm_dw.py).  Forward and dX are the plain library GEMMs."""
 
-    CHUNKS = 32
+    CHUNKS = int(os.environ.get("LSTEP_DW_CHUNKS", "16"))   # tuning knob: 16-32 row chunks are best (tools/gemm_dw.py; 16 in the full step)
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
