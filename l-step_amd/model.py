@@ -350,6 +350,40 @@ class _GatherAggregate(torch.autograd.Function):
         return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None)
 
 
+class _FftCoefficients(torch.autograd.Function):
+    """Real [T, P] coefficient table of the FFT filter (see ``LSTEP.fft_coefficients``) with a hand-derived backward.
+
+        A[f]    = sum_t E+[f, t] a[t] m[t]          E+[f, t] = e^{+2 pi i f t / T}
+        c[f]    = m[f] A[f] / T
+        coef    = Re(E- Q),  Q[f, p] = c[f] W[f, p]  E-[s, f] = e^{-2 pi i f s / T}
+
+    For a real loss with G = d(loss)/d(coef):  gQ = E+ G,  gW = conj(c) gQ,  gc[f] = sum_p conj(W[f, p]) gQ[f, p],
+    gA = (m / T) gc,  g(a m) = Re(E- gA)  (a is real),  ga = m * g(a m).  (PyTorch's convention: the gradient of a complex
+    tensor z = x + iy is dL/dx + i dL/dy.)  ~10 launches instead of ~25 through complex autograd."""
+
+    @staticmethod
+    def forward(ctx, w, a_w, m, e_pos, e_neg_t, T):
+        am = (a_w.reshape(-1).to(torch.float64) * m).to(torch.complex128)
+        big_a = e_pos @ am
+        c = big_a * (m / T)                                       # [f] complex128
+        w128 = w.to(torch.complex128)
+        coef = (e_neg_t @ (w128 * c.unsqueeze(1))).real.to(torch.float32)
+        ctx.save_for_backward(w128, c, m, e_pos, e_neg_t)
+        ctx.T = T
+        ctx.a_shape = tuple(a_w.shape)
+        return coef
+
+    @staticmethod
+    def backward(ctx, g):
+        w128, c, m, e_pos, e_neg_t = ctx.saved_tensors
+        gq = e_pos @ g.to(torch.complex128)                       # E-^H = E+
+        g_w = (gq * c.conj().unsqueeze(1)).to(torch.complex64)
+        g_c = (w128.conj() * gq).sum(dim=1)
+        g_am = (e_neg_t @ (g_c * (m / ctx.T))).real               # E+^H = E-
+        g_a = (g_am * m).to(torch.float32).reshape(ctx.a_shape)
+        return g_w, g_a, None, None, None, None
+
+
 class _HistoryFilter(torch.autograd.Function):
     """out[u] = sum_s coef[s] * hist[ids[u], s]  (lstep_history_filter_fwd / _bwd); gradient only w.r.t. ``coef``."""
 
@@ -576,7 +610,7 @@ class LSTEP(nn.Module):
         fft_agg over time; mask = 1 on indices < batch_idx and only when fewer than T snapshots are stored
         (models/LSTEP.py:108-113).  Everything is linear in x, so with m the mask, W the filter and a the fft_agg row,
             c[s, p] = Re( 1/T * sum_f m[f] W[f, p] e^{-2 pi i f s / T} * sum_t a[t] m[t] e^{+2 pi i f t / T} ).
-        Built in complex128 from the live parameters, so autograd carries d(loss)/d(c) back to fft_filter and fft_agg.
+        Built in complex128 from the live parameters by ``_FftCoefficients`` (hand-derived backward to fft_filter / fft_agg).
         """
         T = self.num_fft_batches
         dev = self.fft_agg.weight.device
@@ -585,17 +619,10 @@ class LSTEP(nn.Module):
             k = torch.arange(T, device=dev, dtype=torch.float64)
             ang = (2.0 * math.pi / T) * torch.outer(k, k)
             e_pos = torch.polar(torch.ones_like(ang), ang)      # e^{+i 2 pi f t / T}, [f, t]
-            self._dft_cache = cache = ((T, dev), k, e_pos, e_pos.conj().t().contiguous())
-        _, k, e_pos, e_neg_t = cache
-        if t_len < T:
-            m = (k < batch_idx).to(torch.float64)
-        else:
-            m = torch.ones(T, device=dev, dtype=torch.float64)
-        a = self.fft_agg.weight.reshape(-1).to(torch.float64) * m
-        big_a = e_pos @ a.to(torch.complex128)                    # [f]
-        q = (m.unsqueeze(1) * self.fft_filter.weight.to(torch.complex128)) * big_a.unsqueeze(1) / T   # [f, P]
-        coef = (e_neg_t @ q).real                                 # [s, P]: sum_f e^{-i 2 pi f s / T} q[f, p]
-        return coef.to(torch.float32)
+            self._dft_cache = cache = ((T, dev), k, e_pos, e_pos.conj().t().contiguous(), torch.ones(T, device=dev, dtype=torch.float64))
+        _, k, e_pos, e_neg_t, ones = cache
+        m = (k < batch_idx).to(torch.float64) if t_len < T else ones
+        return _FftCoefficients.apply(self.fft_filter.weight, self.fft_agg.weight, m, e_pos, e_neg_t, T)
 
     def fourier_transform_pe(self, node_ids, pe, batch_idx, use_dropout=False, use_mixer=False):
         """``pe`` is the PE history ``[N+1, t, P]`` (any strides with unit last stride); returns ``[U, P]``."""
