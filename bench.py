@@ -127,7 +127,9 @@ def main():
     wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0, sharded=use_dist, zipf=args.zipf)
     eng, model = wl.engine, wl.model
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    # Adam, lr 1e-4 (reference defaults, utils/load_configs.py:45,48) through the single-kernel implementation
+    from lstep_amd.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=1e-4)
     if not use_dist:
         runner = eng
     else:

@@ -480,3 +480,27 @@ def test_extreme_neighbour_counts_vs_oracle(hip, K, G):
         ref = om[0].update_pe(torch.from_numpy(pe_np.copy()), bn, eid, src, dst, t, t.max(), num_neighbors=K).numpy()
         got = hm[0].update_pe(torch.from_numpy(pe_np.copy()).to(DEV), bn, eid, src, dst, t, t.max(), num_neighbors=K).cpu().numpy()
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4)
+
+
+def test_fused_adam_matches_torch_adam(hip):
+    """lstep_amd.optim.FusedAdam (one fused kernel, complex parameter through its real view) vs torch.optim.Adam."""
+    from lstep_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    mk = lambda: [torch.nn.Parameter(torch.randn(7, 5, dtype=torch.complex64, device=DEV)), torch.nn.Parameter(torch.randn(9, 4, device=DEV)),  # noqa: E731
+                  torch.nn.Parameter(torch.randn(4, device=DEV))]
+    a = mk()
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa, ob = torch.optim.Adam(a, lr=1e-2), FusedAdam(b, lr=1e-2)
+    for step in range(5):
+        grads = [torch.randn_like(p) for p in a]
+        oa.zero_grad(); ob.zero_grad()
+        for p, q, g in zip(a, b, grads):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        if step == 2:
+            a[2].grad = None
+            b[2].grad = None        # a parameter without gradient is skipped by both
+        oa.step(); ob.step()
+    for p, q in zip(a, b):
+        np.testing.assert_allclose(torch.view_as_real(q.detach()).cpu().numpy() if q.is_complex() else q.detach().cpu().numpy(),
+                                   torch.view_as_real(p.detach()).cpu().numpy() if p.is_complex() else p.detach().cpu().numpy(), rtol=0, atol=1e-6)
