@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 5
+#define LSTEP_ABI_VERSION 7
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -76,8 +76,9 @@ int lstep_time_encode(const float* dt, const uint8_t* zero_mask, int64_t n, cons
  *   out_count [B]       c = interactions strictly earlier than times[b] (saved for the backward)
  * edge_agg_w float32 [K]; pe may be NULL when LSTEP_BRANCH_PE is not requested.
  * ld_* are the row strides (in floats) of the four outputs: 0 = dense (the widths above); a larger multiple of 4 pads each
- * row (the padding columns are written as 0) so the following GEMMs see 16-aligned K (288 / 176 instead of 272 / 172,
- * which hipBLASLt runs up to 2.5x faster). */
+ * row: the columns from the width up to the next multiple of 16 are written as 0 (the dense layers then see 16-aligned K: 176
+ * instead of 172), anything beyond belongs to the caller -- lstep_tail_fwd's concatenated operands take out_node / out_self
+ * as their first column block this way (ld_node = 624, ld_self = 352). */
 int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
                                int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
                                int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids, const double* times,
@@ -158,6 +159,40 @@ int lstep_residual_tanh_rows(float* table, int32_t width, const int64_t* ids, in
 int64_t lstep_group_by_key_workspace(int64_t n, int32_t key_bits);
 int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bits, int32_t limit, void* workspace, int64_t workspace_bytes,
                        int32_t* sorted_keys, int32_t* order, int32_t* seg, int32_t* uniq, int32_t* summary, void* stream);
+
+/* O -- weight / bias gradient of one dense layer of the tail (torch.nn.Linear y = x W^T + b as used by models/LSTEP.py:56-72,
+ * models/modules.py:52-68), on the fp32 matrix cores:
+ *   dw[n, k] = sum_r dy[r, n] * x[r, k]   (row stride ld_dw)        db[n] = sum_r dy[r, n]   (db may be NULL)
+ * dy [m, n] row stride ldy, x [m, k] row stride ldx, fp32.  Exact fp32 products and sums (v_mfma_f32_16x16x4_f32), summed per
+ * row slice and then over the slices in a fixed order: deterministic.  workspace: lstep_linear_wgrad_workspace(m, n, k) bytes of
+ * 16-byte aligned device scratch. */
+int64_t lstep_linear_wgrad_workspace(int64_t m, int32_t n, int32_t k);
+int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t m, int32_t n, int32_t k, float* dw,
+                       int32_t ld_dw, float* db, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* A / N / C / O -- every dense layer after the gather stage in one launch (fp32 matrix cores), for the model's default widths
+ * (feature / PE dim 172, time dim 100: 16-aligned channels 272 / 176 / 176).  Inputs: x_edge [m, ld_edge], x_pe [m, ld_pe] (gather
+ * outputs), cat1 [m, 624] = [x_node | . | .] and cat2 [m, 352] = [own | .] with the first 176 columns filled by the gather stage
+ * (lstep_gather_aggregate_fwd writes them there through its ld_node / ld_self arguments).  The 16-padded, composed weights
+ *   w1 [272, 272], b1 [272]   edge_mlp_1 with edge_agg folded in                (models/LSTEP.py:161-166)
+ *   wn1 [176, 272], bn1 [176] pe_neighbor_mlp_1                                 (:240-242)
+ *   wq [176, 352], bq [176]   [self_update_neighbor_pe | pe_neighbor_mlp_2]     (:243-245)
+ *   wall [176, 624], ball     out_node_emb . node_mlp . edge_mlp_2 pre-multiplied (:170,219,264)
+ * are built by the host layer (DESIGN.md "dense tails").  Outputs: h1 = relu(w1 x_edge + b1) -> cat1[:, 176:448],
+ * p1 = relu(wn1 x_pe + bn1) -> cat2[:, 176:352], q = own + tanh(wq [own; p1] + bq) -> cat1[:, 448:624],
+ * out [m, 176] = wall [x_node; h1; q] + ball (columns >= 172 are padding and come out 0). */
+int lstep_tail_fwd(const float* x_edge, int32_t ld_edge, const float* x_pe, int32_t ld_pe, float* cat1, float* cat2, float* out,
+                   const float* w1, const float* b1, const float* wn1, const float* bn1, const float* wq, const float* bq,
+                   const float* wall, const float* ball, int64_t m, void* stream);
+
+/* Backward of lstep_tail_fwd with respect to its activations.  grad_out [m, 176]; cat1 / cat2 as lstep_tail_fwd left them; the
+ * weights TRANSPOSED ([in, out] row-major): w1t [272, 272], wn1t [272, 176], wqt [352, 176], wallt [624, 176].  Writes
+ *   d_xedge [m, 272], d_xpe [m, 272], d_own [m, ld_down] (first 176 columns)         -- inputs of lstep_gather_aggregate_bwd
+ *   d_h1 [m, 272], d_p1 [m, 176], d_z [m, 176]  (pre-activation gradients)           -- dy operands of lstep_linear_wgrad:
+ *   dW1 = d_h1^T x_edge, dWn1 = d_p1^T x_pe, dWq = d_z^T cat2, dWall = grad_out^T cat1. */
+int lstep_tail_bwd(const float* grad_out, const float* cat1, const float* cat2, const float* w1t, const float* wn1t, const float* wqt,
+                   const float* wallt, float* d_xedge, float* d_xpe, float* d_own, int32_t ld_down, float* d_h1, float* d_p1, float* d_z,
+                   int64_t m, void* stream);
 
 #ifdef __cplusplus
 }

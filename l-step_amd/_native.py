@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
-SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip"]
+SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 5
+ABI_VERSION = 7
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -82,6 +82,10 @@ SIGNATURES = {
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
     "lstep_group_by_key_workspace": (_I64, [_I64, _I32]),
     "lstep_group_by_key": (C.c_int, [_P, _I64, _I32, _I32, _P, _I64, _P, _P, _P, _P, _P, _P]),
+    "lstep_linear_wgrad_workspace": (_I64, [_I64, _I32, _I32]),
+    "lstep_linear_wgrad": (C.c_int, [_P, _I32, _P, _I32, _I64, _I32, _I32, _P, _I32, _P, _P, _I64, _P]),
+    "lstep_tail_fwd": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "lstep_tail_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),
 }
 
 
@@ -136,6 +140,42 @@ def current_stream():
 _WORKSPACES = {}
 
 
+def _workspace(dev, need: int):
+    """Device scratch, one buffer per (device, stream), grown on demand: the engine runs update_pe on a side stream (its own host
+    thread) while the backward pass works on the main stream."""
+    import torch
+
+    wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WORKSPACES.get(wkey)
+    if ws is None or ws.numel() < need:
+        ws = _WORKSPACES[wkey] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def linear_wgrad(dy, x, want_bias: bool = True):
+    """``(dy^T x, dy.sum(0))`` through ``lstep_linear_wgrad``; dy [m, n], x [m, k] fp32 device tensors with unit column stride."""
+    import torch
+
+    lib = load_library()
+    m, n = dy.shape
+    k = x.shape[1]
+    if dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != m or dy.dtype != torch.float32 or x.dtype != torch.float32:
+        raise ValueError("linear_wgrad: fp32 [m, n] / [m, k] operands with unit column stride expected")
+    dev = dy.device
+    dw = torch.empty((n, k), dtype=torch.float32, device=dev)
+    db = torch.empty(n, dtype=torch.float32, device=dev) if want_bias else None
+    if m == 0:
+        dw.zero_()
+        if db is not None:
+            db.zero_()
+        return dw, db
+    ws = _workspace(dev, int(lib.lstep_linear_wgrad_workspace(m, n, k)))
+    with torch.cuda.device(dev):
+        check(lib.lstep_linear_wgrad(ptr(dy), dy.stride(0), ptr(x), x.stride(0), m, n, k, ptr(dw), k, ptr(db), ptr(ws), ws.numel(),
+                                     current_stream()))
+    return dw, db
+
+
 def group_by_key(keys, key_bits: int, limit: int):
     """``lstep_group_by_key`` on an int32 device tensor.  Returns (sorted_keys, order, seg, uniq, (n_unique, n_below, n_unique_below));
     the three counts cost one host sync.  The scratch buffer is cached per device and grown on demand."""
@@ -145,12 +185,7 @@ def group_by_key(keys, key_bits: int, limit: int):
     n = keys.numel()
     dev = keys.device
     need = int(lib.lstep_group_by_key_workspace(n, key_bits))
-    # one scratch buffer per (device, stream): the engine runs update_pe on a side stream (its own host thread) while the
-    # backward pass groups gradient hits on the main stream
-    wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _WORKSPACES.get(wkey)
-    if ws is None or ws.numel() < need:
-        ws = _WORKSPACES[wkey] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
+    ws = _workspace(dev, need)
     sorted_keys = torch.empty(n, dtype=torch.int32, device=dev)
     order = torch.empty(n, dtype=torch.int32, device=dev)
     seg = torch.empty(n, dtype=torch.int32, device=dev)

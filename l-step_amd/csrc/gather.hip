@@ -29,13 +29,15 @@ struct GatherParams {
     float* out_pe;
     float* out_self;
     int32_t* out_count;
-    int ld_edge, ld_node, ld_pe, ld_self;  // row strides (floats) of the four outputs; columns past the width are zeroed
+    int ld_edge, ld_node, ld_pe, ld_self;  // row strides (floats) of the four outputs; padding columns up to the next multiple of 16 are zeroed
 };
 
-// zero the padding columns [width, ld) of one output row (ld - width < 64 floats, multiples of 4)
+// zero the padding columns of one output row: [width, width rounded up to 16), clipped to the row stride.  A stride wider than that
+// (the row is a block of a concatenated operand, lstep_tail_fwd) leaves the rest of the row to its owner.
 __device__ __forceinline__ void zero_tail(float* row, int width, int ld, int lane) {
+    const int end = min(ld, (width + 15) & ~15);
     const int c = width + lane * 4;
-    if (c < ld) st4(row + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (c < end) st4(row + c, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 constexpr int kRowsInFlight = 8;      // edge rows + PE rows per group (2 x 8 loads in flight per wave)
@@ -342,8 +344,8 @@ static int check_dims(const char* who, int F, int P, int D) {
 static int check_ld(const char* who, int a, int wa, int b, int wb, int c, int wc, int d, int wd) {
     const int ld[4] = {a, b, c, d}, w[4] = {wa, wb, wc, wd};
     for (int i = 0; i < 4; ++i)
-        if (ld[i] < w[i] || (ld[i] & 3) || ld[i] - w[i] > 4 * kWave)
-            return set_error(LSTEP_EINVAL, "%s: row stride %d invalid for width %d (need a multiple of 4, >= width, padding <= 256)", who, ld[i], w[i]);
+        if (ld[i] < w[i] || (ld[i] & 3))
+            return set_error(LSTEP_EINVAL, "%s: row stride %d invalid for width %d (need a multiple of 4, >= width)", who, ld[i], w[i]);
     return LSTEP_OK;
 }
 

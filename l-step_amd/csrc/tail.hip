@@ -1,0 +1,422 @@
+// The dense tail after the gather stage as ONE kernel per direction:
+//
+//   h1  = relu(W1 x_edge + b1)                         edge_mlp_1 with edge_agg folded in        (models/LSTEP.py:161-166)
+//   p1  = relu(Wn1 x_pe + bn1)                         pe_neighbor_mlp_1                          (:240-242)
+//   q   = own + tanh(Wq [own ; p1] + bq)               self_update_neighbor_pe + pe_neighbor_mlp_2, tanh, residual (:243-247)
+//   out = Wall [x_node ; h1 ; q] + ball                edge_mlp_2 -> node_mlp -> out_node_emb, pre-multiplied (:170,219,264)
+//
+// (the composed, 16-padded weights come from the host layer, see model.py:_TailWeights).  Everything is computed TRANSPOSED on the
+// fp32 matrix cores: a wave owns S slabs of 16 rows and forms Y^T = W X^T with v_mfma_f32_16x16x4_f32, A = a 16 x 4 block of W,
+// B = a 4 x 16 block of X^T.  Two properties of that instruction make the chain register-only:
+//   * operands straight from row-major memory: lane l = (i = l & 15, g = l >> 4) loads the float4 W[n0 + i][k0 + 4g .. +3] and
+//     X[r0 + i][k0 + 4g .. +3]; component v of both is the (A, B) pair of the MFMA that contracts k in {k0 + 4g' + v};
+//     four MFMAs cover the 16-wide k chunk, in a permuted but consistent k order.  No LDS, no transposes.
+//   * an accumulator tile IS the next product's B operand: the C/D layout puts feature 16t + 4g + v of row i in register v of
+//     lane (i, g) -- exactly the B element the MFMA "v" above wants for k = 16t + 4g + v.  So h1, p1 and q never leave the
+//     registers between the layers (they are also written out once, for the backward pass).
+// The weights stream from L2 (1.2 MB, shared by every wave); the activations are read once from HBM.
+#include <type_traits>
+
+#include "lstep_common.h"
+
+namespace lstep {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCe = 272, kPp = 176, kFn = 176;        // 16-aligned widths: edge / PE-aggregate channel (172 + 100), PE, node / out
+constexpr int kTe = kCe / 16, kTp = kPp / 16, kTn = kFn / 16;
+constexpr int kC1 = kFn + kCe + kPp;                  // [x_node | h1 | q]   624
+constexpr int kC2 = 2 * kPp;                          // [own | p1]          352
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// One 16-wide k chunk of operands: A tiles (weights) and B slabs (activation rows), one float4 per lane each.
+template <int T, int S>
+struct Chunk {
+    f32x4 a[T];
+    f32x4 b[S];
+};
+
+// acc[t][s] += sum_k W[16 t + i][k] * X_s[row][k]  over `chunks` 16-wide k chunks.
+//   wl = W + this lane's (i * ldw + 4 g) (already offset to the first tile / first k);  xl[s] = X + row_s * ldx + 4 g + first k.
+// Double-buffered by hand: the loads of chunk c + 1 are issued before the MFMAs of chunk c (the sched barriers keep them
+// there); one chunk is T * S * 4 MFMAs = 128 T S cycles, enough to cover an L2 hit and most HBM misses.
+template <int T, int S>
+__device__ __forceinline__ void mma_wx(f32x4 (*acc)[S], const float* wl, int ldw, int chunks, const float* const (&xl)[S]) {
+    auto load = [&](Chunk<T, S>& o, int c) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) o.b[s] = ldv4(xl[s] + 16 * c);
+#pragma unroll
+        for (int t = 0; t < T; ++t) o.a[t] = ldv4(wl + (size_t)16 * t * ldw + 16 * c);
+    };
+    auto run = [&](const Chunk<T, S>& o) {
+        // v outermost: back-to-back MFMAs on one accumulator would pay the 40-cycle dependent latency instead of the 32-cycle issue
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[t][s] = mfma4(o.a[t][v], o.b[s][v], acc[t][s]);
+            }
+        }
+    };
+    Chunk<T, S> c0, c1;
+    load(c0, 0);
+    for (int c = 0; c < chunks; c += 2) {
+        const bool two = c + 1 < chunks;   // uniform
+        if (two) load(c1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(c0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) {
+            if (c + 2 < chunks) load(c0, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            run(c1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// acc[t][s] += sum over the TK register tiles r[tk][s] (16 features each) of W[16 t + i][16 tk + k] * r
+template <int T, int S, int TK>
+__device__ __forceinline__ void mma_wr(f32x4 (*acc)[S], const float* wl, int ldw, const f32x4 (*r)[S]) {
+    f32x4 a[2][T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) a[0][t] = ldv4(wl + (size_t)16 * t * ldw);
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk) {
+        if (tk + 1 < TK) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[(tk + 1) & 1][t] = ldv4(wl + (size_t)16 * t * ldw + 16 * (tk + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[t][s] = mfma4(a[tk & 1][t][v], r[tk][s][v], acc[t][s]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct TailFwdParams {
+    const float* xe;    // [m, ld_e]  x_edge  (gather output, kCe used)
+    const float* xp;    // [m, ld_p]  x_pe    (gather output, kCe used)
+    float* c1;          // [m, kC1]   [x_node (in) | h1 (out) | q (out)]
+    float* c2;          // [m, kC2]   [own (in) | p1 (out)]
+    float* out;         // [m, kFn]
+    const float *w1, *b1, *wn1, *bn1, *wq, *bq, *wall, *ball;
+    int64_t m;
+    int32_t ld_e, ld_p;
+};
+
+template <int S>
+__global__ __launch_bounds__(kBlock, 1) void tail_fwd_kernel(const TailFwdParams p) {
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    const int64_t r0 = task * (16 * S);
+    if (r0 >= p.m) return;   // no barriers in this kernel
+
+    // per-slab row of this lane (clamped: rows past m compute on a valid row and are not stored)
+    int64_t row[S];
+    bool live[S];
+    const float *xe_l[S], *xp_l[S], *c1_l[S], *c2_l[S];   // this lane's B-operand position in each activation matrix
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int64_t r = r0 + 16 * s + i;
+        live[s] = r < p.m;
+        if (!live[s]) r = p.m - 1;
+        row[s] = r;
+        xe_l[s] = p.xe + r * p.ld_e + 4 * g;
+        xp_l[s] = p.xp + r * p.ld_p + 4 * g;
+        c1_l[s] = p.c1 + r * kC1 + 4 * g;
+        c2_l[s] = p.c2 + r * kC2 + 4 * g;
+    }
+    // this lane's position in a weight matrix with row stride ldw: row i of a 16-row tile, k = 4 g
+    auto wlane = [&](const float* w, int ldw) { return w + i * ldw + 4 * g; };
+    // bias in C layout: features 16 t + 4 g .. + 3
+    auto bias_tile = [&](const float* b, int t) { return *reinterpret_cast<const f32x4*>(b + 16 * t + 4 * g); };
+
+    // ---- p1 = relu(Wn1 x_pe + bn1) ------------------------------------------------------------------------------------------
+    f32x4 p1[kTp][S];
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+        const f32x4 bv = bias_tile(p.bn1, t);
+#pragma unroll
+        for (int s = 0; s < S; ++s) p1[t][s] = bv;
+    }
+    mma_wx<kTp, S>(p1, wlane(p.wn1, kCe), kCe, kTe, xp_l);
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) p1[t][s][v] = fmaxf(p1[t][s][v], 0.f);
+            if (live[s]) *reinterpret_cast<f32x4*>(p.c2 + row[s] * kC2 + kPp + 16 * t + 4 * g) = p1[t][s];
+        }
+    }
+
+    // ---- q = own + tanh(Wq [own ; p1] + bq) ---------------------------------------------------------------------------------
+    f32x4 q[kTp][S];
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+        const f32x4 bv = bias_tile(p.bq, t);
+#pragma unroll
+        for (int s = 0; s < S; ++s) q[t][s] = bv;
+    }
+    mma_wx<kTp, S>(q, wlane(p.wq, kC2), kC2, kTp, c2_l);
+    mma_wr<kTp, S, kTp>(q, wlane(p.wq + kPp, kC2), kC2, p1);
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const f32x4 own = *reinterpret_cast<const f32x4*>(p.c2 + row[s] * kC2 + 16 * t + 4 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) q[t][s][v] = own[v] + tanhf(q[t][s][v]);
+            if (live[s]) *reinterpret_cast<f32x4*>(p.c1 + row[s] * kC1 + kFn + kCe + 16 * t + 4 * g) = q[t][s];
+        }
+    }
+
+    // ---- out = Wall [x_node ; h1 ; q] + ball, h1 = relu(W1 x_edge + b1) produced 6 (5) tiles at a time -------------------------
+    f32x4 o[kTn][S];
+#pragma unroll
+    for (int t = 0; t < kTn; ++t) {
+        const f32x4 bv = bias_tile(p.ball, t);
+#pragma unroll
+        for (int s = 0; s < S; ++s) o[t][s] = bv;
+    }
+    mma_wx<kTn, S>(o, wlane(p.wall, kC1), kC1, kTn, c1_l);
+    mma_wr<kTn, S, kTp>(o, wlane(p.wall + kFn + kCe, kC1), kC1, q);
+    auto h1_group = [&](auto group_size, int t0) {   // h1 tiles [t0, t0 + G): produce, store, fold into out
+        constexpr int G = decltype(group_size)::value;
+        f32x4 h[G][S];
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const f32x4 bv = bias_tile(p.b1, t0 + t);
+#pragma unroll
+            for (int s = 0; s < S; ++s) h[t][s] = bv;
+        }
+        mma_wx<G, S>(h, wlane(p.w1 + (size_t)16 * t0 * kCe, kCe), kCe, kTe, xe_l);
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) h[t][s][v] = fmaxf(h[t][s][v], 0.f);
+                if (live[s]) *reinterpret_cast<f32x4*>(p.c1 + row[s] * kC1 + kFn + 16 * (t0 + t) + 4 * g) = h[t][s];
+            }
+        }
+        mma_wr<kTn, S, G>(o, wlane(p.wall + kFn + 16 * t0, kC1), kC1, h);
+    };
+    static_assert(kTe == 17, "h1 tile groups 6 + 6 + 5");
+    h1_group(std::integral_constant<int, 6>{}, 0);
+    h1_group(std::integral_constant<int, 6>{}, 6);
+    h1_group(std::integral_constant<int, 5>{}, 12);
+#pragma unroll
+    for (int t = 0; t < kTn; ++t) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (live[s]) *reinterpret_cast<f32x4*>(p.out + row[s] * kFn + 16 * t + 4 * g) = o[t][s];
+    }
+}
+
+// ---- backward: the same chain run through the transposed weights ---------------------------------------------------------------
+//   d_q  = WallT[q rows] g            d_z = d_q * (1 - tanh^2)          d_own = d_q + WqT[own rows] d_z
+//   d_p1 = WqT[p1 rows] d_z * [p1 > 0]                                   d_xpe = Wn1T d_p1
+//   d_h1 = WallT[h1 rows] g * [h1 > 0]                                   d_xedge = W1T d_h1
+// (xT = the [in, out] row-major transpose of a forward weight, so every product has the forward's operand layout).  d_z, d_p1, d_h1
+// are also written out: they are the dY operands of the four weight-gradient products (lstep_linear_wgrad).
+struct TailBwdParams {
+    const float* g;      // [m, kFn]  gradient of out
+    const float* c1;     // [m, kC1]  [x_node | h1 | q]
+    const float* c2;     // [m, kC2]  [own | p1]
+    const float *w1t, *wn1t, *wqt, *wallt;   // [272,272] [272,176] [352,176] [624,176]
+    float* dxe;          // [m, kCe]
+    float* dxp;          // [m, kCe]
+    float* down;         // [m, ld_down] (kPp used)
+    float* dh1;          // [m, kCe]
+    float* dp1;          // [m, kPp]
+    float* dz;           // [m, kPp]
+    int64_t m;
+    int32_t ld_down;
+};
+
+template <int S>
+__global__ __launch_bounds__(kBlock, 1) void tail_bwd_kernel(const TailBwdParams p) {
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    const int64_t r0 = task * (16 * S);
+    if (r0 >= p.m) return;   // no barriers in this kernel
+
+    int64_t row[S];
+    bool live[S];
+    const float* g_l[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int64_t r = r0 + 16 * s + i;
+        live[s] = r < p.m;
+        if (!live[s]) r = p.m - 1;
+        row[s] = r;
+        g_l[s] = p.g + r * kFn + 4 * g;
+    }
+    auto wlane = [&](const float* w, int ldw) { return w + i * ldw + 4 * g; };
+    auto zero = [&](f32x4 (*a)[S], int tiles) {
+#pragma unroll
+        for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) a[t][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    {   // ---- PE channel ---------------------------------------------------------------------------------------------------------
+        f32x4 dq[kTp][S], dz[kTp][S];
+        zero(dq, kTp);
+        mma_wx<kTp, S>(dq, wlane(p.wallt + (size_t)(kFn + kCe) * kFn, kFn), kFn, kTn, g_l);
+#pragma unroll
+        for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const f32x4 qv = ldv4(p.c1 + row[s] * kC1 + kFn + kCe + 16 * t + 4 * g);
+                const f32x4 ov = ldv4(p.c2 + row[s] * kC2 + 16 * t + 4 * g);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float th = qv[v] - ov[v];   // tanh(z), from q = own + tanh(z)
+                    dz[t][s][v] = dq[t][s][v] * (1.f - th * th);
+                }
+                if (live[s]) *reinterpret_cast<f32x4*>(p.dz + row[s] * kPp + 16 * t + 4 * g) = dz[t][s];
+            }
+        }
+        mma_wr<kTp, S, kTp>(dq, wlane(p.wqt, kPp), kPp, dz);   // d_own = d_q + WqT[own rows] d_z
+#pragma unroll
+        for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (live[s]) *reinterpret_cast<f32x4*>(p.down + row[s] * p.ld_down + 16 * t + 4 * g) = dq[t][s];
+        }
+        zero(dq, kTp);                                          // now d_p1
+        mma_wr<kTp, S, kTp>(dq, wlane(p.wqt + (size_t)kPp * kPp, kPp), kPp, dz);
+#pragma unroll
+        for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const f32x4 pv = ldv4(p.c2 + row[s] * kC2 + kPp + 16 * t + 4 * g);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dq[t][s][v] = pv[v] > 0.f ? dq[t][s][v] : 0.f;
+                if (live[s]) *reinterpret_cast<f32x4*>(p.dp1 + row[s] * kPp + 16 * t + 4 * g) = dq[t][s];
+            }
+        }
+        // d_xpe = Wn1T d_p1, 17 output tiles as 9 + 8 (register budget)
+        auto dxp_part = [&](auto tiles, int t0) {
+            constexpr int TT = decltype(tiles)::value;
+            f32x4 dx[TT][S];
+            zero(dx, TT);
+            mma_wr<TT, S, kTp>(dx, wlane(p.wn1t + (size_t)16 * t0 * kPp, kPp), kPp, dq);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    if (live[s]) *reinterpret_cast<f32x4*>(p.dxp + row[s] * kCe + 16 * (t0 + t) + 4 * g) = dx[t][s];
+            }
+        };
+        dxp_part(std::integral_constant<int, 9>{}, 0);
+        dxp_part(std::integral_constant<int, 8>{}, 9);
+    }
+
+    {   // ---- edge channel: d_h1 six (five) tiles at a time, each group folded into d_xedge right away -----------------------------
+        f32x4 dx[kTe][S];
+        zero(dx, kTe);
+        auto dh1_group = [&](auto group_size, int t0) {
+            constexpr int G = decltype(group_size)::value;
+            f32x4 dh[G][S];
+            zero(dh, G);
+            mma_wx<G, S>(dh, wlane(p.wallt + (size_t)(kFn + 16 * t0) * kFn, kFn), kFn, kTn, g_l);
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const f32x4 hv = ldv4(p.c1 + row[s] * kC1 + kFn + 16 * (t0 + t) + 4 * g);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) dh[t][s][v] = hv[v] > 0.f ? dh[t][s][v] : 0.f;
+                    if (live[s]) *reinterpret_cast<f32x4*>(p.dh1 + row[s] * kCe + 16 * (t0 + t) + 4 * g) = dh[t][s];
+                }
+            }
+            // d_xedge[all 17 tiles] += W1T[:, this group's columns] d_h1 group, as 9 + 8 output tiles (A-operand registers)
+            mma_wr<9, S, G>(dx, wlane(p.w1t + 16 * t0, kCe), kCe, dh);
+            mma_wr<kTe - 9, S, G>(dx + 9, wlane(p.w1t + (size_t)(16 * 9) * kCe + 16 * t0, kCe), kCe, dh);
+        };
+        static_assert(kTe == 17, "d_h1 tile groups 6 + 6 + 5");
+        dh1_group(std::integral_constant<int, 6>{}, 0);
+        dh1_group(std::integral_constant<int, 6>{}, 6);
+        dh1_group(std::integral_constant<int, 5>{}, 12);
+#pragma unroll
+        for (int t = 0; t < kTe; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (live[s]) *reinterpret_cast<f32x4*>(p.dxe + row[s] * kCe + 16 * t + 4 * g) = dx[t][s];
+        }
+    }
+}
+
+}  // namespace lstep
+
+using namespace lstep;
+
+// number of 16-row slabs per wave: the choice that needs the fewest rounds of 1024 waves (256 CUs x 4 SIMDs, one wave each)
+static int tail_slabs_per_wave(int64_t m) {
+    const int64_t slabs = (m + 15) / 16;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int s = 1; s <= 3; ++s) {
+        const int64_t tasks = (slabs + s - 1) / s;
+        const int64_t cost = ((tasks + 1023) / 1024) * s;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && s > best)) { best = s; best_cost = cost; }
+    }
+    return best;
+}
+
+extern "C" int lstep_tail_fwd(const float* x_edge, int32_t ld_edge, const float* x_pe, int32_t ld_pe, float* cat1, float* cat2, float* out,
+                              const float* w1, const float* b1, const float* wn1, const float* bn1, const float* wq, const float* bq,
+                              const float* wall, const float* ball, int64_t m, void* stream) {
+    if (m < 0 || ld_edge < kCe || ld_pe < kCe || (ld_edge & 3) || (ld_pe & 3)) return set_error(LSTEP_EINVAL, "lstep_tail_fwd: bad sizes");
+    if (m == 0) return LSTEP_OK;
+    if (!x_edge || !x_pe || !cat1 || !cat2 || !out || !w1 || !b1 || !wn1 || !bn1 || !wq || !bq || !wall || !ball)
+        return set_error(LSTEP_EINVAL, "lstep_tail_fwd: NULL pointer");
+    TailFwdParams p;
+    p.xe = x_edge; p.xp = x_pe; p.c1 = cat1; p.c2 = cat2; p.out = out;
+    p.w1 = w1; p.b1 = b1; p.wn1 = wn1; p.bn1 = bn1; p.wq = wq; p.bq = bq; p.wall = wall; p.ball = ball;
+    p.m = m; p.ld_e = ld_edge; p.ld_p = ld_pe;
+    const int S = tail_slabs_per_wave(m);
+    const int64_t tasks = ((m + 15) / 16 + S - 1) / S;
+    const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (S == 1) hipLaunchKernelGGL(tail_fwd_kernel<1>, grid, block, 0, s, p);
+    else if (S == 2) hipLaunchKernelGGL(tail_fwd_kernel<2>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(tail_fwd_kernel<3>, grid, block, 0, s, p);
+    return check_launch("lstep_tail_fwd");
+}
+
+extern "C" int lstep_tail_bwd(const float* grad_out, const float* cat1, const float* cat2, const float* w1t, const float* wn1t,
+                              const float* wqt, const float* wallt, float* d_xedge, float* d_xpe, float* d_own, int32_t ld_down, float* d_h1,
+                              float* d_p1, float* d_z, int64_t m, void* stream) {
+    if (m < 0 || ld_down < kPp || (ld_down & 3)) return set_error(LSTEP_EINVAL, "lstep_tail_bwd: bad sizes");
+    if (m == 0) return LSTEP_OK;
+    if (!grad_out || !cat1 || !cat2 || !w1t || !wn1t || !wqt || !wallt || !d_xedge || !d_xpe || !d_own || !d_h1 || !d_p1 || !d_z)
+        return set_error(LSTEP_EINVAL, "lstep_tail_bwd: NULL pointer");
+    TailBwdParams p;
+    p.g = grad_out; p.c1 = cat1; p.c2 = cat2; p.w1t = w1t; p.wn1t = wn1t; p.wqt = wqt; p.wallt = wallt;
+    p.dxe = d_xedge; p.dxp = d_xpe; p.down = d_own; p.dh1 = d_h1; p.dp1 = d_p1; p.dz = d_z; p.m = m; p.ld_down = ld_down;
+    const int S = tail_slabs_per_wave(m);
+    const int64_t tasks = ((m + 15) / 16 + S - 1) / S;
+    const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (S == 1) hipLaunchKernelGGL(tail_bwd_kernel<1>, grid, block, 0, s, p);
+    else if (S == 2) hipLaunchKernelGGL(tail_bwd_kernel<2>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(tail_bwd_kernel<3>, grid, block, 0, s, p);
+    return check_launch("lstep_tail_bwd");
+}

@@ -58,6 +58,7 @@ class _Linear(torch.autograd.Function):
     that shape reach 30-60 TFLOP/s on MI355X, the same product as 32 row-chunk ``bmm`` + one ``sum`` reaches 65-105
     (tools/gemm_dw.py).  Forward and dX are the plain library GEMMs."""
 
+    NATIVE_WGRAD = os.environ.get("LSTEP_TORCH_WGRAD", "0") != "1"   # A/B switch: 1 = library GEMMs for the weight gradient
     CHUNKS = int(os.environ.get("LSTEP_DW_CHUNKS", "16"))   # tuning knob: 16-32 row chunks are best (tools/gemm_dw.py; 16 in the full step)
 
     @staticmethod
@@ -84,6 +85,10 @@ class _Linear(torch.autograd.Function):
             dx = dy @ w
         if ctx.needs_input_grad[1]:
             m = x.shape[0]
+            if _Linear.NATIVE_WGRAD and x.is_cuda and x.stride(1) == 1 and w.shape[0] >= 64:
+                # hand-written fp32-MFMA kernel: dW and db in one pass over dy and x (lstep_linear_wgrad)
+                dw, db = nat.linear_wgrad(dy, x, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+                return dx, dw, db, None
             c = math.gcd(m, _Linear.CHUNKS)
             if c >= 4 and m // c >= 256 and x.is_contiguous():
                 dw = torch.bmm(dy.view(c, m // c, -1).transpose(1, 2), x.view(c, m // c, -1)).sum(dim=0)
@@ -170,6 +175,44 @@ class _TailWeights(torch.autograd.Function):
         d_Wo = torch.cat([dWo_a, dWo_b], dim=1)
         return (None, gW1p[:C, :C], d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, dc, gWq[:P, :P], gbq[:P], gWn1p[:P, :CP],
                 gbn1p[:P], gWq[:P, Pp:Pp + P], gbq[:P])
+
+
+class _FusedTail(torch.autograd.Function):
+    """All dense layers after the gather stage as one launch per direction (``lstep_tail_fwd`` / ``lstep_tail_bwd``, fp32 matrix
+    cores) plus four ``lstep_linear_wgrad`` products, instead of ~15 + ~40 library launches.  ``cat1`` = [x_node | . | .] and
+    ``cat2`` = [own | . ] arrive from the gather stage with their first block filled; the kernels write h1 / q / p1 into the rest."""
+
+    @staticmethod
+    def forward(ctx, x_edge, x_pe, cat1, cat2, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp):
+        lib = nat.load_library()
+        m = x_edge.shape[0]
+        out = torch.empty((m, Wall.shape[0]), dtype=torch.float32, device=x_edge.device)
+        ws = [t.contiguous() for t in (W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp)]
+        with torch.cuda.device(x_edge.device):
+            nat.check(lib.lstep_tail_fwd(nat.ptr(x_edge), x_edge.stride(0), nat.ptr(x_pe), x_pe.stride(0), nat.ptr(cat1), nat.ptr(cat2),
+                                         nat.ptr(out), *[nat.ptr(t) for t in ws], m, nat.current_stream()))
+        ctx.save_for_backward(x_edge, x_pe, cat1, cat2, ws[0], ws[2], ws[4], ws[6])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = nat.load_library()
+        x_edge, x_pe, cat1, cat2, W1p, Wn1p, Wq, Wall = ctx.saved_tensors
+        m, dev = x_edge.shape[0], x_edge.device
+        g_out = g_out.contiguous()
+        w1t, wn1t, wqt, wallt = W1p.t().contiguous(), Wn1p.t().contiguous(), Wq.t().contiguous(), Wall.t().contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        d_xe, d_xp, d_own = new(m, W1p.shape[1]), new(m, Wn1p.shape[1]), new(m, cat2.shape[1])
+        d_h1, d_p1, d_z = new(m, W1p.shape[0]), new(m, Wn1p.shape[0]), new(m, Wq.shape[0])
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_tail_bwd(nat.ptr(g_out), nat.ptr(cat1), nat.ptr(cat2), nat.ptr(w1t), nat.ptr(wn1t), nat.ptr(wqt), nat.ptr(wallt),
+                                         nat.ptr(d_xe), nat.ptr(d_xp), nat.ptr(d_own), d_own.stride(0), nat.ptr(d_h1), nat.ptr(d_p1),
+                                         nat.ptr(d_z), m, nat.current_stream()))
+        gW1, gb1 = nat.linear_wgrad(d_h1, x_edge[:, :W1p.shape[1]])
+        gWn1, gbn1 = nat.linear_wgrad(d_p1, x_pe[:, :Wn1p.shape[1]])
+        gWq, gbq = nat.linear_wgrad(d_z, cat2)
+        gWall, gconst = nat.linear_wgrad(g_out, cat1)
+        return d_xe, d_xp, None, d_own, gW1, gb1, gWn1, gbn1, gWq, gbq, gWall, gconst
 
 
 # ------------------------------------------------------------------------------------------------ small modules
@@ -266,19 +309,23 @@ def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self):
 class _GatherAggregate(torch.autograd.Function):
     """lstep_gather_aggregate_fwd / _bwd.  Differentiable inputs: ``pe`` (dense table) OR ``rows`` (spliced rows), ``agg_w``.
     Outputs are row-padded to multiples of 16 floats (``mod.ld_*``; padding columns are zero) so every following GEMM has
-    16-aligned K: hipBLASLt runs 288/176-wide fp32 GEMMs up to 2.5x faster than 272/172-wide ones (tools/gemm_shapes.py)."""
+    16-aligned K: hipBLASLt runs 176-wide fp32 GEMMs up to 2.5x faster than 172-wide ones (tools/gemm_shapes.py)."""
 
     @staticmethod
-    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of):
+    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False):
         lib = nat.load_library()
         dev = ids.device
         B = ids.numel()
         Fd, P, D = mod.feat_dim, mod.pe_dim, mod.time_dim
         en, pb = bool(branches & nat.BRANCH_EDGE_NODE), bool(branches & nat.BRANCH_PE)
+        # wide: the node / self rows land in the first columns of the fused tail's concatenated operands
+        # ([x_node | h1 | q] and [own | p1], lstep_tail_fwd), so no torch.cat ever copies them
+        ld_node = mod.ld_node + mod.ld_edge + mod.ld_self if wide else mod.ld_node
+        ld_self = 2 * mod.ld_self if wide else mod.ld_self
         out_edge = torch.empty((B, mod.ld_edge), dtype=torch.float32, device=dev) if en else None
-        out_node = torch.empty((B, mod.ld_node), dtype=torch.float32, device=dev) if en else None
+        out_node = torch.empty((B, ld_node), dtype=torch.float32, device=dev) if en else None
         out_pe = torch.empty((B, mod.ld_pe), dtype=torch.float32, device=dev) if pb else None
-        out_self = torch.empty((B, mod.ld_self), dtype=torch.float32, device=dev) if pb else None
+        out_self = torch.empty((B, ld_self), dtype=torch.float32, device=dev) if pb else None
         count = torch.empty((B,), dtype=torch.int32, device=dev)
         pe_c = None
         if pb:
@@ -292,9 +339,9 @@ class _GatherAggregate(torch.autograd.Function):
             nat.check(lib.lstep_gather_aggregate_fwd(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
                                                      Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
                                                      int(K), int(G), int(branches), nat.ptr(out_edge), nat.ptr(out_node), nat.ptr(out_pe),
-                                                     nat.ptr(out_self), mod.ld_edge, mod.ld_node, mod.ld_pe, mod.ld_self, nat.ptr(count),
+                                                     nat.ptr(out_self), mod.ld_edge, ld_node, mod.ld_pe, ld_self, nat.ptr(count),
                                                      nat.current_stream()))
-        ctx.mod, ctx.sampler, ctx.K, ctx.branches = mod, s, int(K), int(branches)
+        ctx.mod, ctx.sampler, ctx.K, ctx.branches, ctx.ld_self = mod, s, int(K), int(branches), ld_self
         ctx.pe_shape = tuple(pe.shape) if pe is not None else None
         ctx.rows_shape = tuple(rows.shape) if rows is not None else None
         ctx.save_for_backward(ids, times, count, slot_of if slot_of is not None else torch.empty(0, device=dev))
@@ -332,7 +379,7 @@ class _GatherAggregate(torch.autograd.Function):
             with torch.cuda.device(dev):
                 nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
                                                          nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, nat.ptr(g_edge), nat.ptr(g_pe),
-                                                         nat.ptr(g_self), mod.ld_edge, mod.ld_pe, mod.ld_self,
+                                                         nat.ptr(g_self), mod.ld_edge, mod.ld_pe, ctx.ld_self,
                                                          nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
                                                          nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
         if use_slot:
@@ -347,7 +394,7 @@ class _GatherAggregate(torch.autograd.Function):
         elif grad_rows is not None and g_pe is not None:
             # spliced mode: row 0 only has gradient if node 0 is itself a spliced row (never in the reference data)
             pass
-        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None)
+        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None, None)
 
 
 class _FftCoefficients(torch.autograd.Function):
@@ -503,7 +550,7 @@ class LSTEP(nn.Module):
             if lo < 0 or hi >= self.neighbor_sampler.num_rows or hi >= self.node_raw_features.shape[0]:
                 raise IndexError(f"node id out of range [0, {self.node_raw_features.shape[0]})")
 
-    def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None):
+    def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None, wide: bool = False):
         if K != self.num_neighbors and (branches & nat.BRANCH_EDGE_NODE):
             raise RuntimeError(f"edge_agg was built for num_neighbors={self.num_neighbors}, got {K} "
                                "(the reference fails the same way at models/LSTEP.py:164)")
@@ -526,11 +573,11 @@ class LSTEP(nn.Module):
             raise ValueError("slot_of must be an int32 map with one entry per node id")
         sink = getattr(self, "gather_event_sink", None)
         if sink is None:
-            return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of)
+            return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide)
         # bench.py: HIP events on the launch stream around the forward gather launch (roofline.achieved)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of)
+        out = _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide)
         e1.record()
         sink.append((e0, e1, out[4]))
         return out
@@ -560,11 +607,18 @@ class LSTEP(nn.Module):
     # ---- O (models/LSTEP.py:251-266): one fused gather launch serves A, N and C
     def combining_pe_raw_feat(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, time_gap: int = 2000, testing=False,
                               spliced: SplicedRows = None):
+        fused = self._fused_tail_ok()
         x_edge, x_node, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, time_gap,
-                                                    nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced)
-        return self._combined_tail(x_edge, x_node, x_pe, own)
+                                                    nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced, wide=fused)
+        return self._combined_tail(x_edge, x_node, x_pe, own, fused)
 
-    def _combined_tail(self, x_edge, x_node, x_pe, own):
+    def _fused_tail_ok(self) -> bool:
+        """The single-launch tail is compiled for the default widths (feature / PE dim 172, time dim 100); other shapes (and
+        LSTEP_TORCH_TAIL=1, the A/B switch) take the library-GEMM tail."""
+        return (os.environ.get("LSTEP_TORCH_TAIL", "0") != "1"
+                and (self.ld_edge, self.ld_node, self.ld_pe, self.ld_self) == (272, 176, 272, 176))
+
+    def _combined_tail(self, x_edge, x_node, x_pe, own, fused: bool = False):
         """All dense layers after the gather stage, with the purely linear stretches pre-multiplied.
 
         After the relu of the edge channel nothing non-linear touches the A/N branch any more
@@ -578,12 +632,14 @@ class LSTEP(nn.Module):
         All operands are zero-padded to 16-aligned widths (inputs by the gather kernel, weights here): the padding
         columns stay exactly 0 through relu / tanh / residual, so results are unchanged."""
         Fd, P, D = self.feat_dim, self.pe_dim, self.time_dim
-        Ce, Fn, Cp, Pp = self.ld_edge, self.ld_node, self.ld_pe, self.ld_self   # padded widths (288, 176, 288, 176)
+        Ce, Fn, Cp, Pp = self.ld_edge, self.ld_node, self.ld_pe, self.ld_self   # 16-aligned widths (272, 176, 272, 176)
         W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp = _TailWeights.apply(
             (Fd, D + Fd, P, P + D, Ce, Fn, Cp, Pp), self.edge_mlp_1.weight, self.edge_mlp_1.bias, self.edge_agg.weight, self.edge_agg.bias,
             self.edge_mlp_2.weight, self.edge_mlp_2.bias, self.node_mlp.weight, self.node_mlp.bias, self.out_node_emb.weight,
             self.out_node_emb.bias, self.self_update_neighbor_pe.weight, self.self_update_neighbor_pe.bias,
             self.pe_neighbor_mlp_1.weight, self.pe_neighbor_mlp_1.bias, self.pe_neighbor_mlp_2.weight, self.pe_neighbor_mlp_2.bias)
+        if fused:   # x_node / own are the wide [x_node | h1 | q] / [own | p1] buffers of the gather stage
+            return _FusedTail.apply(x_edge, x_pe, x_node, own, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp)[:, :Fd]
         h1 = fast_linear(x_edge, W1p, b1p, relu=True)                                          # [B, Ce]
         p1 = fast_linear(x_pe, Wn1p, bn1p, relu=True)                                          # [B, Pp]
         q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), Wq, bq))                # [B, Pp]
