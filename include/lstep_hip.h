@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 7
+#define LSTEP_ABI_VERSION 8
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -193,6 +193,27 @@ int lstep_tail_fwd(const float* x_edge, int32_t ld_edge, const float* x_pe, int3
 int lstep_tail_bwd(const float* grad_out, const float* cat1, const float* cat2, const float* w1t, const float* wn1t, const float* wqt,
                    const float* wallt, float* d_xedge, float* d_xpe, float* d_own, int32_t ld_down, float* d_h1, float* d_p1, float* d_z,
                    int64_t m, void* stream);
+
+/* Stable sort of the LIVE entries of an int32 key array: entries with a negative key are dropped first (one select pass), the rest
+ * are sorted on their low key_bits bits.  sorted_keys[num_live], order[num_live] (original index of every sorted entry; equal
+ * keys keep their input order); *num_live is written on the HOST (the call waits for the select pass on `stream`).  Used for the
+ * gradient hits of lstep_gather_aggregate_bwd (out_hits), where ~95 % of the entries are -1.
+ * workspace: lstep_sort_live_workspace(n, key_bits) bytes of device scratch. */
+int64_t lstep_sort_live_workspace(int64_t n, int32_t key_bits);
+int lstep_sort_live(const int32_t* keys, int64_t n, int32_t key_bits, void* workspace, int64_t workspace_bytes, int32_t* sorted_keys,
+                    int32_t* order, int64_t* num_live, void* stream);
+
+/* P -- the scalar end of a training iteration and its gradient (train_LSTEP_link_prediction.py:257-275):
+ *   lp_loss = BCE(sigmoid(logits).clamp(0, 1), [1]*n + [0]*n),  pe_loss = MSE(e_src, e_dst) - neg_weight * MSE(e_src, e_neg),
+ *   loss = (1 - pe_weight) * lp_loss + pe_weight * pe_loss,
+ * e_x = rows[slot_of[x]] if slot_of[x] >= 0 (the spliced, differentiable row of batch node x) else table[x].
+ * logits [2 n] (positive | negative edges), ids int64 [3 n] (src | dst | negative dst).  Outputs: predicts [2 n] (the clamped
+ * probabilities), losses [3] = {lp_loss, pe_loss, loss}, and the gradient of `loss`: d_logits [2 n], d_rows [U, pe_dim]
+ * (accumulated with float atomics: the caller zeroes it).  workspace: lstep_link_loss_workspace(n) bytes. */
+int64_t lstep_link_loss_workspace(int64_t n);
+int lstep_link_loss(const float* logits, const int64_t* ids, int64_t n, const float* table, const float* rows, const int32_t* slot_of,
+                    int32_t pe_dim, float pe_weight, float neg_weight, float* predicts, float* d_logits, float* d_rows, float* losses,
+                    void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

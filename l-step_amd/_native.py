@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
-SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip"]
+SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 7
+ABI_VERSION = 8
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -82,6 +82,10 @@ SIGNATURES = {
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
     "lstep_group_by_key_workspace": (_I64, [_I64, _I32]),
     "lstep_group_by_key": (C.c_int, [_P, _I64, _I32, _I32, _P, _I64, _P, _P, _P, _P, _P, _P]),
+    "lstep_link_loss_workspace": (_I64, [_I64]),
+    "lstep_link_loss": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _I64, _P]),
+    "lstep_sort_live_workspace": (_I64, [_I64, _I32]),
+    "lstep_sort_live": (C.c_int, [_P, _I64, _I32, _P, _I64, _P, _P, C.POINTER(C.c_int64), _P]),
     "lstep_linear_wgrad_workspace": (_I64, [_I64, _I32, _I32]),
     "lstep_linear_wgrad": (C.c_int, [_P, _I32, _P, _I32, _I64, _I32, _I32, _P, _I32, _P, _P, _I64, _P]),
     "lstep_tail_fwd": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
@@ -150,6 +154,24 @@ def _workspace(dev, need: int):
     if ws is None or ws.numel() < need:
         ws = _WORKSPACES[wkey] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
     return ws
+
+
+def sort_live(keys, key_bits: int):
+    """``lstep_sort_live``: (sorted_keys, order, num_live) of the non-negative int32 keys; one host sync inside the call."""
+    import torch
+
+    lib = load_library()
+    n = keys.numel()
+    dev = keys.device
+    sorted_keys = torch.empty(n, dtype=torch.int32, device=dev)
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    live = C.c_int64(0)
+    if n:
+        ws = _workspace(dev, int(lib.lstep_sort_live_workspace(n, key_bits)))
+        with torch.cuda.device(dev):
+            check(lib.lstep_sort_live(ptr(keys), n, int(key_bits), ptr(ws), ws.numel(), ptr(sorted_keys), ptr(order), C.byref(live),
+                                      current_stream()))
+    return sorted_keys, order, int(live.value)
 
 
 def linear_wgrad(dy, x, want_bias: bool = True):

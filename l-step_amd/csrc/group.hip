@@ -34,6 +34,25 @@ __global__ void unique_kernel(const int32_t* __restrict__ sk, const int32_t* __r
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+struct NonNegative {   // select predicate over entry indices: keep i if keys[i] >= 0
+    const int32_t* keys;
+    __host__ __device__ bool operator()(const int32_t& i) const { return keys[i] >= 0; }
+};
+
+__global__ void take_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+                            int32_t* __restrict__ out) {
+    const int64_t n = *count;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = src[idx[i]];
+}
+
+static size_t select_temp_bytes(int64_t n) {
+    size_t a = 0;
+    NonNegative pred{nullptr};
+    (void)hipcub::DeviceSelect::If(nullptr, a, hipcub::CountingInputIterator<int32_t>(0), (int32_t*)nullptr, (int32_t*)nullptr, (int)n, pred,
+                                   (hipStream_t)0);
+    return a;
+}
+
 static size_t cub_temp_bytes(int64_t n, int bits) {
     size_t a = 0, b = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
@@ -78,4 +97,43 @@ extern "C" int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bi
         return set_error(LSTEP_EHIP, "lstep_group_by_key: scan failed");
     hipLaunchKernelGGL(unique_kernel, dim3(grid), dim3(256), 0, s, sorted_keys, seg, n, limit, uniq, summary);
     return check_launch("lstep_group_by_key");
+}
+
+// ---- "sort the live entries": keys < 0 are dropped BEFORE the sort.  The gradient hits of the gather backward are ~95 % dead
+// (only neighbours that are batch nodes themselves carry gradient), and the library sorts ~1 M pairs with ~20 merge passes.
+extern "C" int64_t lstep_sort_live_workspace(int64_t n, int32_t key_bits) {
+    if (n <= 0) return 256;
+    const size_t temp = cub_temp_bytes(n, key_bits) > select_temp_bytes(n) ? cub_temp_bytes(n, key_bits) : select_temp_bytes(n);
+    return (int64_t)(2 * align256((size_t)n * 4) + align256(temp) + 512);
+}
+
+extern "C" int lstep_sort_live(const int32_t* keys, int64_t n, int32_t key_bits, void* workspace, int64_t workspace_bytes, int32_t* sorted_keys,
+                               int32_t* order, int64_t* num_live, void* stream) {
+    if (n < 0 || key_bits <= 0 || key_bits > 31 || !num_live) return set_error(LSTEP_EINVAL, "lstep_sort_live: bad arguments");
+    if (n >= ((int64_t)1 << 31)) return set_error(LSTEP_EINVAL, "lstep_sort_live: more than 2^31 - 1 entries");
+    *num_live = 0;
+    if (n == 0) return LSTEP_OK;
+    if (!keys || !workspace || !sorted_keys || !order) return set_error(LSTEP_EINVAL, "lstep_sort_live: NULL pointer");
+    if (workspace_bytes < lstep_sort_live_workspace(n, key_bits)) return set_error(LSTEP_EINVAL, "lstep_sort_live: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int32_t* idx = (int32_t*)ws;                                   // live entry indices, ascending
+    int32_t* live_keys = (int32_t*)(ws + align256((size_t)n * 4));
+    int32_t* count = (int32_t*)(ws + 2 * align256((size_t)n * 4));
+    void* temp = ws + 2 * align256((size_t)n * 4) + 256;
+    size_t temp_bytes = select_temp_bytes(n);
+    NonNegative pred{keys};
+    if (hipcub::DeviceSelect::If(temp, temp_bytes, hipcub::CountingInputIterator<int32_t>(0), idx, count, (int)n, pred, s) != hipSuccess)
+        return set_error(LSTEP_EHIP, "lstep_sort_live: select failed");
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(take_kernel, dim3(grid), dim3(256), 0, s, keys, idx, count, live_keys);
+    int32_t host_count = 0;   // the one host round trip: the sort (and the caller's segment sum) are sized by it
+    if (hipMemcpyAsync(&host_count, count, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return set_error(LSTEP_EHIP, "lstep_sort_live: count read-back failed");
+    *num_live = host_count;
+    if (host_count == 0) return LSTEP_OK;
+    temp_bytes = cub_temp_bytes(host_count, key_bits);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, live_keys, sorted_keys, idx, order, (int)host_count, 0, key_bits, s) != hipSuccess)
+        return set_error(LSTEP_EHIP, "lstep_sort_live: radix sort failed");
+    return check_launch("lstep_sort_live");
 }

@@ -150,6 +150,37 @@ def _lookup_rows(table: torch.Tensor, spliced: SplicedRows, ids: torch.Tensor) -
     return _LookupRows.apply(spliced.rows, table, spliced.slot_of, ids)
 
 
+class _LinkLoss(torch.autograd.Function):
+    """``lstep_link_loss``: link-prediction BCE + positional-encoding MSE terms of train:257-275 and the gradient of their weighted
+    sum in one launch (the gradient is produced by the forward kernel; backward only scales it by the incoming gradient)."""
+
+    @staticmethod
+    def forward(ctx, logits, rows, table, slot_of, ids, pe_weight, neg_weight):
+        lib = nat.load_library()
+        dev = logits.device
+        n = ids.numel() // 3
+        logits = logits.contiguous()
+        predicts = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        d_logits = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        d_rows = torch.zeros_like(rows)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = nat._workspace(dev, int(lib.lstep_link_loss_workspace(n)))
+        rows_c = rows.detach().contiguous()
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_link_loss(nat.ptr(logits), nat.ptr(ids), n, nat.ptr(table), nat.ptr(rows_c), nat.ptr(slot_of), rows.shape[1],
+                                          float(pe_weight), float(neg_weight), nat.ptr(predicts), nat.ptr(d_logits), nat.ptr(d_rows),
+                                          nat.ptr(losses), nat.ptr(ws), ws.numel(), nat.current_stream()))
+        ctx.save_for_backward(d_logits, d_rows)
+        lp, pe, loss = losses[0], losses[1], losses[2]
+        ctx.mark_non_differentiable(lp, pe, predicts)
+        return loss, lp, pe, predicts
+
+    @staticmethod
+    def backward(ctx, g_loss, g_lp, g_pe, g_pred):
+        d_logits, d_rows = ctx.saved_tensors
+        return g_loss * d_logits, g_loss * d_rows, None, None, None, None, None
+
+
 class LstepEngine:
     def __init__(self, backbone: LSTEP, predictor: MergeLayer, num_neighbors: int, time_gap: int,
                  pe_weight: float = 0.5, neg_sample_weight: float = 0.3, make_ring: bool = True):
@@ -165,6 +196,7 @@ class LstepEngine:
         self.overlap_update = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_OVERLAP") != "1"
         self._update_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
         self.slot_of = torch.full((rows,), -1, dtype=torch.int32, device=dev)
+        self.fused_loss = torch.device(dev).type == "cuda" and backbone.pe_dim % 4 == 0 and os.environ.get("LSTEP_TORCH_LOSS") != "1"
 
     # ---- shared pieces
     def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):
@@ -206,16 +238,22 @@ class LstepEngine:
         else:
             cur, spliced = self._splice(batch_nodes, batch_idx)
             n = src.numel()
-            emb = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_dst]), torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced)
+            ids3 = torch.cat([src, dst, neg_dst])
+            emb = bb.combining_pe_raw_feat(cur, ids3, torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced)
             pos_src = emb[:n]
             # both predictor calls of train:254-255 in one launch: rows [pos_src | pos_dst] and [pos_src | neg_dst] (neg_src = pos_src, train:245)
-            predicts = self._probabilities(torch.cat([pos_src, pos_src], dim=0), emb[n:])
-            labels = self._labels(n)
-            lp_loss = F.binary_cross_entropy(predicts, labels)
-            e_all = _lookup_rows(cur, spliced, torch.cat([src, dst, neg_dst]))      # one gather / one scatter for the three PE lookups
-            e_src = e_all[:n]
-            pe_loss = F.mse_loss(e_src, e_all[n:2 * n]) - self.neg_sample_weight * F.mse_loss(e_src, e_all[2 * n:])
-            loss = (1.0 - self.pe_weight) * lp_loss + self.pe_weight * pe_loss
+            if self.fused_loss:
+                logits = self.predictor(input_1=torch.cat([pos_src, pos_src], dim=0), input_2=emb[n:]).squeeze(dim=-1)
+                loss, lp_loss, pe_loss, predicts = _LinkLoss.apply(logits, spliced.rows, cur, spliced.slot_of, ids3, self.pe_weight,
+                                                                   self.neg_sample_weight)
+            else:   # the same terms with framework ops (LSTEP_TORCH_LOSS=1, the A/B switch)
+                predicts = self._probabilities(torch.cat([pos_src, pos_src], dim=0), emb[n:])
+                labels = self._labels(n)
+                lp_loss = F.binary_cross_entropy(predicts, labels)
+                e_all = _lookup_rows(cur, spliced, ids3)      # one gather / one scatter for the three PE lookups
+                e_src = e_all[:n]
+                pe_loss = F.mse_loss(e_src, e_all[n:2 * n]) - self.neg_sample_weight * F.mse_loss(e_src, e_all[2 * n:])
+                loss = (1.0 - self.pe_weight) * lp_loss + self.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
         def update_and_append():
             bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,

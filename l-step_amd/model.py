@@ -279,8 +279,7 @@ def _segment_reduce_rows(mod, num_rows: int, seg_of_entry: torch.Tensor, src_row
     out = torch.zeros((num_rows, P), dtype=torch.float32, device=dev)
     if seg_of_entry.numel() == 0:
         return out
-    keys = torch.where(seg_of_entry < 0, torch.full_like(seg_of_entry, num_rows), seg_of_entry)
-    sorted_keys, order, _, _, (_, n_hit, _) = nat.group_by_key(keys, max(1, int(num_rows + 1).bit_length()), num_rows)
+    sorted_keys, order, n_hit = nat.sort_live(seg_of_entry.contiguous(), max(1, int(num_rows).bit_length()))
     if n_hit == 0:
         return out
     # NOTE: every tensor whose address goes to the C ABI must stay referenced until the launch has been issued: a

@@ -504,3 +504,55 @@ def test_fused_adam_matches_torch_adam(hip):
     for p, q in zip(a, b):
         np.testing.assert_allclose(torch.view_as_real(q.detach()).cpu().numpy() if q.is_complex() else q.detach().cpu().numpy(),
                                    torch.view_as_real(p.detach()).cpu().numpy() if p.is_complex() else p.detach().cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_sort_live_matches_torch(hip):
+    """lstep_sort_live: drop negative keys, stable sort of the rest."""
+    from lstep_amd import _native as nat
+    g = torch.Generator().manual_seed(3)
+    for n, hi, dead in [(1, 5, 0.0), (1000, 7, 0.9), (200000, 30000, 0.95), (50000, 3, 0.0), (4096, 100, 1.0)]:
+        keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int32)
+        keys[torch.rand(n, generator=g) < dead] = -1
+        sk, order, live = nat.sort_live(keys.to(DEV), max(1, int(hi).bit_length()))
+        idx = torch.nonzero(keys >= 0).reshape(-1)
+        srt, perm = torch.sort(keys[idx].to(torch.int64), stable=True)
+        assert live == idx.numel()
+        assert torch.equal(sk[:live].cpu().to(torch.int64), srt) and torch.equal(order[:live].cpu().to(torch.int64), idx[perm])
+    sk, order, live = nat.sort_live(torch.empty(0, dtype=torch.int32, device=DEV), 4)
+    assert live == 0
+
+
+def test_link_loss_matches_framework_ops(hip):
+    """lstep_link_loss (losses, probabilities and both gradients in one launch) vs the same terms through autograd."""
+    from lstep_amd.engine import _LinkLoss
+    g = torch.Generator().manual_seed(5)
+    N, U, P, n = 500, 60, 172, 41
+    table = torch.randn(N + 1, P, generator=g).to(DEV)
+    batch_nodes = torch.randperm(N, generator=g)[:U] + 1
+    slot_of = torch.full((N + 1,), -1, dtype=torch.int32)
+    slot_of[batch_nodes] = torch.arange(U, dtype=torch.int32)
+    src = batch_nodes[torch.randint(0, U, (n,), generator=g)]
+    dst = batch_nodes[torch.randint(0, U, (n,), generator=g)]
+    neg = torch.randint(1, N + 1, (n,), generator=g)
+    neg[:5] = batch_nodes[:5]                                   # some negatives are spliced rows too
+    ids = torch.cat([src, dst, neg]).to(DEV)
+    logits0 = (4 * torch.randn(2 * n, generator=g))
+    logits0[0], logits0[n] = 40.0, -40.0                        # saturated sigmoid on both sides
+    logits0[1], logits0[n + 1] = -30.0, 30.0
+    rows0 = torch.randn(U, P, generator=g)
+    for pe_w, neg_w in [(0.5, 0.3), (0.0, 1.0), (1.0, 0.0)]:
+        la, ra = logits0.clone().to(DEV).requires_grad_(True), rows0.clone().to(DEV).requires_grad_(True)
+        loss, lp, pe, pred = _LinkLoss.apply(la, ra, table, slot_of.to(DEV), ids, pe_w, neg_w)
+        loss.backward()
+        lb, rb = logits0.clone().to(DEV).requires_grad_(True), rows0.clone().to(DEV).requires_grad_(True)
+        so = slot_of.to(DEV)[ids].long()
+        e = torch.where((so >= 0).unsqueeze(1), rb[so.clamp(min=0)], table[ids])
+        p2 = lb.sigmoid().clamp(0, 1)
+        lp2 = torch.nn.functional.binary_cross_entropy(p2, torch.cat([torch.ones(n), torch.zeros(n)]).to(DEV))
+        pe2 = torch.nn.functional.mse_loss(e[:n], e[n:2 * n]) - neg_w * torch.nn.functional.mse_loss(e[:n], e[2 * n:])
+        loss2 = (1.0 - pe_w) * lp2 + pe_w * pe2
+        loss2.backward()
+        np.testing.assert_allclose([lp.item(), pe.item(), loss.item()], [lp2.item(), pe2.item(), loss2.item()], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(pred.cpu().numpy(), p2.detach().cpu().numpy(), rtol=0, atol=1e-7)
+        np.testing.assert_allclose(la.grad.cpu().numpy(), lb.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(ra.grad.cpu().numpy(), rb.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
