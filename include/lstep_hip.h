@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 8
+#define LSTEP_ABI_VERSION 9
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -214,6 +214,22 @@ int64_t lstep_link_loss_workspace(int64_t n);
 int lstep_link_loss(const float* logits, const int64_t* ids, int64_t n, const float* table, const float* rows, const int32_t* slot_of,
                     int32_t pe_dim, float pe_weight, float neg_weight, float* predicts, float* d_logits, float* d_rows, float* losses,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Link predictor (models/modules.py:42-68, MergeLayer) over the padded embeddings emb [rows, 176] of one batch, with no
+ * concatenation materialised: for edge e < n the positive pair is (emb[pos_first + e], emb[pos_second + e]), the negative pair
+ * (emb[neg_first + e], emb[neg_second + e]) -- training: blocks src | dst | negative dst = offsets (0, n, 0, 2n); evaluation:
+ * src | dst | negative src | negative dst = (0, n, 2n, 3n).  w [176, 352] = fc1.weight re-laid as [first half | second half],
+ * each half zero-padded from 172 to 176 (rows too); b1, w2 [176] zero-padded; b2 [1].
+ * Outputs: h [2 n, 176] = relu(fc1) for the positive then the negative pairs, logits [2 n] = fc2(h). */
+int lstep_head_fwd(const float* emb, int64_t n, int64_t pos_first, int64_t pos_second, int64_t neg_first, int64_t neg_second,
+                   const float* w, const float* b1, const float* w2, const float* b2, float* h, float* logits, void* stream);
+
+/* Backward of lstep_head_fwd in the training layout (0, n, 0, 2n).  wt [352, 176] = w transposed.  Outputs: d_emb [3 n, 176] (all
+ * three row blocks: directly the grad_out of lstep_tail_bwd), d_h [2 n, 176] (pre-activation gradient) and d_hsum [n, 176] =
+ * d_h[pos] + d_h[neg], the dy operands of the weight gradient: dw[:, :176] = d_hsum^T emb[0:n], dw[:, 176:] = d_h^T emb[n:3n],
+ * db1 = column sums of d_h (lstep_linear_wgrad). */
+int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float* wt, const float* w2, float* d_emb, float* d_h,
+                   float* d_hsum, void* stream);
 
 #ifdef __cplusplus
 }

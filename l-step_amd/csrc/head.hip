@@ -1,0 +1,155 @@
+// Link predictor (models/modules.py:42-68 MergeLayer: fc2(relu(fc1(cat[a, b])))) on the embeddings of one batch, without
+// materialising any concatenation: the rows of `emb` are [src | dst | negative dst] blocks of n rows each (training, where the
+// negative source IS the source, train_LSTEP_link_prediction.py:245) or [src | dst | negative src | negative dst] (evaluation).
+//   forward : h = relu(W [emb[first + e] ; emb[second + e]] + b1) for the positive and the negative pair of edge e, logit = w2 . h + b2
+//   backward: from d_logit, the gradient of emb (all three row blocks, ready to be the dense tail's grad_out) and the dY operands
+//             of the weight gradient (lstep_linear_wgrad).
+// W is fc1.weight re-laid as [176, 352] = [first half | second half], both halves zero-padded from 172 to 176 columns / rows.
+#include "lstep_mma.h"
+
+namespace lstep {
+
+constexpr int kHd = 176, kTh = kHd / 16;   // padded embedding / hidden width
+constexpr int kHk = 2 * kHd;               // fc1 input width
+
+struct HeadParams {
+    const float* emb;       // [rows, kHd]
+    const float* w;         // [kHd, kHk]
+    const float* wt;        // [kHk, kHd]  (backward)
+    const float *b1, *w2;   // [kHd]
+    const float* d_logits;  // [2 n]       (backward)
+    float* h;               // [2 n, kHd]  hidden activations (positive pairs, then negative pairs)
+    float* logits;          // [2 n]
+    float* d_emb;           // [3 n, kHd]  (backward)
+    float* d_h;             // [2 n, kHd]  (backward) gradient of the pre-activation hidden layer
+    float* d_hsum;          // [n, kHd]    (backward) d_h[pos] + d_h[neg]: the dY operand for the shared first half
+    int64_t n;
+    int64_t first[2], second[2];   // row offsets into emb of the (positive, negative) pair's first / second half
+    const float* b2;        // [1]
+};
+
+__global__ __launch_bounds__(kBlock, 1) void head_fwd_kernel(const HeadParams p) {
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t e0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_in_block()) * 16;
+    if (e0 >= p.n) return;
+    int64_t e = e0 + i;
+    const bool live = e < p.n;
+    if (!live) e = p.n - 1;
+    const float* first[2] = {p.emb + (p.first[0] + e) * kHd + 4 * g, p.emb + (p.first[1] + e) * kHd + 4 * g};
+    const float* second[2] = {p.emb + (p.second[0] + e) * kHd + 4 * g, p.emb + (p.second[1] + e) * kHd + 4 * g};
+    const float* wl = p.w + i * kHk + 4 * g;
+
+    f32x4 h[kTh][2];
+#pragma unroll
+    for (int t = 0; t < kTh; ++t) {
+        const f32x4 bv = ldv4(p.b1 + 16 * t + 4 * g);
+        h[t][0] = bv;
+        h[t][1] = bv;
+    }
+    mma_wx<kTh, 2>(h, wl, kHk, kTh, first);
+    mma_wx<kTh, 2>(h, wl + kHd, kHk, kTh, second);
+    float dot[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < kTh; ++t) {
+        const f32x4 wv = ldv4(p.w2 + 16 * t + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                h[t][s][v] = fmaxf(h[t][s][v], 0.f);
+                dot[s] = fmaf(h[t][s][v], wv[v], dot[s]);
+            }
+            if (live) *reinterpret_cast<f32x4*>(p.h + ((int64_t)s * p.n + e) * kHd + 16 * t + 4 * g) = h[t][s];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {   // the four lane groups hold disjoint feature subsets of row i
+        float d = dot[s];
+        d += __shfl_xor(d, 16, kWave);
+        d += __shfl_xor(d, 32, kWave);
+        if (g == 0 && live) p.logits[(int64_t)s * p.n + e] = d + p.b2[0];
+    }
+}
+
+// training layout only: first[0] == first[1] (the source block), second = the destination / negative blocks
+__global__ __launch_bounds__(kBlock, 1) void head_bwd_kernel(const HeadParams p) {
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t e0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave_in_block()) * 16;
+    if (e0 >= p.n) return;
+    int64_t e = e0 + i;
+    const bool live = e < p.n;
+    if (!live) e = p.n - 1;
+    const float dl[2] = {p.d_logits[e], p.d_logits[p.n + e]};
+
+    f32x4 dh[kTh][2], dsum[kTh][1];
+#pragma unroll
+    for (int t = 0; t < kTh; ++t) {
+        const f32x4 wv = ldv4(p.w2 + 16 * t + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 hv = ldv4(p.h + ((int64_t)s * p.n + e) * kHd + 16 * t + 4 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dh[t][s][v] = hv[v] > 0.f ? dl[s] * wv[v] : 0.f;
+            if (live) *reinterpret_cast<f32x4*>(p.d_h + ((int64_t)s * p.n + e) * kHd + 16 * t + 4 * g) = dh[t][s];
+        }
+        dsum[t][0] = dh[t][0] + dh[t][1];
+        if (live) *reinterpret_cast<f32x4*>(p.d_hsum + e * kHd + 16 * t + 4 * g) = dsum[t][0];
+    }
+    const float* wtl = p.wt + i * kHd + 4 * g;
+    {   // d emb[src] = Wt[first-half rows] (d_h[pos] + d_h[neg])
+        f32x4 d[kTh][1];
+#pragma unroll
+        for (int t = 0; t < kTh; ++t) d[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mma_wr<kTh, 1, kTh>(d, wtl, kHd, dsum);
+#pragma unroll
+        for (int t = 0; t < kTh; ++t)
+            if (live) *reinterpret_cast<f32x4*>(p.d_emb + (p.first[0] + e) * kHd + 16 * t + 4 * g) = d[t][0];
+    }
+    {   // d emb[dst], d emb[neg] = Wt[second-half rows] d_h[pos / neg]
+        f32x4 d[kTh][2];
+#pragma unroll
+        for (int t = 0; t < kTh; ++t) {
+            d[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            d[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        mma_wr<kTh, 2, kTh>(d, wtl + (size_t)kHd * kHd, kHd, dh);
+#pragma unroll
+        for (int t = 0; t < kTh; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (live) *reinterpret_cast<f32x4*>(p.d_emb + (p.second[s] + e) * kHd + 16 * t + 4 * g) = d[t][s];
+        }
+    }
+}
+
+}  // namespace lstep
+
+using namespace lstep;
+
+extern "C" int lstep_head_fwd(const float* emb, int64_t n, int64_t pos_first, int64_t pos_second, int64_t neg_first, int64_t neg_second,
+                              const float* w, const float* b1, const float* w2, const float* b2, float* h, float* logits, void* stream) {
+    if (n < 0 || pos_first < 0 || pos_second < 0 || neg_first < 0 || neg_second < 0) return set_error(LSTEP_EINVAL, "lstep_head_fwd: bad sizes");
+    if (n == 0) return LSTEP_OK;
+    if (!emb || !w || !b1 || !w2 || !b2 || !h || !logits) return set_error(LSTEP_EINVAL, "lstep_head_fwd: NULL pointer");
+    HeadParams p{};
+    p.emb = emb; p.w = w; p.b1 = b1; p.w2 = w2; p.h = h; p.logits = logits; p.n = n; p.b2 = b2;
+    p.first[0] = pos_first; p.first[1] = neg_first; p.second[0] = pos_second; p.second[1] = neg_second;
+    const int64_t tasks = (n + 15) / 16;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, p);
+    return check_launch("lstep_head_fwd");
+}
+
+extern "C" int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float* wt, const float* w2, float* d_emb, float* d_h,
+                              float* d_hsum, void* stream) {
+    if (n < 0) return set_error(LSTEP_EINVAL, "lstep_head_bwd: bad sizes");
+    if (n == 0) return LSTEP_OK;
+    if (!d_logits || !h || !wt || !w2 || !d_emb || !d_h || !d_hsum) return set_error(LSTEP_EINVAL, "lstep_head_bwd: NULL pointer");
+    HeadParams p{};
+    p.d_logits = d_logits; p.h = const_cast<float*>(h); p.wt = wt; p.w2 = w2; p.d_emb = d_emb; p.d_h = d_h; p.d_hsum = d_hsum; p.n = n;
+    p.first[0] = p.first[1] = 0; p.second[0] = n; p.second[1] = 2 * n;
+    const int64_t tasks = (n + 15) / 16;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, p);
+    return check_launch("lstep_head_bwd");
+}

@@ -1,0 +1,91 @@
+// fp32 matrix-core building blocks shared by the dense kernels (tail.hip, head.hip): every product is formed TRANSPOSED,
+// Y^T = W X^T with v_mfma_f32_16x16x4_f32, a wave owning S slabs of 16 activation rows.
+//   * operands straight from row-major memory: lane l = (i = l & 15, g = l >> 4) loads the float4 W[n0 + i][k0 + 4g .. +3] and
+//     X[r0 + i][k0 + 4g .. +3]; component v of both is the (A, B) pair of the MFMA that contracts k in {k0 + 4g' + v}; four MFMAs
+//     cover the 16-wide k chunk, in a permuted but consistent k order.  No LDS, no transposes.
+//   * an accumulator tile IS the next product's B operand: the C/D layout puts feature 16t + 4g + v of row i in register v of
+//     lane (i, g) -- exactly the B element the MFMA "v" above wants for k = 16t + 4g + v.
+#pragma once
+
+#include "lstep_common.h"
+
+namespace lstep {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// One 16-wide k chunk of operands: A tiles (weights) and B slabs (activation rows), one float4 per lane each.
+template <int T, int S>
+struct Chunk {
+    f32x4 a[T];
+    f32x4 b[S];
+};
+
+// acc[t][s] += sum_k W[16 t + i][k] * X_s[row][k]  over `chunks` 16-wide k chunks.
+//   wl = W + this lane's (i * ldw + 4 g) (already offset to the first tile / first k);  xl[s] = X + row_s * ldx + 4 g + first k.
+// Double-buffered by hand: the loads of chunk c + 1 are issued before the MFMAs of chunk c (the sched barriers keep them
+// there); one chunk is T * S * 4 MFMAs = 128 T S cycles, enough to cover an L2 hit and most HBM misses.
+template <int T, int S>
+__device__ __forceinline__ void mma_wx(f32x4 (*acc)[S], const float* wl, int ldw, int chunks, const float* const (&xl)[S]) {
+    auto load = [&](Chunk<T, S>& o, int c) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) o.b[s] = ldv4(xl[s] + 16 * c);
+#pragma unroll
+        for (int t = 0; t < T; ++t) o.a[t] = ldv4(wl + (size_t)16 * t * ldw + 16 * c);
+    };
+    auto run = [&](const Chunk<T, S>& o) {
+        // v outermost: back-to-back MFMAs on one accumulator would pay the 40-cycle dependent latency instead of the 32-cycle issue
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[t][s] = mfma4(o.a[t][v], o.b[s][v], acc[t][s]);
+            }
+        }
+    };
+    Chunk<T, S> c0, c1;
+    load(c0, 0);
+    for (int c = 0; c < chunks; c += 2) {
+        const bool two = c + 1 < chunks;   // uniform
+        if (two) load(c1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(c0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) {
+            if (c + 2 < chunks) load(c0, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            run(c1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// acc[t][s] += sum over the TK register tiles r[tk][s] (16 features each) of W[16 t + i][16 tk + k] * r
+template <int T, int S, int TK>
+__device__ __forceinline__ void mma_wr(f32x4 (*acc)[S], const float* wl, int ldw, const f32x4 (*r)[S]) {
+    f32x4 a[2][T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) a[0][t] = ldv4(wl + (size_t)16 * t * ldw);
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk) {
+        if (tk + 1 < TK) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[(tk + 1) & 1][t] = ldv4(wl + (size_t)16 * t * ldw + 16 * (tk + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[t][s] = mfma4(a[tk & 1][t][v], r[tk][s][v], acc[t][s]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+}  // namespace lstep

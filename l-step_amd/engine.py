@@ -239,11 +239,15 @@ class LstepEngine:
             cur, spliced = self._splice(batch_nodes, batch_idx)
             n = src.numel()
             ids3 = torch.cat([src, dst, neg_dst])
-            emb = bb.combining_pe_raw_feat(cur, ids3, torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced)
+            emb_p = bb.combining_pe_raw_feat(cur, ids3, torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced, padded=True)
+            emb = emb_p[:, :bb.feat_dim]
             pos_src = emb[:n]
             # both predictor calls of train:254-255 in one launch: rows [pos_src | pos_dst] and [pos_src | neg_dst] (neg_src = pos_src, train:245)
             if self.fused_loss:
-                logits = self.predictor(input_1=torch.cat([pos_src, pos_src], dim=0), input_2=emb[n:]).squeeze(dim=-1)
+                if self.predictor.fused_ok(emb_p):
+                    logits = self.predictor.pair_logits(emb_p, n, (0, n, 0, 2 * n))
+                else:
+                    logits = self.predictor(input_1=torch.cat([pos_src, pos_src], dim=0), input_2=emb[n:]).squeeze(dim=-1)
                 loss, lp_loss, pe_loss, predicts = _LinkLoss.apply(logits, spliced.rows, cur, spliced.slot_of, ids3, self.pe_weight,
                                                                    self.neg_sample_weight)
             else:   # the same terms with framework ops (LSTEP_TORCH_LOSS=1, the A/B switch)

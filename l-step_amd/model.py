@@ -215,6 +215,55 @@ class _FusedTail(torch.autograd.Function):
         return d_xe, d_xp, None, d_own, gW1, gb1, gWn1, gbn1, gWq, gbq, gWall, gconst
 
 
+class _Head(torch.autograd.Function):
+    """Link predictor over the padded embeddings of a batch (``lstep_head_fwd`` / ``lstep_head_bwd``): fc1 -> relu -> fc2 for the
+    positive and the negative pair of every edge, straight from the [src | dst | negative] row blocks (no ``torch.cat``), and a
+    backward that returns the gradient of all three blocks in one [3 n, 176] tensor."""
+
+    @staticmethod
+    def forward(ctx, emb, fc1_w, fc1_b, fc2_w, fc2_b, n, layout):
+        lib = nat.load_library()
+        dev = emb.device
+        half = fc1_w.shape[1] // 2                      # 172
+        Hd = emb.shape[1]                               # 176
+        flat = torch.zeros(Hd * 2 * Hd + 2 * Hd, dtype=torch.float32, device=dev)
+        wp, b1p, w2p = flat[:Hd * 2 * Hd].view(Hd, 2 * Hd), flat[Hd * 2 * Hd:Hd * 2 * Hd + Hd], flat[Hd * 2 * Hd + Hd:]
+        wp[:half, :half] = fc1_w[:, :half]
+        wp[:half, Hd:Hd + half] = fc1_w[:, half:]
+        b1p[:half] = fc1_b
+        w2p[:half] = fc2_w[0]
+        b2 = fc2_b.contiguous()
+        h = torch.empty((2 * n, Hd), dtype=torch.float32, device=dev)
+        logits = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_head_fwd(nat.ptr(emb), n, *layout, nat.ptr(wp), nat.ptr(b1p), nat.ptr(w2p), nat.ptr(b2), nat.ptr(h),
+                                         nat.ptr(logits), nat.current_stream()))
+        ctx.save_for_backward(emb, wp, w2p, h)
+        ctx.n, ctx.half, ctx.layout = n, half, tuple(layout)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        lib = nat.load_library()
+        emb, wp, w2p, h = ctx.saved_tensors
+        n, half, Hd, dev = ctx.n, ctx.half, emb.shape[1], emb.device
+        if ctx.layout != (0, n, 0, 2 * n):
+            raise NotImplementedError("lstep_head_bwd implements the training layout (src | dst | negative dst)")
+        d_logits = d_logits.contiguous()
+        wt = wp.t().contiguous()
+        d_emb = torch.empty((3 * n, Hd), dtype=torch.float32, device=dev)
+        d_h = torch.empty((2 * n, Hd), dtype=torch.float32, device=dev)
+        d_hsum = torch.empty((n, Hd), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_head_bwd(nat.ptr(d_logits), nat.ptr(h), n, nat.ptr(wt), nat.ptr(w2p), nat.ptr(d_emb), nat.ptr(d_h),
+                                         nat.ptr(d_hsum), nat.current_stream()))
+        g_first, _ = nat.linear_wgrad(d_hsum, emb[:n], want_bias=False)
+        g_second, g_b1 = nat.linear_wgrad(d_h, emb[n:3 * n])
+        g_fc1 = torch.cat([g_first[:half, :half], g_second[:half, :half]], dim=1)
+        g_w2 = (d_logits @ h)[:half].reshape(1, half)
+        return d_emb, g_fc1, g_b1[:half], g_w2, d_logits.sum().reshape(1), None, None
+
+
 # ------------------------------------------------------------------------------------------------ small modules
 class TimeEncoder(nn.Module):
     """``cos(t * w + b)``; same parameters as reference ``models/modules.py:7-39``."""
@@ -251,6 +300,16 @@ class MergeLayer(nn.Module):
         self.fc1 = nn.Linear(input_dim1 + input_dim2, hidden_dim)
         self.fc2 = nn.Linear(hidden_dim, output_dim)
         self.act = nn.ReLU()
+
+    def pair_logits(self, emb: torch.Tensor, n: int, layout):
+        """fc2(relu(fc1(cat[a, b]))) for the positive and the negative pair of every edge, read straight from the row blocks of the
+        padded embeddings ``emb`` [rows, 176] (``lstep_head_fwd``); ``layout`` = row offsets (pos_first, pos_second, neg_first,
+        neg_second).  Returns the 2 n logits (positive pairs first)."""
+        return _Head.apply(emb, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, int(n), tuple(int(x) for x in layout))
+
+    def fused_ok(self, emb: torch.Tensor) -> bool:
+        return (emb.is_cuda and emb.shape[1] == 176 and tuple(self.fc1.weight.shape) == (172, 344) and tuple(self.fc2.weight.shape) == (1, 172)
+                and os.environ.get("LSTEP_TORCH_HEAD") != "1")
 
     def forward(self, input_1: torch.Tensor, input_2: torch.Tensor):
         return self.fc2(fast_linear(torch.cat([input_1, input_2], dim=1), self.fc1.weight, self.fc1.bias, relu=True))
@@ -605,11 +664,13 @@ class LSTEP(nn.Module):
 
     # ---- O (models/LSTEP.py:251-266): one fused gather launch serves A, N and C
     def combining_pe_raw_feat(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, time_gap: int = 2000, testing=False,
-                              spliced: SplicedRows = None):
+                              spliced: SplicedRows = None, padded: bool = False):
         fused = self._fused_tail_ok()
         x_edge, x_node, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, time_gap,
                                                     nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced, wide=fused)
-        return self._combined_tail(x_edge, x_node, x_pe, own, fused)
+        out = self._combined_tail(x_edge, x_node, x_pe, own, fused)
+        # padded: the [B, 176] rows the kernels work on (columns >= 172 are 0), for lstep_head_fwd; default: the reference's [B, 172]
+        return out if padded else out[:, :self.feat_dim]
 
     def _fused_tail_ok(self) -> bool:
         """The single-launch tail is compiled for the default widths (feature / PE dim 172, time dim 100); other shapes (and
@@ -638,11 +699,11 @@ class LSTEP(nn.Module):
             self.out_node_emb.bias, self.self_update_neighbor_pe.weight, self.self_update_neighbor_pe.bias,
             self.pe_neighbor_mlp_1.weight, self.pe_neighbor_mlp_1.bias, self.pe_neighbor_mlp_2.weight, self.pe_neighbor_mlp_2.bias)
         if fused:   # x_node / own are the wide [x_node | h1 | q] / [own | p1] buffers of the gather stage
-            return _FusedTail.apply(x_edge, x_pe, x_node, own, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp)[:, :Fd]
+            return _FusedTail.apply(x_edge, x_pe, x_node, own, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp)
         h1 = fast_linear(x_edge, W1p, b1p, relu=True)                                          # [B, Ce]
         p1 = fast_linear(x_pe, Wn1p, bn1p, relu=True)                                          # [B, Pp]
         q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), Wq, bq))                # [B, Pp]
-        return fast_linear(torch.cat([x_node, h1, q], dim=-1), Wall, constp)[:, :Fd]
+        return fast_linear(torch.cat([x_node, h1, q], dim=-1), Wall, constp)
 
     def compute_src_dst_node_temporal_embeddings(self, pe, src_node_ids, dst_node_ids, node_interact_times, num_neighbors: int = 20,
                                                  time_gap: int = 2000, spliced: SplicedRows = None):

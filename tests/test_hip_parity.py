@@ -556,3 +556,36 @@ def test_link_loss_matches_framework_ops(hip):
         np.testing.assert_allclose(pred.cpu().numpy(), p2.detach().cpu().numpy(), rtol=0, atol=1e-7)
         np.testing.assert_allclose(la.grad.cpu().numpy(), lb.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose(ra.grad.cpu().numpy(), rb.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("n", [16384 // 64, 41, 1])
+def test_head_matches_merge_layer(hip, n):
+    """lstep_head_fwd / lstep_head_bwd (link predictor straight from the row blocks of the padded embeddings) vs MergeLayer on
+    concatenated inputs, forward and every gradient; evaluation layout forward-only."""
+    from lstep_amd.model import MergeLayer
+    torch.manual_seed(11)
+    ml = MergeLayer(172, 172, 172, 1).to(DEV)
+    emb = torch.zeros(4 * n, 176, device=DEV)
+    emb[:, :172] = torch.randn(4 * n, 172, device=DEV)
+    # training layout: src | dst | neg
+    a = emb[:3 * n].clone().requires_grad_(True)
+    logits = ml.pair_logits(a, n, (0, n, 0, 2 * n))
+    w = torch.randn(2 * n, device=DEV)
+    (logits * w).sum().backward()
+    got = [a.grad.clone()] + [p.grad.clone() for p in ml.parameters()]
+    ml.zero_grad()
+    b = emb[:3 * n, :172].clone().requires_grad_(True)
+    ref = ml(torch.cat([b[:n], b[:n]]), b[n:]).squeeze(-1)
+    (ref * w).sum().backward()
+    want = [b.grad.clone()] + [p.grad.clone() for p in ml.parameters()]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got[0][:, :172].cpu().numpy(), want[0].cpu().numpy(), rtol=0, atol=2e-5)
+    assert float(got[0][:, 172:].abs().max()) == 0.0
+    for g_, w_ in zip(got[1:], want[1:]):
+        np.testing.assert_allclose(g_.cpu().numpy(), w_.cpu().numpy(), rtol=1e-4, atol=2e-4 * max(1.0, n / 64))
+    # evaluation layout: src | dst | neg_src | neg_dst
+    with torch.no_grad():
+        le = ml.pair_logits(emb, n, (0, n, 2 * n, 3 * n))
+        e = emb[:, :172]
+        re = torch.cat([ml(e[:n], e[n:2 * n]), ml(e[2 * n:3 * n], e[3 * n:])]).squeeze(-1)
+    np.testing.assert_allclose(le.cpu().numpy(), re.cpu().numpy(), rtol=0, atol=2e-5)
