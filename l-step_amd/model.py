@@ -782,17 +782,31 @@ class LSTEP(nn.Module):
     def _update_mlp(self, agg):
         """pe_mlp_2(relu(pe_mlp_1(agg))) on row-padded operands -> [n, ld_self] (padding columns 0).
         ``agg`` may carry extra bucket rows (see ``_bucket_rows``); they are computed and ignored."""
-        Cp, Pp = self.ld_pe, self.ld_self
-        w1, b1 = _pad2(self.pe_mlp_1.weight, Pp, Cp), _pad1(self.pe_mlp_1.bias, Pp)
-        w2, b2 = _pad2(self.pe_mlp_2.weight, Pp, Pp), _pad1(self.pe_mlp_2.bias, Pp)
+        w1t, b1, w2t, b2 = self._update_weights()
+        Pp = self.ld_self
         n, blk = agg.shape[0], self.MLP_ROW_BLOCK
-        w1t, w2t = w1.t(), w2.t()
         if n <= blk:
             return torch.addmm(b2, _addmm_relu(b1, agg, w1t), w2t)                     # relu runs in the GEMM epilogue
         out = torch.empty((n, Pp), dtype=torch.float32, device=agg.device)
         for i in range(0, n, blk):
             torch.addmm(b2, _addmm_relu(b1, agg[i:i + blk], w1t), w2t, out=out[i:i + blk])
         return out
+
+    def _padded_cached(self, name: str, params, build):
+        """Padded copies of forward-only weights (no gradient ever reaches the update_pe layers, so they only change when the user
+        loads or edits them): rebuilt when any source tensor's version counter or storage changed."""
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.setdefault("_pad_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = cache[name] = (key, build())
+        return hit[1]
+
+    def _update_weights(self):
+        Cp, Pp = self.ld_pe, self.ld_self
+        m1, m2 = self.pe_mlp_1, self.pe_mlp_2
+        return self._padded_cached("update_mlp", (m1.weight, m1.bias, m2.weight, m2.bias), lambda: (
+            _pad2(m1.weight.detach(), Pp, Cp).t(), _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).t(), _pad1(m2.bias.detach(), Pp)))
 
     @classmethod
     def _bucket_rows(cls, n: int) -> int:
@@ -854,7 +868,10 @@ class LSTEP(nn.Module):
         own = torch.zeros((agg.shape[0], self.pe_dim), dtype=torch.float32, device=pe.device)
         own[:n] = pe[ids]
         Pp = self.ld_self
-        z = F.linear(own, _pad2(self.self_update_pe.weight, Pp, self.pe_dim), _pad1(self.self_update_pe.bias, Pp)) + self._update_mlp(agg)
+        su = self.self_update_pe
+        ws, bs = self._padded_cached("self_update", (su.weight, su.bias),
+                                     lambda: (_pad2(su.weight.detach(), Pp, self.pe_dim), _pad1(su.bias.detach(), Pp)))
+        z = F.linear(own, ws, bs) + self._update_mlp(agg)
         return ids, z[:n]
 
     @torch.no_grad()
