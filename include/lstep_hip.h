@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 9
+#define LSTEP_ABI_VERSION 11
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -131,12 +131,13 @@ int lstep_history_filter_bwd(const float* hist, int64_t node_stride, int64_t tim
  *   out[s, W:W+D] = sum_e cos(ent_dt[e] * time_w + time_b)            (time_dim D may be 0: no time part, ent_dt unused)
  * `out` (row stride ld_out) MUST be zero-initialised by the caller: rows that own no entry stay zero, and a segment that
  * straddles a 64-entry chunk boundary is accumulated with float atomics (long segments = hub nodes); all other
- * segments are plain stores summed in entry order (deterministic).  Uses:
+ * segments are plain stores summed in entry order (deterministic).  accumulate != 0: the sums are ADDED to what `out`
+ * already holds (a second reduction into the same rows, e.g. neighbour + self gradients).  Uses:
  *   update_pe U1/U2 (models/LSTEP.py:282-290, 319-322) with table = pe, D = time dim: replaces both dense [N+1, P+D]
  *   torch_scatter targets;  gather backward: table = grad of the PE aggregate, D = 0, segment = spliced PE row. */
 int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
                            int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
-                           int64_t num_entries, float* out, int32_t ld_out, void* stream);
+                           int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, void* stream);
 
 /* In-place row write pe[ids[i], :] = rows[i, :] (models/LSTEP.py:303,339). ids must be unique. */
 int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* rows,
@@ -227,9 +228,18 @@ int lstep_head_fwd(const float* emb, int64_t n, int64_t pos_first, int64_t pos_s
 /* Backward of lstep_head_fwd in the training layout (0, n, 0, 2n).  wt [352, 176] = w transposed.  Outputs: d_emb [3 n, 176] (all
  * three row blocks: directly the grad_out of lstep_tail_bwd), d_h [2 n, 176] (pre-activation gradient) and d_hsum [n, 176] =
  * d_h[pos] + d_h[neg], the dy operands of the weight gradient: dw[:, :176] = d_hsum^T emb[0:n], dw[:, 176:] = d_h^T emb[n:3n],
- * db1 = column sums of d_h (lstep_linear_wgrad). */
+ * db1 = column sums of d_h (lstep_linear_wgrad); dw2_partial [ceil(n / 16), 176]: per-slab partial sums of d_logit * h, whose column
+ * sums are the gradient of fc2.weight. */
 int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float* wt, const float* w2, float* d_emb, float* d_h,
-                   float* d_hsum, void* stream);
+                   float* d_hsum, float* dw2_partial, void* stream);
+
+/* U1 / U2 -- the dense end of update_pe in one launch (models/LSTEP.py:292-303, 327-339), default widths (pe_dim <= 176, time dim
+ * such that pe_dim + time_dim = 272):  z = w2 relu(w1 agg[r] + b1) + b2 (+ ws table[ids[r]] + bs when ws != NULL: phase 1;
+ * phase 2 passes NULL, the reference discards that term), then IN PLACE table[ids[r], :] += tanh(z).
+ * agg [>= n, ld_agg] = the segment sums of lstep_segment_rows_sum; ids int64 [n], unique; weights zero-padded to
+ * w1 [176, 272], w2 / ws [176, 176], biases [176]. */
+int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* ws, const float* bs, float* table, int32_t pe_dim, void* stream);
 
 #ifdef __cplusplus
 }

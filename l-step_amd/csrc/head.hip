@@ -23,6 +23,7 @@ struct HeadParams {
     float* d_emb;           // [3 n, kHd]  (backward)
     float* d_h;             // [2 n, kHd]  (backward) gradient of the pre-activation hidden layer
     float* d_hsum;          // [n, kHd]    (backward) d_h[pos] + d_h[neg]: the dY operand for the shared first half
+    float* dw2_part;        // [waves, kHd] (backward) per-wave partial sums of d_logit * h (the fc2 weight gradient)
     int64_t n;
     int64_t first[2], second[2];   // row offsets into emb of the (positive, negative) pair's first / second half
     const float* b2;        // [1]
@@ -83,17 +84,29 @@ __global__ __launch_bounds__(kBlock, 1) void head_bwd_kernel(const HeadParams p)
     if (!live) e = p.n - 1;
     const float dl[2] = {p.d_logits[e], p.d_logits[p.n + e]};
 
+    const int64_t wave_id = e0 / 16;
     f32x4 dh[kTh][2], dsum[kTh][1];
 #pragma unroll
     for (int t = 0; t < kTh; ++t) {
         const f32x4 wv = ldv4(p.w2 + 16 * t + 4 * g);
+        f32x4 gw = f32x4{0.f, 0.f, 0.f, 0.f};   // this row's share of d fc2.weight = sum over rows of d_logit * h
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const f32x4 hv = ldv4(p.h + ((int64_t)s * p.n + e) * kHd + 16 * t + 4 * g);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) dh[t][s][v] = hv[v] > 0.f ? dl[s] * wv[v] : 0.f;
+            for (int v = 0; v < 4; ++v) {
+                dh[t][s][v] = hv[v] > 0.f ? dl[s] * wv[v] : 0.f;
+                if (live) gw[v] = fmaf(dl[s], hv[v], gw[v]);
+            }
             if (live) *reinterpret_cast<f32x4*>(p.d_h + ((int64_t)s * p.n + e) * kHd + 16 * t + 4 * g) = dh[t][s];
         }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {   // sum over the 16 rows of the slab (lanes with equal g)
+            float x = gw[v];
+            x += __shfl_xor(x, 1, kWave); x += __shfl_xor(x, 2, kWave); x += __shfl_xor(x, 4, kWave); x += __shfl_xor(x, 8, kWave);
+            gw[v] = x;
+        }
+        if (i == 0) *reinterpret_cast<f32x4*>(p.dw2_part + wave_id * kHd + 16 * t + 4 * g) = gw;
         dsum[t][0] = dh[t][0] + dh[t][1];
         if (live) *reinterpret_cast<f32x4*>(p.d_hsum + e * kHd + 16 * t + 4 * g) = dsum[t][0];
     }
@@ -142,12 +155,12 @@ extern "C" int lstep_head_fwd(const float* emb, int64_t n, int64_t pos_first, in
 }
 
 extern "C" int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float* wt, const float* w2, float* d_emb, float* d_h,
-                              float* d_hsum, void* stream) {
+                              float* d_hsum, float* dw2_partial, void* stream) {
     if (n < 0) return set_error(LSTEP_EINVAL, "lstep_head_bwd: bad sizes");
     if (n == 0) return LSTEP_OK;
-    if (!d_logits || !h || !wt || !w2 || !d_emb || !d_h || !d_hsum) return set_error(LSTEP_EINVAL, "lstep_head_bwd: NULL pointer");
+    if (!d_logits || !h || !wt || !w2 || !d_emb || !d_h || !d_hsum || !dw2_partial) return set_error(LSTEP_EINVAL, "lstep_head_bwd: NULL pointer");
     HeadParams p{};
-    p.d_logits = d_logits; p.h = const_cast<float*>(h); p.wt = wt; p.w2 = w2; p.d_emb = d_emb; p.d_h = d_h; p.d_hsum = d_hsum; p.n = n;
+    p.d_logits = d_logits; p.h = const_cast<float*>(h); p.wt = wt; p.w2 = w2; p.d_emb = d_emb; p.d_h = d_h; p.d_hsum = d_hsum; p.dw2_part = dw2_partial; p.n = n;
     p.first[0] = p.first[1] = 0; p.second[0] = n; p.second[1] = 2 * n;
     const int64_t tasks = (n + 15) / 16;
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, p);

@@ -12,9 +12,16 @@ constexpr int kChunk = 64;   // entries per wave: bounds the work of one wave wh
 // flush one run of a segment: plain store when this chunk holds the whole segment, float atomics (contiguous dwords
 // per wave-instruction) when the segment is split over several chunks (long segments = hub nodes)
 __device__ __forceinline__ void flush_run(float* __restrict__ o, const float4& acc, float t0, float t1, int W, int D, bool whole,
-                                          int lane) {
+                                          bool accumulate, int lane) {
     const bool wa = lane < (W >> 2);
-    if (whole) {
+    if (whole && accumulate) {   // this wave is the only writer of the row: plain read-modify-write
+        if (wa) {
+            const float4 old = ld4(o + lane * 4);
+            st4(o + lane * 4, make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w));
+        }
+        if (lane < D) o[W + lane] += t0;
+        if (lane + kWave < D) o[W + lane + kWave] += t1;
+    } else if (whole) {
         if (wa) st4(o + lane * 4, acc);
         if (lane < D) o[W + lane] = t0;
         if (lane + kWave < D) o[W + lane + kWave] = t1;
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                                                                    const float* __restrict__ tw, const float* __restrict__ tb, int D,
                                                                    const int32_t* __restrict__ ent_seg, const int32_t* __restrict__ ent_row,
                                                                    const float* __restrict__ ent_dt, int64_t num_entries,
-                                                                   float* __restrict__ out, int ld_out) {
+                                                                   float* __restrict__ out, int ld_out, bool accumulate) {
     const int lane = lane_id();
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t e0 = chunk * kChunk;
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                 if ((j + u) >= m) break;
                 const int sj = bcast_i32(sg, j + u);
                 if (sj != cur) {
-                    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, lane);
+                    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane);
                     cur = sj;
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     t0 = t1 = 0.f;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
             }
         }
     }
-    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, lane);
+    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane);
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(float* __restrict__ table, int W, const int64_t* __restrict__ ids,
@@ -122,7 +129,7 @@ using namespace lstep;
 
 extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
                                       int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
-                                      int64_t num_entries, float* out, int32_t ld_out, void* stream) {
+                                      int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, void* stream) {
     if (num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: negative count");
     if (num_entries == 0) return LSTEP_OK;
     if (ld_table == 0) ld_table = width;
@@ -135,7 +142,7 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate != 0);
     return check_launch("segment_rows_sum_kernel");
 }
 

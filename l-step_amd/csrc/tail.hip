@@ -286,6 +286,97 @@ __global__ __launch_bounds__(kBlock, 1) void tail_bwd_kernel(const TailBwdParams
     }
 }
 
+// ---- update_pe: z = pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(own)], table[id] += tanh(z)  (models/LSTEP.py:292-303, 327-339) ----
+struct UpdateParams {
+    const float* agg;      // [>= n, ld_agg]  aggregated messages cat[pe, time] (kCe used)
+    const int64_t* ids;    // [n] rows of the table to update (unique)
+    const float *w1, *b1, *w2, *b2;   // [176, 272], [176], [176, 176], [176]   (zero-padded)
+    const float *ws, *bs;  // [176, 176], [176] self_update_pe, or NULL (phase 2: the term is dead code in the reference)
+    float* table;          // [N + 1, pe_dim]
+    int64_t n;
+    int32_t ld_agg, pe_dim;
+};
+
+template <int S>
+__global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(const UpdateParams p) {
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    const int64_t r0 = task * (16 * S);
+    if (r0 >= p.n) return;   // no barriers in this kernel
+    bool live[S];
+    const float *agg_l[S], *own_l[S];
+    float* own_row[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        int64_t r = r0 + 16 * s + i;
+        live[s] = r < p.n;
+        if (!live[s]) r = p.n - 1;
+        agg_l[s] = p.agg + r * p.ld_agg + 4 * g;
+        own_row[s] = p.table + p.ids[r] * p.pe_dim;
+        own_l[s] = own_row[s] + 4 * g;
+    }
+    auto wlane = [&](const float* w, int ldw) { return w + i * ldw + 4 * g; };
+    f32x4 h[kTp][S], z[kTp][S];
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+        const f32x4 b1v = ldv4(p.b1 + 16 * t + 4 * g);
+        f32x4 b2v = ldv4(p.b2 + 16 * t + 4 * g);
+        if (p.ws != nullptr) b2v += ldv4(p.bs + 16 * t + 4 * g);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            h[t][s] = b1v;
+            z[t][s] = b2v;
+        }
+    }
+    mma_wx<kTp, S>(h, wlane(p.w1, kCe), kCe, kTe, agg_l);
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) h[t][s][v] = fmaxf(h[t][s][v], 0.f);
+        }
+    }
+    mma_wr<kTp, S, kTp>(z, wlane(p.w2, kPp), kPp, h);
+    if (p.ws != nullptr) {
+        // own rows straight from the table: pe_dim = 172 columns, so the last lane group of the last chunk would read past the
+        // row.  Those lanes re-read the row start instead: the padded weight columns they meet are zero.
+        const int last = (p.pe_dim + 15) / 16 - 1;
+        for (int c = 0; c <= last; ++c) {
+            f32x4 a[kTp], b[S];
+            const bool ok = 16 * c + 4 * g + 4 <= p.pe_dim;
+#pragma unroll
+            for (int s = 0; s < S; ++s) b[s] = ldv4(ok ? own_l[s] + 16 * c : own_row[s]);
+#pragma unroll
+            for (int t = 0; t < kTp; ++t) a[t] = ldv4(wlane(p.ws, kPp) + (size_t)16 * t * kPp + 16 * c);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) z[t][s] = mfma4(a[t][v], b[s][v], z[t][s]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+        const int f = 16 * t + 4 * g;
+        if (f + 4 <= p.pe_dim) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (live[s]) {
+                    f32x4 old = ldv4(own_row[s] + f);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) old[v] += tanhf(z[t][s][v]);
+                    *reinterpret_cast<f32x4*>(own_row[s] + f) = old;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace lstep
 
 using namespace lstep;
@@ -342,4 +433,20 @@ extern "C" int lstep_tail_bwd(const float* grad_out, const float* cat1, const fl
     else if (S == 2) hipLaunchKernelGGL(tail_bwd_kernel<2>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(tail_bwd_kernel<3>, grid, block, 0, s, p);
     return check_launch("lstep_tail_bwd");
+}
+
+extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, const float* ws, const float* bs, float* table, int32_t pe_dim, void* stream) {
+    if (n < 0 || ld_agg < kCe || (ld_agg & 3) || pe_dim <= 0 || pe_dim > kPp || (pe_dim & 3)) return set_error(LSTEP_EINVAL, "lstep_update_rows: bad sizes");
+    if (n == 0) return LSTEP_OK;
+    if (!agg || !ids || !w1 || !b1 || !w2 || !b2 || !table || (ws && !bs)) return set_error(LSTEP_EINVAL, "lstep_update_rows: NULL pointer");
+    UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, n, ld_agg, pe_dim};
+    const int S = tail_slabs_per_wave(n);
+    const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
+    const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (S == 1) hipLaunchKernelGGL(update_rows_kernel<1>, grid, block, 0, s, p);
+    else if (S == 2) hipLaunchKernelGGL(update_rows_kernel<2>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(update_rows_kernel<3>, grid, block, 0, s, p);
+    return check_launch("lstep_update_rows");
 }

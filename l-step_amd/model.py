@@ -254,13 +254,14 @@ class _Head(torch.autograd.Function):
         d_emb = torch.empty((3 * n, Hd), dtype=torch.float32, device=dev)
         d_h = torch.empty((2 * n, Hd), dtype=torch.float32, device=dev)
         d_hsum = torch.empty((n, Hd), dtype=torch.float32, device=dev)
+        dw2_part = torch.empty(((n + 15) // 16, Hd), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             nat.check(lib.lstep_head_bwd(nat.ptr(d_logits), nat.ptr(h), n, nat.ptr(wt), nat.ptr(w2p), nat.ptr(d_emb), nat.ptr(d_h),
-                                         nat.ptr(d_hsum), nat.current_stream()))
+                                         nat.ptr(d_hsum), nat.ptr(dw2_part), nat.current_stream()))
         g_first, _ = nat.linear_wgrad(d_hsum, emb[:n], want_bias=False)
         g_second, g_b1 = nat.linear_wgrad(d_h, emb[n:3 * n])
         g_fc1 = torch.cat([g_first[:half, :half], g_second[:half, :half]], dim=1)
-        g_w2 = (d_logits @ h)[:half].reshape(1, half)
+        g_w2 = dw2_part.sum(dim=0)[:half].reshape(1, half)
         return d_emb, g_fc1, g_b1[:half], g_w2, d_logits.sum().reshape(1), None, None
 
 
@@ -330,37 +331,36 @@ class SplicedRows:
         self.slot_of = slot_of
 
 
-def _segment_reduce_rows(mod, num_rows: int, seg_of_entry: torch.Tensor, src_row_of, table: torch.Tensor):
-    """out[u] = sum of table[src_row, :P] over the entries with seg_of_entry == u; entries with a negative segment are
-    dropped.  ``seg_of_entry`` int32 [n]; ``src_row_of(order)`` maps original entry indices to table rows."""
+def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src_row_of, table: torch.Tensor, accumulate: bool):
+    """out[u] (+)= sum of table[src_row, :P] over the entries with seg_of_entry == u; entries with a negative segment are
+    dropped.  ``seg_of_entry`` int32 [n]; ``src_row_of(order)`` maps original entry indices to table rows.  ``out`` [U, P] must be
+    zero where nothing has been accumulated yet."""
     lib = nat.load_library()
     dev, P = table.device, mod.pe_dim
-    out = torch.zeros((num_rows, P), dtype=torch.float32, device=dev)
     if seg_of_entry.numel() == 0:
-        return out
-    sorted_keys, order, n_hit = nat.sort_live(seg_of_entry.contiguous(), max(1, int(num_rows).bit_length()))
+        return
+    sorted_keys, order, n_hit = nat.sort_live(seg_of_entry.contiguous(), max(1, int(out.shape[0]).bit_length()))
     if n_hit == 0:
-        return out
+        return
     # NOTE: every tensor whose address goes to the C ABI must stay referenced until the launch has been issued: a
     # temporary dies as soon as nat.ptr() returns and the caching allocator may hand its block to the next temporary.
     ent_seg = sorted_keys[:n_hit]
     ent_row = src_row_of(order[:n_hit])
     with torch.cuda.device(dev):
         nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, int(table.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
-                                             n_hit, nat.ptr(out), P, nat.current_stream()))
-    return out
+                                             n_hit, nat.ptr(out), P, 1 if accumulate else 0, nat.current_stream()))
 
 
 def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self):
     """Gradient of the spliced PE rows: every (row b, slot j) whose neighbour is spliced row u contributes g_pe[b, :P],
-    every row b whose own node is spliced row u contributes g_self[b].  Grouped by u (``lstep_group_by_key``) and reduced
-    by ``lstep_segment_rows_sum``: no atomics on hot (hub) rows, deterministic summation order."""
+    every row b whose own node is spliced row u contributes g_self[b].  Grouped by u (``lstep_sort_live``) and reduced
+    by ``lstep_segment_rows_sum`` into one buffer: no atomics on hot (hub) rows, deterministic summation order."""
     K = hits.shape[1]
     total = torch.zeros((num_rows, mod.pe_dim), dtype=torch.float32, device=hits.device)
     if g_pe is not None:
-        total = total + _segment_reduce_rows(mod, num_rows, hits.reshape(-1), lambda o: (o // K).contiguous(), g_pe)
+        _segment_reduce_rows(mod, total, hits.reshape(-1), lambda o: (o // K).contiguous(), g_pe, accumulate=False)
     if g_self is not None:
-        total = total + _segment_reduce_rows(mod, num_rows, self_slot.to(torch.int32), lambda o: o.contiguous(), g_self)
+        _segment_reduce_rows(mod, total, self_slot.to(torch.int32), lambda o: o.contiguous(), g_self, accumulate=True)
     return total
 
 
@@ -773,7 +773,7 @@ class LSTEP(nn.Module):
         out = torch.zeros((self._bucket_rows(nseg), self.ld_pe), dtype=torch.float32, device=pe.device)
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_segment_rows_sum(nat.ptr(pe), P, P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
-                                                 nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), ent_row.numel(), nat.ptr(out), self.ld_pe,
+                                                 nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), ent_row.numel(), nat.ptr(out), self.ld_pe, 0,
                                                  nat.current_stream()))
         return out
 
@@ -808,6 +808,23 @@ class LSTEP(nn.Module):
         return self._padded_cached("update_mlp", (m1.weight, m1.bias, m2.weight, m2.bias), lambda: (
             _pad2(m1.weight.detach(), Pp, Cp).t(), _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).t(), _pad1(m2.bias.detach(), Pp)))
 
+    def _update_rows(self, pe, ids, agg, with_self: bool):
+        """``lstep_update_rows``: pe[ids] += tanh(pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(pe[ids])]) in place, one launch."""
+        lib = nat.load_library()
+        Pp = self.ld_self
+        w1t, b1, w2t, b2 = self._update_weights()
+        w1, w2 = self._padded_cached("update_mlp_rowmajor", (self.pe_mlp_1.weight, self.pe_mlp_2.weight),
+                                     lambda: (w1t.t().contiguous(), w2t.t().contiguous()))
+        ws = bs = None
+        if with_self:
+            su = self.self_update_pe
+            ws, bs = self._padded_cached("self_update_sq", (su.weight, su.bias),
+                                         lambda: (_pad2(su.weight.detach(), Pp, Pp).contiguous(), _pad1(su.bias.detach(), Pp)))
+        ids = ids.contiguous()
+        with torch.cuda.device(pe.device):
+            nat.check(lib.lstep_update_rows(nat.ptr(agg), int(agg.stride(0)), nat.ptr(ids), ids.numel(), nat.ptr(w1), nat.ptr(b1), nat.ptr(w2),
+                                            nat.ptr(b2), nat.ptr(ws), nat.ptr(bs), nat.ptr(pe), self.pe_dim, nat.current_stream()))
+
     @classmethod
     def _bucket_rows(cls, n: int) -> int:
         """Row count rounded up to a coarse bucket: the number of updated rows changes every batch, and every new GEMM
@@ -832,7 +849,7 @@ class LSTEP(nn.Module):
                                                    nat.current_stream()))
 
     @torch.no_grad()
-    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None):
+    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None, fused: bool = False):
         """U1 (LSTEP.py:277-303): every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints.
         Returns (ids, z) with the new row = pe[ids] + tanh(z), WITHOUT writing; ``shard=(W, r)`` restricts the work to
         nodes with id % W == r; ``presorted=(order, inverse, counts)`` reuses the caller's stable sort of cat[src, dst]
@@ -865,6 +882,9 @@ class LSTEP(nn.Module):
             ent_seg, ent_row, ent_dt = ent_seg[keep_e], ent_row[keep_e], ent_dt[keep_e]
         agg = self._segment_sum(pe, ids.numel(), ent_seg.to(torch.int32), ent_row.to(torch.int32), ent_dt.contiguous())
         n = ids.numel()
+        if fused:   # MLP + self term + tanh + residual + in-place row write in one launch
+            self._update_rows(pe, ids, agg, with_self=True)
+            return None
         own = torch.zeros((agg.shape[0], self.pe_dim), dtype=torch.float32, device=pe.device)
         own[:n] = pe[ids]
         Pp = self.ld_self
@@ -875,7 +895,7 @@ class LSTEP(nn.Module):
         return ids, z[:n]
 
     @torch.no_grad()
-    def update_pe_phase2(self, pe, bn, t, now32: float, num_neighbors: int, shard=None):
+    def update_pe_phase2(self, pe, bn, t, now32: float, num_neighbors: int, shard=None, fused: bool = False):
         """U2 (LSTEP.py:305-339): push the updated PE of each batch node to its K most recent neighbours.
         ``bn`` (U rows) is zipped with the B edge times: row i uses t[i]; rows >= min(U, B) stay padding.
         Sets pe[0] = 0 (LSTEP.py:317) before reading.  Returns (touched ids, z) with new row = pe[id] + tanh(z), WITHOUT
@@ -911,6 +931,9 @@ class LSTEP(nn.Module):
             agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
         else:
             agg2 = self._segment_sum(pe, nseg, inverse, ent_row, ent_dt)
+        if fused:
+            self._update_rows(pe, touched, agg2, with_self=False)
+            return None
         return touched, self._update_mlp(agg2)[:touched.numel()]
 
     @torch.no_grad()
@@ -925,6 +948,10 @@ class LSTEP(nn.Module):
         src, dst = self._ids(batch_src_node_ids), self._ids(batch_dst_node_ids)
         t = self._times(node_interact_times)
         now32 = float(np.float32(current_time))  # torch.Tensor([current_time]) rounds to float32 first (LSTEP.py:277)
+        if self._fused_tail_ok() and os.environ.get("LSTEP_TORCH_UPDATE") != "1":
+            self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted, fused=True)
+            self.update_pe_phase2(pe, bn, t, now32, num_neighbors, fused=True)
+            return pe
         ids, z = self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted)
         self.apply_residual_tanh(pe, ids, z)
         ids, z = self.update_pe_phase2(pe, bn, t, now32, num_neighbors)

@@ -333,11 +333,16 @@ def test_segment_rows_sum_vs_index_add(hip):
         table = torch.randn(nsrc, ld, device=DEV)
         seg = torch.randint(-2, n_rows, (n_ent,), device=DEV)          # negative segment = entry to drop
         src = torch.randint(0, nsrc, (n_ent,), device=DEV)
-        out = _segment_reduce_rows(M, n_rows, seg.to(torch.int32), lambda o: src.to(torch.int32)[o.long()].contiguous(), table)
+        out = torch.zeros(n_rows, 172, device=DEV)
+        _segment_reduce_rows(M, out, seg.to(torch.int32), lambda o: src.to(torch.int32)[o.long()].contiguous(), table, accumulate=False)
         keep = seg >= 0
         ref = torch.zeros(n_rows, 172, device=DEV, dtype=torch.float64).index_add_(0, seg[keep], table[src[keep]][:, :172].double())
         scale = max(1.0, float(ref.abs().max()))
-        assert float((out.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (n_ent / max(n_rows, 1)) ** 0.5)
+        tol = 2e-6 * scale * max(1.0, (n_ent / max(n_rows, 1)) ** 0.5)
+        assert float((out.double() - ref).abs().max()) <= tol
+        # a second reduction accumulated on top of the first (neighbour + self gradients share one buffer)
+        _segment_reduce_rows(M, out, seg.to(torch.int32), lambda o: src.to(torch.int32)[o.long()].contiguous(), table, accumulate=True)
+        assert float((out.double() - 2 * ref).abs().max()) <= 2 * tol
 
 
 def test_large_tables_64bit_addressing_vs_oracle(hip):
