@@ -4,6 +4,7 @@
 //   (3) spliced-row hits of the gather backward -> gradient segments
 // One stable radix sort (hipCUB) + head flags + one scan instead of ~50 small framework launches per use.
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include "lstep_common.h"
 
@@ -34,6 +35,17 @@ __global__ void unique_kernel(const int32_t* __restrict__ sk, const int32_t* __r
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Stable LSD radix sort of (key, value) pairs on the low `bits` key bits.  The library's default switches to a merge sort below
+// 1 M items (8 - 21 passes of two launches each at the 30 k - 1 M sizes met here); Onesweep takes bits / 8 passes.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+
+static hipError_t sort_pairs(void* temp, size_t& temp_bytes, const int32_t* keys_in, int32_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
+                             int64_t n, int bits, hipStream_t s) {
+    // keys are non-negative int32: sorted as unsigned (rocprim's signed-key bit flip only touches the sign bit, outside `bits`)
+    return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, reinterpret_cast<const uint32_t*>(keys_in), reinterpret_cast<uint32_t*>(keys_out),
+                                                 vals_in, vals_out, (size_t)n, 0u, (unsigned)bits, s);
+}
+
 struct NonNegative {   // select predicate over entry indices: keep i if keys[i] >= 0
     const int32_t* keys;
     __host__ __device__ bool operator()(const int32_t& i) const { return keys[i] >= 0; }
@@ -55,8 +67,7 @@ static size_t select_temp_bytes(int64_t n) {
 
 static size_t cub_temp_bytes(int64_t n, int bits) {
     size_t a = 0, b = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                       (int)n, 0, bits, (hipStream_t)0);
+    (void)sort_pairs(nullptr, a, nullptr, nullptr, nullptr, nullptr, n, bits, (hipStream_t)0);
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, (hipStream_t)0);
     return a > b ? a : b;
 }
@@ -89,7 +100,7 @@ extern "C" int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bi
     size_t temp_bytes = cub_temp_bytes(n, key_bits);
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(256), 0, s, idx, n);
-    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, sorted_keys, idx, order, (int)n, 0, key_bits, s) != hipSuccess)
+    if (sort_pairs(temp, temp_bytes, keys, sorted_keys, idx, order, n, key_bits, s) != hipSuccess)
         return set_error(LSTEP_EHIP, "lstep_group_by_key: radix sort failed");
     hipLaunchKernelGGL(head_flag_kernel, dim3(grid), dim3(256), 0, s, sorted_keys, flag, n);
     temp_bytes = cub_temp_bytes(n, key_bits);
@@ -133,7 +144,7 @@ extern "C" int lstep_sort_live(const int32_t* keys, int64_t n, int32_t key_bits,
     *num_live = host_count;
     if (host_count == 0) return LSTEP_OK;
     temp_bytes = cub_temp_bytes(host_count, key_bits);
-    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, live_keys, sorted_keys, idx, order, (int)host_count, 0, key_bits, s) != hipSuccess)
+    if (sort_pairs(temp, temp_bytes, live_keys, sorted_keys, idx, order, host_count, key_bits, s) != hipSuccess)
         return set_error(LSTEP_EHIP, "lstep_sort_live: radix sort failed");
     return check_launch("lstep_sort_live");
 }

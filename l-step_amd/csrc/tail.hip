@@ -381,15 +381,17 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(const UpdatePara
 
 using namespace lstep;
 
-// number of 16-row slabs per wave: the choice that needs the fewest rounds of 1024 waves (256 CUs x 4 SIMDs, one wave each)
+// number of 16-row slabs per wave: fewest rounds of 1024 waves (256 CUs x 4 SIMDs, one wave each), weighted by what a slab costs at
+// that width (a wave re-reads all the weights whatever S is: measured 1.35 / 1.1 / 1.0 relative time per slab at S = 1 / 2 / 3)
 static int tail_slabs_per_wave(int64_t m) {
     const int64_t slabs = (m + 15) / 16;
-    int best = 1;
-    int64_t best_cost = -1;
-    for (int s = 1; s <= 3; ++s) {
+    const double per_slab[4] = {0.0, 1.35, 1.1, 1.0};
+    int best = 3;
+    double best_cost = -1.0;
+    for (int s = 3; s >= 1; --s) {
         const int64_t tasks = (slabs + s - 1) / s;
-        const int64_t cost = ((tasks + 1023) / 1024) * s;
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && s > best)) { best = s; best_cost = cost; }
+        const double cost = (double)((tasks + 1023) / 1024) * s * per_slab[s];
+        if (best_cost < 0 || cost < best_cost) { best = s; best_cost = cost; }
     }
     return best;
 }
