@@ -594,3 +594,71 @@ def test_head_matches_merge_layer(hip, n):
         e = emb[:, :172]
         re = torch.cat([ml(e[:n], e[n:2 * n]), ml(e[2 * n:3 * n], e[3 * n:])]).squeeze(-1)
     np.testing.assert_allclose(le.cpu().numpy(), re.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("m,n,k", [(4096, 176, 272), (1000, 272, 272), (777, 176, 352), (2048, 176, 624), (37, 64, 48), (5, 16, 16), (3000, 172, 344)])
+def test_linear_wgrad_vs_float64(hip, m, n, k):
+    """lstep_linear_wgrad (split-M fp32-MFMA weight gradient + bias gradient) against a float64 product, incl. row counts that are
+    not multiples of the 4-row MFMA step / the 16-row pipeline round and widths that are not multiples of 16."""
+    from lstep_amd import _native as nat
+    g = torch.Generator().manual_seed(m + n + k)
+    dy = torch.randn(m, n, generator=g).to(DEV)
+    x = torch.randn(m, k, generator=g).to(DEV)
+    dw, db = nat.linear_wgrad(dy, x)
+    ref = dy.double().t() @ x.double()
+    tol = 3e-6 * (m ** 0.5) * 4
+    assert float((dw.double() - ref).abs().max()) <= tol
+    assert float((db.double() - dy.double().sum(0)).abs().max()) <= tol
+    # strided operands (column blocks of wider matrices), no bias
+    wide_y, wide_x = torch.randn(m, n + 32, generator=g).to(DEV), torch.randn(m, k + 16, generator=g).to(DEV)
+    dw2, none = nat.linear_wgrad(wide_y[:, 16:16 + n], wide_x[:, :k], want_bias=False)
+    assert none is None
+    assert float((dw2.double() - wide_y[:, 16:16 + n].double().t() @ wide_x[:, :k].double()).abs().max()) <= tol
+
+
+def test_fused_dense_kernels_match_library_path(hip, monkeypatch):
+    """The single-launch dense tail / predictor / update_pe kernels (lstep_tail_fwd/bwd, lstep_head_fwd/bwd, lstep_update_rows,
+    lstep_link_loss) against the same model run through the library-GEMM path (LSTEP_TORCH_* switches): outputs, every
+    parameter gradient and the updated PE table of one engine iteration."""
+    from lstep_amd import synth
+    from lstep_amd.engine import EdgeStream, LstepEngine
+    from lstep_amd.sampler import NeighborSampler
+    from lstep_amd.smoke import build_hip_model
+    g = synth.make_temporal_graph(num_nodes=300, num_edges=6000, seed=5, zipf=1.1)
+    node_raw, edge_raw = synth.make_features(300, 6000, seed=5)
+    K, T, B = 20, 4, 500
+    results = []
+    for torch_path in (False, True):
+        for var in ("LSTEP_TORCH_TAIL", "LSTEP_TORCH_HEAD", "LSTEP_TORCH_LOSS", "LSTEP_TORCH_UPDATE", "LSTEP_TORCH_WGRAD"):
+            if torch_path:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
+        sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=300, device=DEV)
+        model = build_hip_model(node_raw, edge_raw, sampler, K, T, synth.make_state_dict(K, T), DEV)
+        model.train()
+        from lstep_amd import model as model_mod
+        model_mod._Linear.NATIVE_WGRAD = not torch_path
+        eng = LstepEngine(model[0], model[1], K, 2000)
+        eng.overlap_update = False
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)      # lr 0: the gradients stay in .grad, the weights do not move
+        stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+        init = torch.from_numpy(synth.make_initial_pe(300, seed=5)).to(DEV)
+        outs = []
+        for b in range(3):
+            lo = 3000 + b * B
+            neg = torch.from_numpy(synth.make_negatives(300, B, seed=b)).to(DEV)
+            res = eng.train_iteration(opt, b, *stream.batch(lo, lo + B), neg, initial_pe=init)
+            if res is not None:
+                outs.append([res["loss"].item(), res["lp_loss"].item(), res["pe_loss"].item()])
+        grads = {n_: (torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad).clone() for n_, p in model.named_parameters() if p.grad is not None}
+        results.append((np.array(outs), grads, eng.ring.last().clone(), res["predicts"].clone()))
+    model_mod._Linear.NATIVE_WGRAD = True
+    (la, ga, ta, pa), (lb, gb, tb, pb) = results
+    np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(ta.cpu().numpy(), tb.cpu().numpy(), rtol=0, atol=2e-5)
+    assert set(ga) == set(gb) and len(ga) >= 20
+    for name in ga:
+        scale = max(1e-6, float(gb[name].abs().max()))
+        assert float((ga[name] - gb[name]).abs().max()) <= 2e-4 * scale + 1e-7, name
