@@ -393,12 +393,19 @@ class _GatherAggregate(torch.autograd.Function):
         aw = agg_w.detach().contiguous() if en else None
         tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
         s = mod.neighbor_sampler
+        sink = getattr(mod, "gather_event_sink", None)   # bench.py: HIP events on the launch stream right around the launch (roofline.achieved)
+        if sink is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         with torch.cuda.device(dev):
             nat.check(lib.lstep_gather_aggregate_fwd(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
                                                      Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
                                                      int(K), int(G), int(branches), nat.ptr(out_edge), nat.ptr(out_node), nat.ptr(out_pe),
                                                      nat.ptr(out_self), mod.ld_edge, ld_node, mod.ld_pe, ld_self, nat.ptr(count),
                                                      nat.current_stream()))
+        if sink is not None:
+            e1.record()
+            sink.append((e0, e1, count))
         ctx.mod, ctx.sampler, ctx.K, ctx.branches, ctx.ld_self = mod, s, int(K), int(branches), ld_self
         ctx.pe_shape = tuple(pe.shape) if pe is not None else None
         ctx.rows_shape = tuple(rows.shape) if rows is not None else None
@@ -629,16 +636,7 @@ class LSTEP(nn.Module):
         slot_of = spliced.slot_of if spliced is not None else None
         if slot_of is not None and (slot_of.dtype != torch.int32 or slot_of.numel() < self.neighbor_sampler.num_rows):
             raise ValueError("slot_of must be an int32 map with one entry per node id")
-        sink = getattr(self, "gather_event_sink", None)
-        if sink is None:
-            return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide)
-        # bench.py: HIP events on the launch stream around the forward gather launch (roofline.achieved)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide)
-        e1.record()
-        sink.append((e0, e1, out[4]))
-        return out
+        return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide)
 
     def _edge_node_tail(self, x_edge, x_node):
         """edge_mlp_1 -> edge_agg (reassociated) -> relu -> edge_mlp_2 ; node_mlp(cat[node, edge])  (models/LSTEP.py:161-170,219)."""
@@ -851,7 +849,8 @@ class LSTEP(nn.Module):
     @torch.no_grad()
     def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None, fused: bool = False):
         """U1 (LSTEP.py:277-303): every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints.
-        Returns (ids, z) with the new row = pe[ids] + tanh(z), WITHOUT writing; ``shard=(W, r)`` restricts the work to
+        Returns (ids, z) with the new row = pe[ids] + tanh(z), WITHOUT writing (``fused=True``: writes the rows in place with
+        ``lstep_update_rows`` and returns ids only); ``shard=(W, r)`` restricts the work to
         nodes with id % W == r; ``presorted=(order, inverse, counts)`` reuses the caller's stable sort of cat[src, dst]
         (the engine derives the batch-node set and the segments from one sort; then ``bn`` must be that node set)."""
         dt1 = (now32 - t).to(torch.float32)                       # float32 scalar - float64 -> float64 -> .float()
@@ -884,7 +883,7 @@ class LSTEP(nn.Module):
         n = ids.numel()
         if fused:   # MLP + self term + tanh + residual + in-place row write in one launch
             self._update_rows(pe, ids, agg, with_self=True)
-            return None
+            return ids
         own = torch.zeros((agg.shape[0], self.pe_dim), dtype=torch.float32, device=pe.device)
         own[:n] = pe[ids]
         Pp = self.ld_self
@@ -933,7 +932,7 @@ class LSTEP(nn.Module):
             agg2 = self._segment_sum(pe, nseg, inverse, ent_row, ent_dt)
         if fused:
             self._update_rows(pe, touched, agg2, with_self=False)
-            return None
+            return touched
         return touched, self._update_mlp(agg2)[:touched.numel()]
 
     @torch.no_grad()

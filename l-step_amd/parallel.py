@@ -24,12 +24,14 @@ to fp32 summation order (``tests/test_parallel.py``).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from .engine import HistoryRing, LstepEngine, _lookup_rows
+from .engine import HistoryRing, LstepEngine, _LinkLoss, _lookup_rows
 from .model import SplicedRows
 
 
@@ -177,6 +179,9 @@ class DistributedLstep:
         self.table = torch.zeros((rows, self.bb.pe_dim), dtype=torch.float32, device=dev)  # replicated current PE
         self.slot_of = engine.slot_of
         engine.ring = None  # the unsharded ring is not used (and must not be allocated at scale)
+        # update_pe's layers are forward-only (no gradient ever reaches them): they stay out of the bucket
+        frozen = {id(p) for m in (self.bb.pe_mlp_1, self.bb.pe_mlp_2, self.bb.self_update_pe) for p in m.parameters()}
+        self._trainable = [p for p in list(self.bb.parameters()) + list(self.predictor.parameters()) if id(p) not in frozen]
 
     # ---- state import/export (tests, checkpoints)
     def load_history(self, history: torch.Tensor):
@@ -209,22 +214,47 @@ class DistributedLstep:
     def _probabilities(self, a, b):
         return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
 
-    def _update_start(self, bn, src, dst, ts, presorted=None, owner_counts=None) -> PendingGather:
-        """Phase 1 completely (its rows feed phase 2), phase 2 up to the all-gather of its rows, which is left in flight."""
+    def _rows_with_ids(self, ids: torch.Tensor) -> torch.Tensor:
+        """[n, P + 4] block: the current table rows of ``ids`` with the ids packed into the padding columns (one collective)."""
+        P = self.bb.pe_dim
+        z = torch.zeros((ids.numel(), P + 4), dtype=torch.float32, device=self.device)
+        z[:, :P] = self.table[ids]
+        return pack_ids(z, ids, P)
+
+    def _write_rows(self, z_all: torch.Tensor):
+        P = self.bb.pe_dim
+        self.table.index_copy_(0, unpack_ids(z_all, P), z_all[:, :P])
+
+    def _update_start(self, bn, src, dst, ts, presorted=None, owner_counts=None):
+        """Phase 1 completely (its rows feed phase 2), phase 2 up to the all-gather of its rows, which is left in flight.
+        Fused path (default widths): every rank updates the rows it owns IN PLACE (``lstep_update_rows``) and the new rows are
+        all-gathered; library path: the pre-activation rows z are gathered and every replica applies pe += tanh(z)."""
         now32 = float(np.float32(float(ts.max().item())))
         shard = (self.W, self.rank)
         P = self.bb.pe_dim
+        fused = self.bb._fused_tail_ok() and os.environ.get("LSTEP_TORCH_UPDATE") != "1"
+        if fused:
+            ids = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted, fused=True)
+            if self.W > 1:
+                self._write_rows(all_gather_var(self._rows_with_ids(ids), self.group, counts=owner_counts)[0])
+            ids = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard, fused=True)
+            return ("rows", PendingGather(self._rows_with_ids(ids), self.group) if self.W > 1 else None)
         ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
         # ids ride in z's padding columns: one collective per phase; phase-1 row counts are known locally
         z_all, _ = all_gather_var(pack_ids(z, ids, P), self.group, counts=owner_counts)
         self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)       # every replica applies the same update
         ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
-        return PendingGather(pack_ids(z, ids, P), self.group)
+        return ("z", PendingGather(pack_ids(z, ids, P), self.group))
 
-    def _update_finish(self, pending: PendingGather):
+    def _update_finish(self, pending):
         """Apply the gathered phase-2 rows on every replica and append the snapshot to this rank's ring shard."""
-        z_all = pending.wait()
-        self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, self.bb.pe_dim), z_all)
+        kind, gather = pending
+        if kind == "rows":
+            if gather is not None:
+                self._write_rows(gather.wait())
+        else:
+            z_all = gather.wait()
+            self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, self.bb.pe_dim), z_all)
         self._append_snapshot()
 
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
@@ -242,16 +272,23 @@ class DistributedLstep:
             rows_mine, leaf, (owner_order, owner_counts) = self._splice(bn, batch_idx)
             spliced = SplicedRows(leaf, self.slot_of)
             s_, d_, n_, t_ = src[sl], dst[sl], neg_dst[sl], ts[sl]
-            emb = self.bb.combining_pe_raw_feat(self.table, torch.cat([s_, d_, n_]), torch.cat([t_, t_, t_]), self.K, self.G, spliced=spliced)
+            ids3 = torch.cat([s_, d_, n_])
+            emb_p = self.bb.combining_pe_raw_feat(self.table, ids3, torch.cat([t_, t_, t_]), self.K, self.G, spliced=spliced, padded=True)
+            emb = emb_p[:, :self.bb.feat_dim]
             pos_src, pos_dst, neg_emb = emb[:b], emb[b:2 * b], emb[2 * b:]
-            p_pos = self._probabilities(pos_src, pos_dst)
-            p_neg = self._probabilities(pos_src, neg_emb)
-            predicts = torch.cat([p_pos, p_neg], dim=0)
-            labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
-            lp_loss = F.binary_cross_entropy(predicts, labels)
-            e_src = _lookup_rows(self.table, spliced, s_)
-            pe_loss = F.mse_loss(e_src, _lookup_rows(self.table, spliced, d_)) - self.eng.neg_sample_weight * F.mse_loss(e_src, _lookup_rows(self.table, spliced, n_))
-            loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
+            if self.eng.fused_loss and self.predictor.fused_ok(emb_p):   # predictor + loss terms + their gradient: three launches
+                logits = self.predictor.pair_logits(emb_p, b, (0, b, 0, 2 * b))
+                loss, lp_loss, pe_loss, predicts = _LinkLoss.apply(logits, leaf, self.table, self.slot_of, ids3, self.eng.pe_weight,
+                                                                   self.eng.neg_sample_weight)
+            else:
+                p_pos = self._probabilities(pos_src, pos_dst)
+                p_neg = self._probabilities(pos_src, neg_emb)
+                predicts = torch.cat([p_pos, p_neg], dim=0)
+                labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
+                lp_loss = F.binary_cross_entropy(predicts, labels)
+                e_src = _lookup_rows(self.table, spliced, s_)
+                pe_loss = F.mse_loss(e_src, _lookup_rows(self.table, spliced, d_)) - self.eng.neg_sample_weight * F.mse_loss(e_src, _lookup_rows(self.table, spliced, n_))
+                loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
         # update_pe: the all-gather of the phase-2 rows (the largest collective, ~0.7 KB per touched node) stays in flight
         # while the backward pass runs; neither reads what the other writes
@@ -268,7 +305,7 @@ class DistributedLstep:
             g_mine = reduce_scatter_var(g_rows[owner_order].contiguous(), owner_counts, self.group)
             if rows_mine.numel():
                 rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
-            all_reduce_gradients(list(self.bb.parameters()) + list(self.predictor.parameters()), self.group)
+            all_reduce_gradients(self._trainable, self.group)
             self._update_finish(pending)
             optimizer.step()
             self.slot_of[bn] = -1
