@@ -177,8 +177,9 @@ def sort_live(keys, key_bits: int):
     return sorted_keys, order, int(live.value)
 
 
-def linear_wgrad(dy, x, want_bias: bool = True):
-    """``(dy^T x, dy.sum(0))`` through ``lstep_linear_wgrad``; dy [m, n], x [m, k] fp32 device tensors with unit column stride."""
+def linear_wgrad(dy, x, want_bias: bool = True, out=None):
+    """``(dy^T x, dy.sum(0))`` through ``lstep_linear_wgrad``; dy [m, n], x [m, k] fp32 device tensors with unit column stride.
+    ``out=(dw, db)``: contiguous destination tensors (either may be None)."""
     import torch
 
     lib = load_library()
@@ -187,8 +188,10 @@ def linear_wgrad(dy, x, want_bias: bool = True):
     if dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != m or dy.dtype != torch.float32 or x.dtype != torch.float32:
         raise ValueError("linear_wgrad: fp32 [m, n] / [m, k] operands with unit column stride expected")
     dev = dy.device
-    dw = torch.empty((n, k), dtype=torch.float32, device=dev)
-    db = torch.empty(n, dtype=torch.float32, device=dev) if want_bias else None
+    dw = out[0] if out is not None and out[0] is not None else torch.empty((n, k), dtype=torch.float32, device=dev)
+    db = (out[1] if out is not None and out[1] is not None else torch.empty(n, dtype=torch.float32, device=dev)) if want_bias else None
+    if tuple(dw.shape) != (n, k) or not dw.is_contiguous() or (db is not None and (db.numel() != n or not db.is_contiguous())):
+        raise ValueError("linear_wgrad: destination tensors must be contiguous [n, k] / [n]")
     if m == 0:
         dw.zero_()
         if db is not None:

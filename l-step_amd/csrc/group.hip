@@ -36,8 +36,9 @@ __global__ void unique_kernel(const int32_t* __restrict__ sk, const int32_t* __r
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Stable LSD radix sort of (key, value) pairs on the low `bits` key bits.  The library's default switches to a merge sort below
-// 1 M items (8 - 21 passes of two launches each at the 30 k - 1 M sizes met here); Onesweep takes bits / 8 passes.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+// 1 M items; measured here (MI355X, 15-20 key bits): merge sort 8 launches / 36 us at 32 k items but 21 launches / 250 us at 330 k,
+// Onesweep ~31 us per 6-8-bit pass whatever the size.  So: merge sort up to 64 k items, Onesweep above.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
 
 static hipError_t sort_pairs(void* temp, size_t& temp_bytes, const int32_t* keys_in, int32_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
                              int64_t n, int bits, hipStream_t s) {

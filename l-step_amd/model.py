@@ -104,8 +104,66 @@ def fast_linear(x, w, b=None, relu=False):
     return _Linear.apply(x, w, b, relu)
 
 
+def _tail_weights_forward(dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2):
+    """Padded / pre-multiplied weights of the dense tail (see ``_TailWeights``).  Returns (the 8 operands, their 4 transposes for the
+    backward kernel, (a_sum, M) for the hand-derived backward)."""
+    Fd, C, P, CP, Ce, Fn, Cp, Pp = dims   # F, D+F, P, P+D and their 16-aligned paddings
+    dev = W1.device
+    sizes = [Ce * Ce, Ce, Pp * Cp, Pp, Pp * 2 * Pp, Pp, Fn * (Fn + Ce + Pp), Fn]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    parts = torch.split(flat, sizes)
+    W1p, b1p, Wn1p, bn1p = parts[0].view(Ce, Ce), parts[1], parts[2].view(Pp, Cp), parts[3]
+    Wq, bq, Wall, constp = parts[4].view(Pp, 2 * Pp), parts[5], parts[6].view(Fn, Fn + Ce + Pp), parts[7]
+    a_sum = aw.sum()
+    W1p[:C, :C] = W1
+    torch.addcmul(ab.expand(C), a_sum.expand(C), b1, out=b1p[:C])
+    Wn1p[:P, :CP] = Wn1
+    bn1p[:P] = bn1
+    Wq[:P, :P] = Ws
+    Wq[:P, Pp:Pp + P] = Wn2
+    torch.add(bs, bn2, out=bq[:P])
+    wo_a, wo_b = Wo[:, :Fd], Wo[:, Fd:]
+    wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
+    M = wo_a @ wn_b                                           # [F, C]
+    Wall[:Fd, :Fd] = wo_a @ wn_a
+    Wall[:Fd, Fn:Fn + C] = M @ W2
+    Wall[:Fd, Fn + Ce:Fn + Ce + P] = wo_b
+    constp[:Fd] = torch.addmv(torch.addmv(bo, M, b2), wo_a, bn)
+    transposed = (W1p.t().contiguous(), Wn1p.t().contiguous(), Wq.t().contiguous(), Wall.t().contiguous())
+    return (W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp), transposed, (a_sum, M)
+
+
+def _tail_weights_backward(dims, K, b1, W2, b2, Wn, bn, Wo, a_sum, M, gW1p, gb1p, gWn1p, gbn1p, gWq, gbq, gWall, gconst, dense=False):
+    """Hand-derived chain rule of ``_tail_weights_forward``: gradients of the 16 parameters in its argument order."""
+    Fd, C, P, CP, Ce, Fn, Cp, Pp = dims
+    db1e = gb1p[:C]
+    d_b1 = a_sum * db1e
+    d_aw = torch.dot(db1e, b1).expand(1, K)
+    d_ab = db1e.sum().reshape(1)
+    wo_a = Wo[:, :Fd]
+    wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
+    dA1, dA2, dWo_b, dc = gWall[:Fd, :Fd], gWall[:Fd, Fn:Fn + C], gWall[:Fd, Fn + Ce:Fn + Ce + P], gconst[:Fd]
+    dM = torch.addr(dA2 @ W2.t(), dc, b2)                     # from A2 = M W2 and const = M b2 + ...
+    d_W2 = M.t() @ dA2
+    d_b2 = M.t() @ dc
+    dWo_a = torch.addr(dA1 @ wn_a.t() + dM @ wn_b.t(), dc, bn)
+    d_Wn = torch.cat([wo_a.t() @ dA1, wo_a.t() @ dM], dim=1)
+    d_bn = wo_a.t() @ dc
+    d_Wo = torch.cat([dWo_a, dWo_b], dim=1)
+    out = (gW1p[:C, :C], d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, dc, gWq[:P, :P], gbq[:P], gWn1p[:P, :CP],
+           gbn1p[:P], gWq[:P, Pp:Pp + P], gbq[:P])
+    if dense:   # the graph path assigns these to .grad itself: dense, parameter-shaped, pairwise distinct storage (free inside a graph)
+        out = tuple(t.clone(memory_format=torch.contiguous_format) for t in out)
+    return out
+
+
+def _tail_grad_shapes(dims):
+    Fd, C, P, CP, Ce, Fn, Cp, Pp = dims
+    return [(Ce, Ce), (Ce,), (Pp, Cp), (Pp,), (Pp, 2 * Pp), (Pp,), (Fn, Fn + Ce + Pp), (Fn,)]
+
+
 class _TailWeights(torch.autograd.Function):
-    """Padded / pre-multiplied weights of the dense tail in ~15 launches forward and ~25 backward.
+    """Padded / pre-multiplied weights of the dense tail in ~25 launches forward and ~20 backward.
 
     Built from the raw parameters every call (they change every optimiser step):
         W1p  [Ce, Ce]  = edge_mlp_1.weight                      b1p  = (sum a) * edge_mlp_1.bias + edge_agg.bias
@@ -113,68 +171,121 @@ class _TailWeights(torch.autograd.Function):
         Wq   [Pp, 2Pp] = [self_update_neighbor_pe.weight | pe_neighbor_mlp_2.weight]     bq = sum of their biases
         Wall [Fn, Fn+Ce+Pp] = [Wo_a Wn_a | Wo_a Wn_b W2 | Wo_b]  const = Wo_a Wn_b b2 + Wo_a bn + bo
     (Wo = out_node_emb.weight = [Wo_a | Wo_b], Wn = node_mlp.weight = [Wn_a | Wn_b], W2/b2 = edge_mlp_2), all zero-padded
-    to the 16-aligned widths.  The same thing written with F.pad / cat / matmul costs ~45 launches forward and ~60 in
-    autograd's backward; here the backward is the hand-derived chain rule of the products above."""
+    to the 16-aligned widths, plus the four transposes the backward kernel reads.  The same thing written with F.pad / cat / matmul
+    costs ~45 launches forward and ~60 in autograd's backward; here the backward is the hand-derived chain rule of the products above.
+    ``_TailWeightsGraph`` replays both directions as one HIP graph launch each."""
 
     @staticmethod
     def forward(ctx, dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2):
-        Fd, C, P, CP, Ce, Fn, Cp, Pp = dims   # F, D+F, P, P+D and their 16-aligned paddings
-        dev = W1.device
-        sizes = [Ce * Ce, Ce, Pp * Cp, Pp, Pp * 2 * Pp, Pp, Fn * (Fn + Ce + Pp), Fn]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        parts = torch.split(flat, sizes)
-        W1p, b1p, Wn1p, bn1p = parts[0].view(Ce, Ce), parts[1], parts[2].view(Pp, Cp), parts[3]
-        Wq, bq, Wall, constp = parts[4].view(Pp, 2 * Pp), parts[5], parts[6].view(Fn, Fn + Ce + Pp), parts[7]
-        a_sum = aw.sum()
-        W1p[:C, :C] = W1
-        torch.addcmul(ab.expand(C), a_sum.expand(C), b1, out=b1p[:C])
-        Wn1p[:P, :CP] = Wn1
-        bn1p[:P] = bn1
-        Wq[:P, :P] = Ws
-        Wq[:P, Pp:Pp + P] = Wn2
-        torch.add(bs, bn2, out=bq[:P])
-        wo_a, wo_b = Wo[:, :Fd], Wo[:, Fd:]
-        wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
-        M = wo_a @ wn_b                                           # [F, C]
-        Wall[:Fd, :Fd] = wo_a @ wn_a
-        Wall[:Fd, Fn:Fn + C] = M @ W2
-        Wall[:Fd, Fn + Ce:Fn + Ce + P] = wo_b
-        constp[:Fd] = torch.addmv(torch.addmv(bo, M, b2), wo_a, bn)
+        outs, transposed, (a_sum, M) = _tail_weights_forward(dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2)
         ctx.dims = dims
         ctx.save_for_backward(b1, a_sum, W2, b2, Wn, bn, Wo, M)
         ctx.K = aw.numel()
-        return W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp
+        ctx.mark_non_differentiable(*transposed)
+        return outs + transposed
 
     @staticmethod
-    def backward(ctx, gW1p, gb1p, gWn1p, gbn1p, gWq, gbq, gWall, gconst):
-        Fd, C, P, CP, Ce, Fn, Cp, Pp = ctx.dims
+    def backward(ctx, gW1p, gb1p, gWn1p, gbn1p, gWq, gbq, gWall, gconst, *_):
         b1, a_sum, W2, b2, Wn, bn, Wo, M = ctx.saved_tensors
         dev = b1.device
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
-        gW1p = gW1p if gW1p is not None else z(Ce, Ce)
-        gb1p = gb1p if gb1p is not None else z(Ce)
-        gWn1p = gWn1p if gWn1p is not None else z(Pp, Cp)
-        gbn1p = gbn1p if gbn1p is not None else z(Pp)
-        gWq = gWq if gWq is not None else z(Pp, 2 * Pp)
-        gbq = gbq if gbq is not None else z(Pp)
-        gWall = gWall if gWall is not None else z(Fn, Fn + Ce + Pp)
-        gconst = gconst if gconst is not None else z(Fn)
-        db1e = gb1p[:C]
-        d_b1 = a_sum * db1e
-        d_aw = torch.dot(db1e, b1).expand(1, ctx.K)
-        d_ab = db1e.sum().reshape(1)
-        wo_a = Wo[:, :Fd]
-        wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
-        dA1, dA2, dWo_b, dc = gWall[:Fd, :Fd], gWall[:Fd, Fn:Fn + C], gWall[:Fd, Fn + Ce:Fn + Ce + P], gconst[:Fd]
-        dM = torch.addr(dA2 @ W2.t(), dc, b2)                     # from A2 = M W2 and const = M b2 + ...
-        d_W2 = M.t() @ dA2
-        d_b2 = M.t() @ dc
-        dWo_a = torch.addr(dA1 @ wn_a.t() + dM @ wn_b.t(), dc, bn)
-        d_Wn = torch.cat([wo_a.t() @ dA1, wo_a.t() @ dM], dim=1)
-        d_bn = wo_a.t() @ dc
-        d_Wo = torch.cat([dWo_a, dWo_b], dim=1)
-        return (None, gW1p[:C, :C], d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, dc, gWq[:P, :P], gbq[:P], gWn1p[:P, :CP],
-                gbn1p[:P], gWq[:P, Pp:Pp + P], gbq[:P])
+        grads = [g if g is not None else torch.zeros(shape, dtype=torch.float32, device=dev)
+                 for g, shape in zip((gW1p, gb1p, gWn1p, gbn1p, gWq, gbq, gWall, gconst), _tail_grad_shapes(ctx.dims))]
+        return (None,) + _tail_weights_backward(ctx.dims, ctx.K, b1, W2, b2, Wn, bn, Wo, a_sum, M, *grads)
+
+
+class _TailWeightsGraph:
+    """``_TailWeights`` as two HIP graphs (``torch.cuda.CUDAGraph``): the ~25 + ~20 tiny launches that turn the live parameters into
+    the dense tail's operands, and the operand gradients back into parameter gradients, are functions of fixed-address tensors with
+    fixed shapes, so each direction is captured once and replayed with one launch per step.  The operand gradients arrive in
+    fixed buffers (``grad_buffers``: ``lstep_linear_wgrad`` writes straight into them); the parameter gradients are static tensors
+    too and are assigned to ``param.grad`` directly (returned through autograd they would be cloned one by one)."""
+
+    def __init__(self, dims, params):
+        self.dims, self.params = dims, list(params)
+        dev = self.params[0].device
+        self.gin = [torch.zeros(shape, dtype=torch.float32, device=dev) for shape in _tail_grad_shapes(dims)]
+        self.g_fwd = self.g_bwd = None
+        self.ptrs = None
+        self.live = 0       # forward results whose backward has not run yet: the static buffers serve ONE autograd node at a time
+
+    def _detached(self):
+        return [p.detach() for p in self.params]
+
+    def forward(self):
+        ptrs = tuple(p.data_ptr() for p in self.params)
+        if self.g_fwd is None or ptrs != self.ptrs:     # first use, or a parameter's storage was replaced: (re)capture
+            self.ptrs, self.g_bwd = ptrs, None
+            with torch.no_grad():
+                _tail_weights_forward(self.dims, *self._detached())   # warm-up outside the capture (library handles, workspaces)
+                torch.cuda.current_stream().synchronize()
+                self.g_fwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
+                    self.outs, self.transposed, self.saved = _tail_weights_forward(self.dims, *self._detached())
+        self.g_fwd.replay()
+        return self.outs, self.transposed
+
+    def backward(self):
+        """Operand gradients in ``self.gin`` -> the 16 parameter gradients (static tensors, valid until the next call)."""
+        if self.g_bwd is None:
+            d = self._detached()
+            W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo = d[:10]
+            a_sum, M = self.saved
+            args = (self.dims, aw.numel(), b1, W2, b2, Wn, bn, Wo, a_sum, M, *self.gin, True)
+            with torch.no_grad():
+                keep = [g.clone() for g in self.gin]
+                _tail_weights_backward(*args)
+                torch.cuda.current_stream().synchronize()
+                self.g_bwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_bwd, capture_error_mode="thread_local"):
+                    self.pgrads = _tail_weights_backward(*args)
+                for g, k in zip(self.gin, keep):
+                    g.copy_(k)
+        self.g_bwd.replay()
+        return self.pgrads
+
+
+class _LiveToken:
+    """Marks a ``_TailWeightsGraph`` as in use from a forward until its backward has run, or until the autograd node is dropped."""
+
+    def __init__(self, tw):
+        self.tw = tw
+        tw.live += 1
+
+    def release(self):
+        if self.tw is not None:
+            self.tw.live -= 1
+            self.tw = None
+
+    __del__ = release
+
+
+class _TailWeightsReplay(torch.autograd.Function):
+    """Autograd face of ``_TailWeightsGraph``."""
+
+    @staticmethod
+    def forward(ctx, tw, *params):
+        outs, transposed = tw.forward()
+        ctx.tw = tw
+        ctx.token = _LiveToken(tw)
+        res = tuple(t.detach() for t in outs + transposed)   # fresh tensor objects over the static storage
+        ctx.mark_non_differentiable(*res[len(outs):])
+        return res
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tw = ctx.tw
+        for buf, g in zip(tw.gin, grads[:len(tw.gin)]):
+            if g is None:
+                buf.zero_()
+            elif g.data_ptr() != buf.data_ptr():
+                buf.copy_(g)
+        for p, g in zip(tw.params, tw.backward()):
+            if p.grad is None:
+                p.grad = g.detach()
+            else:
+                p.grad = p.grad + g      # out of place: an earlier contribution may be a broadcast view or shared with autograd
+        ctx.token.release()
+        return (None,) * (1 + len(tw.params))
 
 
 class _FusedTail(torch.autograd.Function):
@@ -183,7 +294,7 @@ class _FusedTail(torch.autograd.Function):
     ``cat2`` = [own | . ] arrive from the gather stage with their first block filled; the kernels write h1 / q / p1 into the rest."""
 
     @staticmethod
-    def forward(ctx, x_edge, x_pe, cat1, cat2, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp):
+    def forward(ctx, x_edge, x_pe, cat1, cat2, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt, grad_buffers):
         lib = nat.load_library()
         m = x_edge.shape[0]
         out = torch.empty((m, Wall.shape[0]), dtype=torch.float32, device=x_edge.device)
@@ -191,28 +302,30 @@ class _FusedTail(torch.autograd.Function):
         with torch.cuda.device(x_edge.device):
             nat.check(lib.lstep_tail_fwd(nat.ptr(x_edge), x_edge.stride(0), nat.ptr(x_pe), x_pe.stride(0), nat.ptr(cat1), nat.ptr(cat2),
                                          nat.ptr(out), *[nat.ptr(t) for t in ws], m, nat.current_stream()))
-        ctx.save_for_backward(x_edge, x_pe, cat1, cat2, ws[0], ws[2], ws[4], ws[6])
+        ctx.save_for_backward(x_edge, x_pe, cat1, cat2, w1t, wn1t, wqt, wallt)
+        ctx.grad_buffers = grad_buffers     # optional fixed [dW, db] x 4 destinations (``_TailWeightsGraph.gin``)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = nat.load_library()
-        x_edge, x_pe, cat1, cat2, W1p, Wn1p, Wq, Wall = ctx.saved_tensors
+        x_edge, x_pe, cat1, cat2, w1t, wn1t, wqt, wallt = ctx.saved_tensors
         m, dev = x_edge.shape[0], x_edge.device
         g_out = g_out.contiguous()
-        w1t, wn1t, wqt, wallt = W1p.t().contiguous(), Wn1p.t().contiguous(), Wq.t().contiguous(), Wall.t().contiguous()
+        Ce, Cp, Pp = w1t.shape[1], wn1t.shape[0], wqt.shape[1]
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
-        d_xe, d_xp, d_own = new(m, W1p.shape[1]), new(m, Wn1p.shape[1]), new(m, cat2.shape[1])
-        d_h1, d_p1, d_z = new(m, W1p.shape[0]), new(m, Wn1p.shape[0]), new(m, Wq.shape[0])
+        d_xe, d_xp, d_own = new(m, w1t.shape[0]), new(m, Cp), new(m, cat2.shape[1])
+        d_h1, d_p1, d_z = new(m, Ce), new(m, wn1t.shape[1]), new(m, Pp)
         with torch.cuda.device(dev):
             nat.check(lib.lstep_tail_bwd(nat.ptr(g_out), nat.ptr(cat1), nat.ptr(cat2), nat.ptr(w1t), nat.ptr(wn1t), nat.ptr(wqt), nat.ptr(wallt),
                                          nat.ptr(d_xe), nat.ptr(d_xp), nat.ptr(d_own), d_own.stride(0), nat.ptr(d_h1), nat.ptr(d_p1),
                                          nat.ptr(d_z), m, nat.current_stream()))
-        gW1, gb1 = nat.linear_wgrad(d_h1, x_edge[:, :W1p.shape[1]])
-        gWn1, gbn1 = nat.linear_wgrad(d_p1, x_pe[:, :Wn1p.shape[1]])
-        gWq, gbq = nat.linear_wgrad(d_z, cat2)
-        gWall, gconst = nat.linear_wgrad(g_out, cat1)
-        return d_xe, d_xp, None, d_own, gW1, gb1, gWn1, gbn1, gWq, gbq, gWall, gconst
+        gb = ctx.grad_buffers or [None] * 8
+        gW1, gb1 = nat.linear_wgrad(d_h1, x_edge[:, :w1t.shape[0]], out=(gb[0], gb[1]))
+        gWn1, gbn1 = nat.linear_wgrad(d_p1, x_pe[:, :Cp], out=(gb[2], gb[3]))
+        gWq, gbq = nat.linear_wgrad(d_z, cat2, out=(gb[4], gb[5]))
+        gWall, gconst = nat.linear_wgrad(g_out, cat1, out=(gb[6], gb[7]))
+        return d_xe, d_xp, None, d_own, gW1, gb1, gWn1, gbn1, gWq, gbq, gWall, gconst, None, None, None, None, None
 
 
 class _Head(torch.autograd.Function):
@@ -691,13 +804,25 @@ class LSTEP(nn.Module):
         columns stay exactly 0 through relu / tanh / residual, so results are unchanged."""
         Fd, P, D = self.feat_dim, self.pe_dim, self.time_dim
         Ce, Fn, Cp, Pp = self.ld_edge, self.ld_node, self.ld_pe, self.ld_self   # 16-aligned widths (272, 176, 272, 176)
-        W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp = _TailWeights.apply(
-            (Fd, D + Fd, P, P + D, Ce, Fn, Cp, Pp), self.edge_mlp_1.weight, self.edge_mlp_1.bias, self.edge_agg.weight, self.edge_agg.bias,
-            self.edge_mlp_2.weight, self.edge_mlp_2.bias, self.node_mlp.weight, self.node_mlp.bias, self.out_node_emb.weight,
-            self.out_node_emb.bias, self.self_update_neighbor_pe.weight, self.self_update_neighbor_pe.bias,
-            self.pe_neighbor_mlp_1.weight, self.pe_neighbor_mlp_1.bias, self.pe_neighbor_mlp_2.weight, self.pe_neighbor_mlp_2.bias)
+        dims = (Fd, D + Fd, P, P + D, Ce, Fn, Cp, Pp)
+        params = (self.edge_mlp_1.weight, self.edge_mlp_1.bias, self.edge_agg.weight, self.edge_agg.bias,
+                  self.edge_mlp_2.weight, self.edge_mlp_2.bias, self.node_mlp.weight, self.node_mlp.bias, self.out_node_emb.weight,
+                  self.out_node_emb.bias, self.self_update_neighbor_pe.weight, self.self_update_neighbor_pe.bias,
+                  self.pe_neighbor_mlp_1.weight, self.pe_neighbor_mlp_1.bias, self.pe_neighbor_mlp_2.weight, self.pe_neighbor_mlp_2.bias)
+        tw = None
+        if fused and x_edge.is_cuda and torch.is_grad_enabled() and os.environ.get("LSTEP_NO_GRAPH") != "1":
+            tw = self.__dict__.get("_tail_weight_graph")
+            if tw is None or tw.dims != dims or any(a is not b for a, b in zip(tw.params, params)):
+                tw = self.__dict__["_tail_weight_graph"] = _TailWeightsGraph(dims, params)
+            if tw.live > 0:       # a second call inside one autograd graph (reference-style loop: three calls per iteration): eager
+                tw = None
+        if tw is not None:
+            W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt = _TailWeightsReplay.apply(tw, *params)
+        else:
+            W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt = _TailWeights.apply(dims, *params)
         if fused:   # x_node / own are the wide [x_node | h1 | q] / [own | p1] buffers of the gather stage
-            return _FusedTail.apply(x_edge, x_pe, x_node, own, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp)
+            return _FusedTail.apply(x_edge, x_pe, x_node, own, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt,
+                                    tw.gin if tw is not None else None)
         h1 = fast_linear(x_edge, W1p, b1p, relu=True)                                          # [B, Ce]
         p1 = fast_linear(x_pe, Wn1p, bn1p, relu=True)                                          # [B, Pp]
         q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), Wq, bq))                # [B, Pp]

@@ -165,8 +165,11 @@ def test_tail_weight_composition_matches_autograd():
            torch.cat([_pad2(Ws, Pp, Pp), _pad2(Wn2, Pp, Pp)], 1), _pad1(bs + bn2, Pp),
            torch.cat([_pad2(wo_a @ wn_a, Fn, Fn), _pad2(M @ W2, Fn, Ce), _pad2(wo_b, Fn, Pp)], 1), _pad1(M @ b2 + wo_a @ bn + bo, Fn))
     got = _TailWeights.apply((Fd, C, P, CP, Ce, Fn, Cp, Pp), *params)
+    assert len(got) == 12                       # 8 operands + the 4 transposed matrices the backward kernel reads
     for x, y in zip(got, ref):
         np.testing.assert_allclose(x.detach().numpy(), y.detach().numpy(), rtol=0, atol=1e-6)
+    for t, src in zip(got[8:], (got[0], got[2], got[4], got[6])):
+        assert t.is_contiguous() and not t.requires_grad and torch.equal(t, src.detach().t())
     ws = [torch.randn_like(o) for o in ref]
     g_ref = torch.autograd.grad(sum((o * w).sum() for o, w in zip(ref, ws)), params)
     g_got = torch.autograd.grad(sum((o * w).sum() for o, w in zip(got, ws)), params)
