@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 11
+#define LSTEP_ABI_VERSION 12
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -240,6 +240,12 @@ int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float
  * w1 [176, 272], w2 / ws [176, 176], biases [176]. */
 int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* ws, const float* bs, float* table, int32_t pe_dim, void* stream);
+
+/* out[slot[i], :width] += rows[i, :width] for every i with slot[i] >= 0 (float atomics).  The stragglers of the spliced-row gradient:
+ * negative-sample rows whose own node happens to be a batch node (a few hundred per batch; everything else goes through the sorted,
+ * deterministic lstep_segment_rows_sum path). */
+int lstep_scatter_add_rows(float* out, int32_t width, int32_t ld_out, const int32_t* slot, int64_t n, const float* rows, int32_t ld_rows,
+                           void* stream);
 
 #ifdef __cplusplus
 }

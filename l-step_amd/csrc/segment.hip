@@ -123,6 +123,17 @@ __global__ __launch_bounds__(kBlock) void residual_tanh_rows_kernel(float* __res
     }
 }
 
+// out[slot[i], :W] += rows[i, :W] for the entries with slot[i] >= 0 (float atomics: for the few stragglers that are not worth a sort)
+__global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restrict__ out, int W, int ld_out, const int32_t* __restrict__ slot,
+                                                                   int64_t n, const float* __restrict__ rows, int ld_rows) {
+    const int lane = lane_id();
+    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (i >= n) return;
+    const int sl = slot[i];
+    if (sl < 0) return;
+    for (int c = lane; c < W; c += kWave) atomicAdd(out + (int64_t)sl * ld_out + c, rows[i * (int64_t)ld_rows + c]);
+}
+
 }  // namespace lstep
 
 using namespace lstep;
@@ -144,6 +155,17 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
                        time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate != 0);
     return check_launch("segment_rows_sum_kernel");
+}
+
+extern "C" int lstep_scatter_add_rows(float* out, int32_t width, int32_t ld_out, const int32_t* slot, int64_t n, const float* rows, int32_t ld_rows,
+                                      void* stream) {
+    if (n < 0 || width <= 0 || ld_out < width || ld_rows < width) return set_error(LSTEP_EINVAL, "lstep_scatter_add_rows: bad sizes");
+    if (n == 0) return LSTEP_OK;
+    if (!out || !slot || !rows) return set_error(LSTEP_EINVAL, "lstep_scatter_add_rows: NULL pointer");
+    const unsigned grid = (unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, out, (int)width, (int)ld_out, slot, n, rows,
+                       (int)ld_rows);
+    return check_launch("scatter_add_rows_kernel");
 }
 
 extern "C" int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* rows, void* stream) {

@@ -206,7 +206,8 @@ class LstepEngine:
         cur = ring.base_for_next()
         cur.index_copy_(0, batch_nodes, rows.detach())
         self.slot_of[batch_nodes] = torch.arange(batch_nodes.numel(), dtype=torch.int32, device=self.device)
-        return cur, SplicedRows(rows, self.slot_of)
+        # the engine's gather rows are cat[src, dst, neg]: their first 2B rows are the entries batch_nodes_and_segments grouped
+        return cur, SplicedRows(rows, self.slot_of, getattr(self, "_batch_groups", None))
 
     def _probabilities(self, a, b):
         return self.predictor(input_1=a, input_2=b).squeeze(dim=-1).sigmoid().clamp(0, 1)
@@ -224,6 +225,7 @@ class LstepEngine:
         rows = self.backbone.node_raw_features.shape[0]
         keys = torch.cat([src, dst]).to(torch.int32)
         _, order, seg, uniq, (n_unique, _, _) = nat.group_by_key(keys, max(1, int(rows).bit_length()), rows)
+        self._batch_groups = (seg, order)          # int32: the batch rows cat[src, dst] grouped by batch node = by spliced row
         return uniq[:n_unique].long(), (order.long(), seg.long(), None)
 
     # ---- train:204-311
@@ -292,11 +294,16 @@ class LstepEngine:
             except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
                 err.append(e)
 
-        th = threading.Thread(target=worker, name="lstep-update-pe")
-        th.start()
-        optimizer.zero_grad()
-        loss.backward()
-        th.join()
+        if os.environ.get("LSTEP_OVERLAP") == "inline":   # experiment: same streams, update_pe enqueued from this thread first
+            worker()
+            optimizer.zero_grad()
+            loss.backward()
+        else:
+            th = threading.Thread(target=worker, name="lstep-update-pe")
+            th.start()
+            optimizer.zero_grad()
+            loss.backward()
+            th.join()
         if err:
             raise err[0]
         main.wait_stream(side)
@@ -308,6 +315,7 @@ class LstepEngine:
     def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst):
         bb, ring = self.backbone, self.ring
         batch_nodes = torch.unique(torch.cat([src, dst]))
+        self._batch_groups = None
         cur, _ = self._splice(batch_nodes, batch_idx)
         self.slot_of[batch_nodes] = -1
         n = src.numel()

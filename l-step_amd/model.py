@@ -439,9 +439,12 @@ class SplicedRows:
     gather stage accumulates into ``[U, P]`` instead of a dense ``[N+1, P]`` buffer.
     """
 
-    def __init__(self, rows: torch.Tensor, slot_of: torch.Tensor):
+    def __init__(self, rows: torch.Tensor, slot_of: torch.Tensor, self_groups=None):
         self.rows = rows
         self.slot_of = slot_of
+        # optional (ent_seg, ent_row) int32: the leading rows of the next gather call, already grouped by spliced row (see
+        # ``_reduce_spliced_gradient``); only valid when those rows are exactly the entries the grouping was made from
+        self.self_groups = self_groups
 
 
 def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src_row_of, table: torch.Tensor, accumulate: bool):
@@ -464,16 +467,34 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
                                              n_hit, nat.ptr(out), P, 1 if accumulate else 0, nat.current_stream()))
 
 
-def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self):
+def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, self_groups=None):
     """Gradient of the spliced PE rows: every (row b, slot j) whose neighbour is spliced row u contributes g_pe[b, :P],
     every row b whose own node is spliced row u contributes g_self[b].  Grouped by u (``lstep_sort_live``) and reduced
-    by ``lstep_segment_rows_sum`` into one buffer: no atomics on hot (hub) rows, deterministic summation order."""
+    by ``lstep_segment_rows_sum`` into one buffer: no atomics on hot (hub) rows, deterministic summation order.
+    ``self_groups = (ent_seg, ent_row)`` (int32): the caller already knows the grouping of the first ``len(ent_row)`` rows by spliced
+    row (the engine's batch rows are cat[src, dst], grouped once per batch for the batch-node set): no second sort; the remaining
+    rows (negative samples, rarely batch nodes) are added with float atomics (``lstep_scatter_add_rows``)."""
+    lib = nat.load_library()
     K = hits.shape[1]
-    total = torch.zeros((num_rows, mod.pe_dim), dtype=torch.float32, device=hits.device)
+    P = mod.pe_dim
+    total = torch.zeros((num_rows, P), dtype=torch.float32, device=hits.device)
     if g_pe is not None:
         _segment_reduce_rows(mod, total, hits.reshape(-1), lambda o: (o // K).contiguous(), g_pe, accumulate=False)
-    if g_self is not None:
+    if g_self is None:
+        return total
+    if self_groups is None:
         _segment_reduce_rows(mod, total, self_slot.to(torch.int32), lambda o: o.contiguous(), g_self, accumulate=True)
+        return total
+    ent_seg, ent_row = self_groups
+    n_known = ent_row.numel()
+    with torch.cuda.device(hits.device):
+        nat.check(lib.lstep_segment_rows_sum(nat.ptr(g_self), P, int(g_self.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
+                                             n_known, nat.ptr(total), P, 1, nat.current_stream()))
+        rest = self_slot[n_known:].to(torch.int32).contiguous()
+        if rest.numel():
+            g_rest = g_self[n_known:]
+            nat.check(lib.lstep_scatter_add_rows(nat.ptr(total), P, P, nat.ptr(rest), rest.numel(), nat.ptr(g_rest), int(g_self.stride(0)),
+                                                 nat.current_stream()))
     return total
 
 
@@ -483,7 +504,7 @@ class _GatherAggregate(torch.autograd.Function):
     16-aligned K: hipBLASLt runs 176-wide fp32 GEMMs up to 2.5x faster than 172-wide ones (tools/gemm_shapes.py)."""
 
     @staticmethod
-    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False):
+    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False, self_groups=None):
         lib = nat.load_library()
         dev = ids.device
         B = ids.numel()
@@ -519,7 +540,7 @@ class _GatherAggregate(torch.autograd.Function):
         if sink is not None:
             e1.record()
             sink.append((e0, e1, count))
-        ctx.mod, ctx.sampler, ctx.K, ctx.branches, ctx.ld_self = mod, s, int(K), int(branches), ld_self
+        ctx.mod, ctx.sampler, ctx.K, ctx.branches, ctx.ld_self, ctx.self_groups = mod, s, int(K), int(branches), ld_self, self_groups
         ctx.pe_shape = tuple(pe.shape) if pe is not None else None
         ctx.rows_shape = tuple(rows.shape) if rows is not None else None
         ctx.save_for_backward(ids, times, count, slot_of if slot_of is not None else torch.empty(0, device=dev))
@@ -561,7 +582,7 @@ class _GatherAggregate(torch.autograd.Function):
                                                          nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
                                                          nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
         if use_slot:
-            grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self)
+            grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self, ctx.self_groups)
         g_w = slot_dot.sum(dim=0) if slot_dot is not None else None
         g_table = None
         if grad_rows is not None and not use_slot:
@@ -572,7 +593,7 @@ class _GatherAggregate(torch.autograd.Function):
         elif grad_rows is not None and g_pe is not None:
             # spliced mode: row 0 only has gradient if node 0 is itself a spliced row (never in the reference data)
             pass
-        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None, None)
+        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None, None, None)
 
 
 class _FftCoefficients(torch.autograd.Function):
@@ -749,7 +770,8 @@ class LSTEP(nn.Module):
         slot_of = spliced.slot_of if spliced is not None else None
         if slot_of is not None and (slot_of.dtype != torch.int32 or slot_of.numel() < self.neighbor_sampler.num_rows):
             raise ValueError("slot_of must be an int32 map with one entry per node id")
-        return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide)
+        return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide,
+                                      getattr(spliced, "self_groups", None))
 
     def _edge_node_tail(self, x_edge, x_node):
         """edge_mlp_1 -> edge_agg (reassociated) -> relu -> edge_mlp_2 ; node_mlp(cat[node, edge])  (models/LSTEP.py:161-170,219)."""

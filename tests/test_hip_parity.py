@@ -657,7 +657,7 @@ def test_fused_dense_kernels_match_library_path(hip, monkeypatch):
     (la, ga, ta, pa), (lb, gb, tb, pb) = results
     np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
     np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), rtol=0, atol=5e-6)
-    np.testing.assert_allclose(ta.cpu().numpy(), tb.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ta.cpu().numpy(), tb.cpu().numpy(), rtol=0, atol=5e-5)   # hub segments: float atomics, order varies
     assert set(ga) == set(gb) and len(ga) >= 20
     for name in ga:
         scale = max(1e-6, float(gb[name].abs().max()))
