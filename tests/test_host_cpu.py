@@ -176,3 +176,10 @@ def test_tail_weight_composition_matches_autograd():
     for i, (x, y) in enumerate(zip(g_got, g_ref)):
         assert x.shape == y.shape, i
         np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-4, atol=2e-5, err_msg=str(i))
+
+
+def test_graft_entry_build_runs():
+    """The driver's build hook: compiles (or finds up to date) the library, checks the ABI version, imports the package."""
+    import importlib
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
