@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 12
+#define LSTEP_ABI_VERSION 13
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -246,6 +246,14 @@ int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int6
  * deterministic lstep_segment_rows_sum path). */
 int lstep_scatter_add_rows(float* out, int32_t width, int32_t ld_out, const int32_t* slot, int64_t n, const float* rows, int32_t ld_rows,
                            void* stream);
+
+/* U2, row 0 -- what the PADDED slots of update_pe's sampled neighbourhoods scatter into row 0 (models/LSTEP.py:317-322):
+ *   sum_r (number of zero entries of nbr[r, :]) * table[ids[r], :width]
+ * as per-block partial sums partial [lstep_padding_rows_sum_blocks(n), width] (the caller adds them: fixed order, no atomics).
+ * nbr int64 [n, num_neighbors] (lstep_sample_recent's output), ids int64 [n] the source rows. */
+int64_t lstep_padding_rows_sum_blocks(int64_t n);
+int lstep_padding_rows_sum(const int64_t* nbr, int32_t num_neighbors, const int64_t* ids, int64_t n, const float* table, int32_t width,
+                           int32_t ld_table, float* partial, void* stream);
 
 #ifdef __cplusplus
 }

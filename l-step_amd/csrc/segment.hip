@@ -123,6 +123,42 @@ __global__ __launch_bounds__(kBlock) void residual_tanh_rows_kernel(float* __res
     }
 }
 
+// update_pe phase 2, row 0: every PADDED slot of the sampled neighbourhoods scatters cat[pe[source], 0] into row 0 (models/LSTEP.py:317-322:
+// the reference lets row 0 collect them like any other neighbour).  partial[blk, :] = sum over the block's source rows r of
+// (number of zero slots of nbr[r, :]) * table[ids[r], :W]; the caller adds the partials.  Rows without padding cost one ballot.
+constexpr int kPadRowsPerWave = 16;
+__global__ __launch_bounds__(kBlock) void padding_rows_sum_kernel(const int64_t* __restrict__ nbr, int K, const int64_t* __restrict__ ids, int64_t n,
+                                                                   const float* __restrict__ table, int W, int ld, float* __restrict__ partial) {
+    __shared__ float4 sh[kWavesPerBlock][kMaxRowVec];
+    const int lane = lane_id(), wave = wave_in_block();
+    const bool wa = lane < (W >> 2);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t r0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kPadRowsPerWave;
+    for (int64_t r = r0; r < r0 + kPadRowsPerWave && r < n; ++r) {
+        int zeros = 0;
+        for (int j0 = 0; j0 < K; j0 += kWave) {
+            const bool z = (j0 + lane < K) && nbr[r * K + j0 + lane] == 0;
+            zeros += __popcll(__ballot(z));
+        }
+        if (zeros == 0) continue;   // wave-uniform
+        if (wa) {
+            const float4 v = ld4(table + ids[r] * (int64_t)ld + lane * 4);
+            const float w = (float)zeros;
+            acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+        }
+    }
+    if (wa) sh[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && wa) {
+#pragma unroll
+        for (int w2 = 1; w2 < kWavesPerBlock; ++w2) {
+            const float4 v = sh[w2][lane];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        st4(partial + (int64_t)blockIdx.x * W + lane * 4, acc);
+    }
+}
+
 // out[slot[i], :W] += rows[i, :W] for the entries with slot[i] >= 0 (float atomics: for the few stragglers that are not worth a sort)
 __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restrict__ out, int W, int ld_out, const int32_t* __restrict__ slot,
                                                                    int64_t n, const float* __restrict__ rows, int ld_rows) {
@@ -155,6 +191,21 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
                        time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate != 0);
     return check_launch("segment_rows_sum_kernel");
+}
+
+extern "C" int64_t lstep_padding_rows_sum_blocks(int64_t n) {
+    return n <= 0 ? 0 : (n + kWavesPerBlock * kPadRowsPerWave - 1) / (kWavesPerBlock * kPadRowsPerWave);
+}
+
+extern "C" int lstep_padding_rows_sum(const int64_t* nbr, int32_t num_neighbors, const int64_t* ids, int64_t n, const float* table, int32_t width,
+                                      int32_t ld_table, float* partial, void* stream) {
+    if (n < 0 || num_neighbors <= 0 || width <= 0 || (width & 3) || width > 4 * kMaxRowVec || ld_table < width || (ld_table & 3))
+        return set_error(LSTEP_EINVAL, "lstep_padding_rows_sum: bad sizes");
+    if (n == 0) return LSTEP_OK;
+    if (!nbr || !ids || !table || !partial) return set_error(LSTEP_EINVAL, "lstep_padding_rows_sum: NULL pointer");
+    hipLaunchKernelGGL(padding_rows_sum_kernel, dim3((unsigned)lstep_padding_rows_sum_blocks(n)), dim3(kBlock), 0, (hipStream_t)stream, nbr,
+                       (int)num_neighbors, ids, n, table, (int)width, (int)ld_table, partial);
+    return check_launch("padding_rows_sum_kernel");
 }
 
 extern "C" int lstep_scatter_add_rows(float* out, int32_t width, int32_t ld_out, const int32_t* slot, int64_t n, const float* rows, int32_t ld_rows,

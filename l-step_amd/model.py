@@ -1071,10 +1071,14 @@ class LSTEP(nn.Module):
         if own_row0 and n_zero > 0:
             # row 0 collects cat[pe[source], 0] from every padded slot: a weighted column sum instead of a hot segment.
             # It goes first (ids are sorted): segment 0 has no entries and its aggregate is filled in afterwards.
-            zeros_per_row = (nbr == 0).sum(dim=1)                                       # slots that scatter into row 0
             touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
             agg2 = self._segment_sum(pe, nseg + 1, inverse + 1, ent_row, ent_dt)
-            agg2[0, :P] = (zeros_per_row.to(torch.float32).unsqueeze(1) * pe[bn]).sum(dim=0)
+            lib = nat.load_library()
+            part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(U)), P), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):   # sum over the rows of (their number of padded slots) * pe[source row]
+                nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), int(num_neighbors), nat.ptr(bn), U, nat.ptr(pe), P, int(pe.stride(0)),
+                                                     nat.ptr(part), nat.current_stream()))
+            agg2[0, :P] = part.sum(dim=0)
         else:
             agg2 = self._segment_sum(pe, nseg, inverse, ent_row, ent_dt)
         if fused:
