@@ -161,6 +161,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # Host hygiene before the timed region: move everything allocated so far (torch, the workload, the captured graphs: a few million
+    # tracked objects) out of the cyclic collector's reach.  A full collection otherwise lands inside the run about once per 60 steps
+    # and costs 35-50 ms (measured: tools/variance.py -- one 20-step block at 7-8 ms/step among blocks at 5.2).
+    import gc
+    gc.collect()
+    gc.freeze()
     sink = []
     model[0].gather_event_sink = sink
     barrier()
