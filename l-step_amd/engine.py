@@ -276,7 +276,7 @@ class LstepEngine:
                 optimizer.zero_grad()
                 loss.backward()
                 optimizer.step()
-                self.slot_of[batch_nodes] = -1
+                self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
             return out
 
         # update_pe (forward-only, reads and writes only the current PE table) and the backward pass (never reads that table)
@@ -305,7 +305,7 @@ class LstepEngine:
             raise err[0]
         main.wait_stream(side)
         optimizer.step()      # after update_pe has read its weights
-        self.slot_of[batch_nodes] = -1
+        self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
         return out
 
     # ---- evaluate_model_utils.py:38-142 (call under torch.no_grad())
@@ -314,7 +314,7 @@ class LstepEngine:
         batch_nodes = torch.unique(torch.cat([src, dst]))
         self._batch_groups = None
         cur, _ = self._splice(batch_nodes, batch_idx)
-        self.slot_of[batch_nodes] = -1
+        self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
         n = src.numel()
         emb = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_src, neg_dst]), torch.cat([ts, ts, ts, ts]), self.K, self.G)
         p_pos = self._probabilities(emb[:n], emb[n:2 * n])

@@ -1052,7 +1052,7 @@ class LSTEP(nn.Module):
         nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, num_neighbors)
         key = nbr.reshape(-1)
         rows = pe.shape[0]
-        pe[0] = 0.0
+        pe[0].zero_()
         real = key != 0
         if shard is not None:
             real = real & ((key % shard[0]) == shard[1])

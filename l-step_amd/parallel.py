@@ -308,7 +308,7 @@ class DistributedLstep:
             all_reduce_gradients(self._trainable, self.group)
             self._update_finish(pending)
             optimizer.step()
-            self.slot_of[bn] = -1
+            self.slot_of.index_fill_(0, bn, -1)
             # losses reported as global means (one collective for the three scalars)
             v = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
             all_reduce_sum(v, self.group)
@@ -322,7 +322,7 @@ class DistributedLstep:
         sl = slice(self.rank * b, (self.rank + 1) * b)
         bn = torch.unique(torch.cat([src, dst]))
         self._splice(bn, batch_idx)
-        self.slot_of[bn] = -1
+        self.slot_of.index_fill_(0, bn, -1)
         ids = torch.cat([src[sl], dst[sl], neg_src[sl], neg_dst[sl]])
         emb = self.bb.combining_pe_raw_feat(self.table, ids, torch.cat([ts[sl]] * 4), self.K, self.G)
         p_pos = self._probabilities(emb[:b], emb[b:2 * b])
