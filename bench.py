@@ -152,7 +152,10 @@ def main():
             neg_src = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
             with torch.no_grad():
                 return runner.eval_iteration(1000 + i, src, dst, ts, eid, neg_src, neg)
-        return runner.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg)
+        nxt = None
+        if lo + 2 * B * world <= wl.num_edges:     # the edge stream is known ahead: let the engine group the next batch's endpoints early
+            nxt = wl.stream.batch(lo + B * world, lo + 2 * B * world)[:2]
+        return runner.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg, lookahead=nxt)
 
     def barrier():
         if use_dist:

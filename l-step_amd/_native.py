@@ -207,9 +207,28 @@ def linear_wgrad(dy, x, want_bias: bool = True, out=None):
     return dw, db
 
 
-def group_by_key(keys, key_bits: int, limit: int):
+class PendingCounts:
+    """The three counts of a ``group_by_key(..., wait=False)`` call on their way to the host: a pinned buffer, an asynchronous copy and
+    an event recorded right behind it.  ``get()`` waits for THAT point of the stream only, not for whatever was enqueued later."""
+
+    def __init__(self, summary):
+        import torch
+
+        self.host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+        self.host.copy_(summary, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._keep = summary
+
+    def get(self):
+        self.event.synchronize()
+        return self.host.tolist()
+
+
+def group_by_key(keys, key_bits: int, limit: int, wait: bool = True):
     """``lstep_group_by_key`` on an int32 device tensor.  Returns (sorted_keys, order, seg, uniq, (n_unique, n_below, n_unique_below));
-    the three counts cost one host sync.  The scratch buffer is cached per device and grown on demand."""
+    the three counts cost one host sync (``wait=False``: a ``PendingCounts`` instead, read later with ``.get()``).
+    The scratch buffer is cached per device and grown on demand."""
     import torch
 
     lib = load_library()
@@ -225,4 +244,4 @@ def group_by_key(keys, key_bits: int, limit: int):
     with torch.cuda.device(dev):
         check(lib.lstep_group_by_key(ptr(keys), n, int(key_bits), int(limit), ptr(ws), ws.numel(), ptr(sorted_keys), ptr(order), ptr(seg),
                                      ptr(uniq), ptr(summary), current_stream()))
-    return sorted_keys, order, seg, uniq, summary.tolist()
+    return sorted_keys, order, seg, uniq, (summary.tolist() if wait else PendingCounts(summary))

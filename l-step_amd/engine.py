@@ -219,17 +219,35 @@ class LstepEngine:
             lab = self._label_cache = torch.cat([torch.ones(n, device=self.device), torch.zeros(n, device=self.device)])
         return lab
 
-    def batch_nodes_and_segments(self, src, dst):
-        """One native group-by-key of cat[src, dst] (``lstep_group_by_key``) gives the sorted unique batch nodes
-        (train:221-222) AND the per-node segments of update_pe phase 1 (entries grouped by receiving endpoint)."""
+    def _group_batch(self, src, dst, wait: bool):
         rows = self.backbone.node_raw_features.shape[0]
         keys = torch.cat([src, dst]).to(torch.int32)
-        _, order, seg, uniq, (n_unique, _, _) = nat.group_by_key(keys, max(1, int(rows).bit_length()), rows)
+        _, order, seg, uniq, counts = nat.group_by_key(keys, max(1, int(rows).bit_length()), rows, wait=wait)
+        return order, seg, uniq, counts
+
+    def batch_nodes_and_segments(self, src, dst):
+        """One native group-by-key of cat[src, dst] (``lstep_group_by_key``) gives the sorted unique batch nodes
+        (train:221-222) AND the per-node segments of update_pe phase 1 (entries grouped by receiving endpoint).
+        If ``prefetch_batch_nodes`` was called for exactly these tensors, its result is picked up: the only host wait is for the
+        prefetched counts, which were copied out long ago."""
+        pre = self.__dict__.pop("_prefetched_group", None)
+        if pre is not None and pre[0] == (src.data_ptr(), dst.data_ptr(), src.numel(), dst.numel()):
+            order, seg, uniq, counts = pre[1]
+            n_unique = counts.get()[0]
+        else:
+            order, seg, uniq, (n_unique, _, _) = self._group_batch(src, dst, wait=True)
         self._batch_groups = (seg, order)          # int32: the batch rows cat[src, dst] grouped by batch node = by spliced row
         return uniq[:n_unique].long(), (order.long(), seg.long(), None)
 
+    def prefetch_batch_nodes(self, src, dst):
+        """Group the NEXT batch's endpoints now (the edge stream is known ahead).  Its kernels queue up behind the current forward pass
+        and its counts travel to the host asynchronously, so the next ``train_iteration`` starts without draining the GPU: the host
+        can enqueue the next forward while the current backward is still running."""
+        self._prefetched_group = ((src.data_ptr(), dst.data_ptr(), src.numel(), dst.numel()), self._group_batch(src, dst, wait=False))
+
     # ---- train:204-311
-    def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):
+    def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
+        """``lookahead = (src, dst)`` of the next batch (optional): see ``prefetch_batch_nodes``."""
         bb, ring = self.backbone, self.ring
         out, loss = None, None
         batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)
@@ -261,6 +279,9 @@ class LstepEngine:
                 pe_loss = F.mse_loss(e_src, e_all[n:2 * n]) - self.neg_sample_weight * F.mse_loss(e_src, e_all[2 * n:])
                 loss = (1.0 - self.pe_weight) * lp_loss + self.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
+        if lookahead is not None:
+            self.prefetch_batch_nodes(*lookahead)
+
         def update_and_append():
             bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
                          node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G,

@@ -258,7 +258,7 @@ class DistributedLstep:
         self._append_snapshot()
 
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
-    def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None):
+    def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
         n_glob = src.numel()
         assert n_glob % self.W == 0, "global batch must divide by the world size"
         b = n_glob // self.W
