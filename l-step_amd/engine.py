@@ -197,6 +197,8 @@ class LstepEngine:
         self._update_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
         self.slot_of = torch.full((rows,), -1, dtype=torch.int32, device=dev)
         self.fused_loss = torch.device(dev).type == "cuda" and backbone.pe_dim % 4 == 0 and os.environ.get("LSTEP_TORCH_LOSS") != "1"
+        # the engine joins the auxiliary stream before every optimiser step, so the model may put its weight-gradient products there
+        backbone.aux_wgrad_stream = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
 
     # ---- shared pieces
     def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):
@@ -296,6 +298,7 @@ class LstepEngine:
             if loss is not None:
                 optimizer.zero_grad()
                 loss.backward()
+                bb.join_aux_stream()
                 optimizer.step()
                 self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
             return out
@@ -321,6 +324,7 @@ class LstepEngine:
         th.start()
         optimizer.zero_grad()
         loss.backward()
+        bb.join_aux_stream()
         th.join()
         if err:
             raise err[0]

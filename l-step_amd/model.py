@@ -207,6 +207,7 @@ class _TailWeightsGraph:
         self.g_fwd = self.g_bwd = None
         self.ptrs = None
         self.live = 0       # forward results whose backward has not run yet: the static buffers serve ONE autograd node at a time
+        self.aux = None     # stream the backward replay runs on (set per forward by LSTEP._combined_tail)
 
     def _detached(self):
         return [p.detach() for p in self.params]
@@ -274,6 +275,14 @@ class _TailWeightsReplay(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         tw = ctx.tw
+        aux = getattr(tw, "aux", None)
+        if aux is not None:      # the operand gradients were produced on the auxiliary stream: stay there
+            with torch.cuda.stream(aux):
+                return _TailWeightsReplay._backward(ctx, tw, grads)
+        return _TailWeightsReplay._backward(ctx, tw, grads)
+
+    @staticmethod
+    def _backward(ctx, tw, grads):
         for buf, g in zip(tw.gin, grads[:len(tw.gin)]):
             if g is None:
                 buf.zero_()
@@ -288,13 +297,26 @@ class _TailWeightsReplay(torch.autograd.Function):
         return (None,) * (1 + len(tw.params))
 
 
+_AUX_STREAMS = {}
+
+
+def _aux_stream(dev):
+    """Second stream for the weight-gradient products (matrix-core bound, no consumer inside the backward pass): they run beside the
+    HBM-bound rest of the backward (gather backward, gradient sorts, history filter backward) instead of in front of it."""
+    dev = torch.device(dev)
+    st = _AUX_STREAMS.get(dev)
+    if st is None:
+        st = _AUX_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class _FusedTail(torch.autograd.Function):
     """All dense layers after the gather stage as one launch per direction (``lstep_tail_fwd`` / ``lstep_tail_bwd``, fp32 matrix
     cores) plus four ``lstep_linear_wgrad`` products, instead of ~15 + ~40 library launches.  ``cat1`` = [x_node | . | .] and
     ``cat2`` = [own | . ] arrive from the gather stage with their first block filled; the kernels write h1 / q / p1 into the rest."""
 
     @staticmethod
-    def forward(ctx, x_edge, x_pe, cat1, cat2, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt, grad_buffers):
+    def forward(ctx, x_edge, x_pe, cat1, cat2, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt, grad_buffers, aux):
         lib = nat.load_library()
         m = x_edge.shape[0]
         out = torch.empty((m, Wall.shape[0]), dtype=torch.float32, device=x_edge.device)
@@ -304,6 +326,7 @@ class _FusedTail(torch.autograd.Function):
                                          nat.ptr(out), *[nat.ptr(t) for t in ws], m, nat.current_stream()))
         ctx.save_for_backward(x_edge, x_pe, cat1, cat2, w1t, wn1t, wqt, wallt)
         ctx.grad_buffers = grad_buffers     # optional fixed [dW, db] x 4 destinations (``_TailWeightsGraph.gin``)
+        ctx.aux = aux                       # optional stream for the weight-gradient products (only with grad_buffers)
         return out
 
     @staticmethod
@@ -321,11 +344,27 @@ class _FusedTail(torch.autograd.Function):
                                          nat.ptr(d_xe), nat.ptr(d_xp), nat.ptr(d_own), d_own.stride(0), nat.ptr(d_h1), nat.ptr(d_p1),
                                          nat.ptr(d_z), m, nat.current_stream()))
         gb = ctx.grad_buffers or [None] * 8
-        gW1, gb1 = nat.linear_wgrad(d_h1, x_edge[:, :w1t.shape[0]], out=(gb[0], gb[1]))
-        gWn1, gbn1 = nat.linear_wgrad(d_p1, x_pe[:, :Cp], out=(gb[2], gb[3]))
-        gWq, gbq = nat.linear_wgrad(d_z, cat2, out=(gb[4], gb[5]))
-        gWall, gconst = nat.linear_wgrad(g_out, cat1, out=(gb[6], gb[7]))
-        return d_xe, d_xp, None, d_own, gW1, gb1, gWn1, gbn1, gWq, gbq, gWall, gconst, None, None, None, None, None
+
+        def weight_gradients():
+            gW1, gb1 = nat.linear_wgrad(d_h1, x_edge[:, :w1t.shape[0]], out=(gb[0], gb[1]))
+            gWn1, gbn1 = nat.linear_wgrad(d_p1, x_pe[:, :Cp], out=(gb[2], gb[3]))
+            gWq, gbq = nat.linear_wgrad(d_z, cat2, out=(gb[4], gb[5]))
+            gWall, gconst = nat.linear_wgrad(g_out, cat1, out=(gb[6], gb[7]))
+            return gW1, gb1, gWn1, gbn1, gWq, gbq, gWall, gconst
+
+        if ctx.aux is not None:
+            # engine mode: the four products (and, right behind them, the replayed backward of the weight composition) go to the
+            # auxiliary stream; the caller joins it before the optimiser step (LSTEP.join_aux_stream)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(ctx.aux):
+                ctx.aux.wait_event(ready)
+                grads = weight_gradients()
+            for t in (d_h1, d_p1, d_z, g_out, x_edge, x_pe, cat1, cat2):
+                t.record_stream(ctx.aux)
+        else:
+            grads = weight_gradients()
+        return (d_xe, d_xp, None, d_own) + grads + (None,) * 6
 
 
 class _Head(torch.autograd.Function):
@@ -805,6 +844,12 @@ class LSTEP(nn.Module):
         # padded: the [B, 176] rows the kernels work on (columns >= 172 are 0), for lstep_head_fwd; default: the reference's [B, 172]
         return out if padded else out[:, :self.feat_dim]
 
+    def join_aux_stream(self):
+        """Make the current stream wait for the weight-gradient work that ``aux_wgrad_stream = True`` put on the auxiliary stream
+        (call after ``backward()`` and before anything reads the parameter gradients)."""
+        for dev, st in _AUX_STREAMS.items():     # keyed by the tensors' device (always indexed, unlike a bare "cuda")
+            torch.cuda.current_stream(dev).wait_stream(st)
+
     def _fused_tail_ok(self) -> bool:
         """The single-launch tail is compiled for the default widths (feature / PE dim 172, time dim 100); other shapes (and
         LSTEP_TORCH_TAIL=1, the A/B switch) take the library-GEMM tail."""
@@ -843,8 +888,11 @@ class LSTEP(nn.Module):
         else:
             W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt = _TailWeights.apply(dims, *params)
         if fused:   # x_node / own are the wide [x_node | h1 | q] / [own | p1] buffers of the gather stage
+            aux = _aux_stream(x_edge.device) if (tw is not None and self.__dict__.get("aux_wgrad_stream", False)) else None
+            if tw is not None:
+                tw.aux = aux
             return _FusedTail.apply(x_edge, x_pe, x_node, own, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt,
-                                    tw.gin if tw is not None else None)
+                                    tw.gin if tw is not None else None, aux)
         h1 = fast_linear(x_edge, W1p, b1p, relu=True)                                          # [B, Ce]
         p1 = fast_linear(x_pe, Wn1p, bn1p, relu=True)                                          # [B, Pp]
         q = own + torch.tanh(fast_linear(torch.cat([own, p1], dim=-1), Wq, bq))                # [B, Pp]

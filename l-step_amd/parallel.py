@@ -300,6 +300,7 @@ class DistributedLstep:
         if loss is not None:
             optimizer.zero_grad()
             (loss / self.W).backward()                       # global mean = mean of the rank means
+            self.bb.join_aux_stream()
             g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
             # every rank's loss touches every spliced row; each rank needs the summed gradient of the rows it owns
             g_mine = reduce_scatter_var(g_rows[owner_order].contiguous(), owner_counts, self.group)
