@@ -252,6 +252,7 @@ class LstepEngine:
         """``lookahead = (src, dst)`` of the next batch (optional): see ``prefetch_batch_nodes``."""
         bb, ring = self.backbone, self.ring
         out, loss = None, None
+        bb.prepare_step()
         batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)
         if batch_idx == 0:
             cur = ring.spare()

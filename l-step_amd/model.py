@@ -208,6 +208,7 @@ class _TailWeightsGraph:
         self.ptrs = None
         self.live = 0       # forward results whose backward has not run yet: the static buffers serve ONE autograd node at a time
         self.aux = None     # stream the backward replay runs on (set per forward by LSTEP._combined_tail)
+        self.prepared = None   # event of a forward replay issued ahead of time
 
     def _detached(self):
         return [p.detach() for p in self.params]
@@ -222,8 +223,22 @@ class _TailWeightsGraph:
                 self.g_fwd = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
                     self.outs, self.transposed, self.saved = _tail_weights_forward(self.dims, *self._detached())
-        self.g_fwd.replay()
+        if self.prepared is not None:        # replayed ahead of time on the auxiliary stream (LSTEP.prepare_step): just wait for it
+            torch.cuda.current_stream().wait_event(self.prepared)
+            self.prepared = None
+        else:
+            self.g_fwd.replay()
         return self.outs, self.transposed
+
+    def prepare(self, aux):
+        """Replay the forward graph on ``aux`` now (it only depends on the parameters); the next ``forward()`` waits for it."""
+        if self.g_fwd is None or tuple(p.data_ptr() for p in self.params) != self.ptrs or self.live > 0:
+            return
+        aux.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(aux):
+            self.g_fwd.replay()
+            self.prepared = torch.cuda.Event()
+            self.prepared.record()
 
     def backward(self):
         """Operand gradients in ``self.gin`` -> the 16 parameter gradients (static tensors, valid until the next call)."""
@@ -843,6 +858,14 @@ class LSTEP(nn.Module):
         out = self._combined_tail(x_edge, x_node, x_pe, own, fused)
         # padded: the [B, 176] rows the kernels work on (columns >= 172 are 0), for lstep_head_fwd; default: the reference's [B, 172]
         return out if padded else out[:, :self.feat_dim]
+
+    def prepare_step(self):
+        """Issue the parameter-only work of the next ``combining_pe_raw_feat`` (the replay of the dense tail's weight composition, ~25
+        small kernels) on the auxiliary stream now, so it runs beside the history filter and the gather stage instead of between the
+        gather stage and the dense tail.  Optional; call once per iteration, after the previous optimiser step."""
+        tw = self.__dict__.get("_tail_weight_graph")
+        if tw is not None and self.__dict__.get("aux_wgrad_stream", False) and torch.is_grad_enabled():
+            tw.prepare(_aux_stream(tw.params[0].device))
 
     def join_aux_stream(self):
         """Make the current stream wait for the weight-gradient work that ``aux_wgrad_stream = True`` put on the auxiliary stream
