@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 13
+#define LSTEP_ABI_VERSION 14
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -254,6 +254,18 @@ int lstep_scatter_add_rows(float* out, int32_t width, int32_t ld_out, const int3
 int64_t lstep_padding_rows_sum_blocks(int64_t n);
 int lstep_padding_rows_sum(const int64_t* nbr, int32_t num_neighbors, const int64_t* ids, int64_t n, const float* table, int32_t width,
                            int32_t ld_table, float* partial, void* stream);
+
+/* F, parameter side -- the real [T, P] coefficient table the history filter kernels consume (models/LSTEP.py:104-137 is linear in the
+ * history): coef[s, p] = Re(1/T sum_f m[f] W[f, p] e^{-2 pi i f s / T} sum_t a[t] m[t] e^{+2 pi i f t / T}), computed in complex128.
+ * filter_weight = fft_filter.weight as interleaved (re, im) float32 [T, P, 2]; agg_weight = fft_agg.weight float32 [T]; mask float64 [T]
+ * (1 on the valid leading snapshots while the window is not full, else all ones: models/LSTEP.py:108-113); c_out float64 [T, 2]
+ * receives the per-frequency factor c[f] the backward needs.  T <= 256. */
+int lstep_fft_coef_fwd(const float* filter_weight, const float* agg_weight, const double* mask, int32_t t_len, int32_t pe_dim, float* coef,
+                       double* c_out, void* stream);
+/* Gradients of the table: grad_filter (re, im) float32 [T, P, 2] (PyTorch's convention dL/dRe + i dL/dIm), grad_agg float32 [T];
+ * scratch float64 [T, 2]. */
+int lstep_fft_coef_bwd(const float* grad_coef, const float* filter_weight, const double* c, const double* mask, int32_t t_len, int32_t pe_dim,
+                       float* grad_filter, float* grad_agg, double* scratch, void* stream);
 
 #ifdef __cplusplus
 }

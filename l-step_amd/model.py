@@ -663,6 +663,18 @@ class _FftCoefficients(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, a_w, m, e_pos, e_neg_t, T):
+        ctx.native = bool(w.is_cuda and T <= 256 and os.environ.get("LSTEP_TORCH_FFTCOEF") != "1")
+        if ctx.native:      # one kernel (lstep_fft_coef_fwd) instead of ~12 complex128 framework launches
+            lib = nat.load_library()
+            wr = torch.view_as_real(w.detach().contiguous())
+            a32 = a_w.detach().reshape(-1).to(torch.float32).contiguous()
+            coef = torch.empty((T, w.shape[1]), dtype=torch.float32, device=w.device)
+            c = torch.empty((T, 2), dtype=torch.float64, device=w.device)
+            with torch.cuda.device(w.device):
+                nat.check(lib.lstep_fft_coef_fwd(nat.ptr(wr), nat.ptr(a32), nat.ptr(m), T, w.shape[1], nat.ptr(coef), nat.ptr(c), nat.current_stream()))
+            ctx.save_for_backward(wr, c, m)
+            ctx.T, ctx.a_shape = T, tuple(a_w.shape)
+            return coef
         am = (a_w.reshape(-1).to(torch.float64) * m).to(torch.complex128)
         big_a = e_pos @ am
         c = big_a * (m / T)                                       # [f] complex128
@@ -675,6 +687,18 @@ class _FftCoefficients(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.native:
+            lib = nat.load_library()
+            wr, c, m = ctx.saved_tensors
+            T, P = wr.shape[0], wr.shape[1]
+            g = g.contiguous()
+            g_w = torch.empty((T, P, 2), dtype=torch.float32, device=g.device)
+            g_a = torch.empty(T, dtype=torch.float32, device=g.device)
+            scratch = torch.empty((T, 2), dtype=torch.float64, device=g.device)
+            with torch.cuda.device(g.device):
+                nat.check(lib.lstep_fft_coef_bwd(nat.ptr(g), nat.ptr(wr), nat.ptr(c), nat.ptr(m), T, P, nat.ptr(g_w), nat.ptr(g_a), nat.ptr(scratch),
+                                                 nat.current_stream()))
+            return torch.view_as_complex(g_w), g_a.reshape(ctx.a_shape), None, None, None, None
         w128, c, m, e_pos, e_neg_t = ctx.saved_tensors
         gq = e_pos @ g.to(torch.complex128)                       # E-^H = E+
         g_w = (gq * c.conj().unsqueeze(1)).to(torch.complex64)

@@ -662,3 +662,34 @@ def test_fused_dense_kernels_match_library_path(hip, monkeypatch):
     for name in ga:
         scale = max(1e-6, float(gb[name].abs().max()))
         assert float((ga[name] - gb[name]).abs().max()) <= 2e-4 * scale + 1e-7, name
+
+
+@pytest.mark.parametrize("T,t_len,batch_idx", [(100, 100, 1000), (100, 37, 37), (6, 3, 3), (8, 8, 5)])
+def test_fft_coefficient_kernels_match_complex128_formulation(hip, monkeypatch, T, t_len, batch_idx):
+    """lstep_fft_coef_fwd / _bwd (coefficient table of the FFT filter and its gradient, one / two kernels) against the complex128
+    framework formulation, full and partially masked windows."""
+    from lstep_amd.model import _FftCoefficients
+    g = torch.Generator().manual_seed(T + t_len)
+    P = 172
+    w0 = torch.complex(torch.randn(T, P, generator=g), torch.randn(T, P, generator=g)).to(torch.complex64)
+    a0 = torch.randn(1, T, generator=g)
+    k = torch.arange(T, dtype=torch.float64, device=DEV)
+    ang = (2.0 * np.pi / T) * torch.outer(k, k)
+    e_pos = torch.polar(torch.ones_like(ang), ang)
+    e_neg_t = e_pos.conj().t().contiguous()
+    m = (k < batch_idx).to(torch.float64) if t_len < T else torch.ones(T, dtype=torch.float64, device=DEV)
+    gout = torch.randn(T, P, generator=g).to(DEV)
+    res = []
+    for torch_path in (False, True):
+        if torch_path:
+            monkeypatch.setenv("LSTEP_TORCH_FFTCOEF", "1")
+        else:
+            monkeypatch.delenv("LSTEP_TORCH_FFTCOEF", raising=False)
+        w = w0.clone().to(DEV).requires_grad_(True)
+        a = a0.clone().to(DEV).requires_grad_(True)
+        coef = _FftCoefficients.apply(w, a, m, e_pos, e_neg_t, T)
+        coef.backward(gout)
+        res.append((coef.detach().cpu().numpy(), torch.view_as_real(w.grad).cpu().numpy(), a.grad.cpu().numpy()))
+    for x, y in zip(*res):
+        scale = max(1.0, float(np.abs(y).max()))
+        np.testing.assert_allclose(x, y, rtol=0, atol=2e-6 * scale)
