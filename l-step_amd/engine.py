@@ -199,6 +199,7 @@ class LstepEngine:
         self.fused_loss = torch.device(dev).type == "cuda" and backbone.pe_dim % 4 == 0 and os.environ.get("LSTEP_TORCH_LOSS") != "1"
         # the engine joins the auxiliary stream before every optimiser step, so the model may put its weight-gradient products there
         backbone.aux_wgrad_stream = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
+        predictor.aux_wgrad_stream = backbone.aux_wgrad_stream
 
     # ---- shared pieces
     def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):

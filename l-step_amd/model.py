@@ -291,9 +291,12 @@ class _TailWeightsReplay(torch.autograd.Function):
     def backward(ctx, *grads):
         tw = ctx.tw
         aux = getattr(tw, "aux", None)
-        if aux is not None:      # the operand gradients were produced on the auxiliary stream: stay there
-            with torch.cuda.stream(aux):
-                return _TailWeightsReplay._backward(ctx, tw, grads)
+        if aux is not None:      # the operand gradients are produced on the auxiliary stream (postponed): queue up behind them
+            def on_aux():
+                with torch.cuda.stream(aux):
+                    _TailWeightsReplay._backward(ctx, tw, grads)
+            _defer(tw.params[0].device, on_aux)
+            return (None,) * (1 + len(tw.params))
         return _TailWeightsReplay._backward(ctx, tw, grads)
 
     @staticmethod
@@ -323,6 +326,23 @@ def _aux_stream(dev):
     if st is None:
         st = _AUX_STREAMS[dev] = torch.cuda.Stream(device=dev)
     return st
+
+
+_DEFERRED = {}     # device -> callables: auxiliary-stream work whose launch is postponed until the critical kernels are out
+
+
+def _defer(dev, fn):
+    _DEFERRED.setdefault(torch.device(dev), []).append(fn)
+
+
+def _flush_deferred(dev=None):
+    """Launch the postponed auxiliary-stream work (weight-gradient products, replayed weight-composition backward).  Called right
+    after the gather backward kernel has been launched -- the host work of these launches (~0.3 ms) would otherwise sit between the
+    dense tail's backward kernel and the gather backward kernel on the critical stream -- and, as a safety net, by ``join_aux_stream``."""
+    for d in ([torch.device(dev)] if dev is not None else list(_DEFERRED)):
+        q = _DEFERRED.get(d)
+        while q:
+            q.pop(0)()
 
 
 class _FusedTail(torch.autograd.Function):
@@ -369,14 +389,21 @@ class _FusedTail(torch.autograd.Function):
 
         if ctx.aux is not None:
             # engine mode: the four products (and, right behind them, the replayed backward of the weight composition) go to the
-            # auxiliary stream; the caller joins it before the optimiser step (LSTEP.join_aux_stream)
+            # auxiliary stream, and their launch is postponed (``_flush_deferred``); the destinations are the fixed buffers, so the
+            # gradients can be handed to autograd now.  The caller joins the stream before the optimiser step (LSTEP.join_aux_stream).
+            aux = ctx.aux
             ready = torch.cuda.Event()
             ready.record()
-            with torch.cuda.stream(ctx.aux):
-                ctx.aux.wait_event(ready)
-                grads = weight_gradients()
-            for t in (d_h1, d_p1, d_z, g_out, x_edge, x_pe, cat1, cat2):
-                t.record_stream(ctx.aux)
+
+            def on_aux():
+                with torch.cuda.stream(aux):
+                    aux.wait_event(ready)
+                    weight_gradients()
+                for t in (d_h1, d_p1, d_z, g_out, x_edge, x_pe, cat1, cat2):
+                    t.record_stream(aux)
+
+            _defer(dev, on_aux)
+            grads = tuple(gb)
         else:
             grads = weight_gradients()
         return (d_xe, d_xp, None, d_own) + grads + (None,) * 6
@@ -388,7 +415,7 @@ class _Head(torch.autograd.Function):
     backward that returns the gradient of all three blocks in one [3 n, 176] tensor."""
 
     @staticmethod
-    def forward(ctx, emb, fc1_w, fc1_b, fc2_w, fc2_b, n, layout):
+    def forward(ctx, emb, fc1_w, fc1_b, fc2_w, fc2_b, n, layout, aux=None):
         lib = nat.load_library()
         dev = emb.device
         half = fc1_w.shape[1] // 2                      # 172
@@ -407,6 +434,7 @@ class _Head(torch.autograd.Function):
                                          nat.ptr(logits), nat.current_stream()))
         ctx.save_for_backward(emb, wp, w2p, h)
         ctx.n, ctx.half, ctx.layout = n, half, tuple(layout)
+        ctx.aux, ctx.params = aux, (fc1_w, fc1_b, fc2_w, fc2_b)
         return logits
 
     @staticmethod
@@ -425,11 +453,32 @@ class _Head(torch.autograd.Function):
         with torch.cuda.device(dev):
             nat.check(lib.lstep_head_bwd(nat.ptr(d_logits), nat.ptr(h), n, nat.ptr(wt), nat.ptr(w2p), nat.ptr(d_emb), nat.ptr(d_h),
                                          nat.ptr(d_hsum), nat.ptr(dw2_part), nat.current_stream()))
-        g_first, _ = nat.linear_wgrad(d_hsum, emb[:n], want_bias=False)
-        g_second, g_b1 = nat.linear_wgrad(d_h, emb[n:3 * n])
-        g_fc1 = torch.cat([g_first[:half, :half], g_second[:half, :half]], dim=1)
-        g_w2 = dw2_part.sum(dim=0)[:half].reshape(1, half)
-        return d_emb, g_fc1, g_b1[:half], g_w2, d_logits.sum().reshape(1), None, None
+        def parameter_gradients():
+            g_first, _ = nat.linear_wgrad(d_hsum, emb[:n], want_bias=False)
+            g_second, g_b1 = nat.linear_wgrad(d_h, emb[n:3 * n])
+            g_fc1 = torch.cat([g_first[:half, :half], g_second[:half, :half]], dim=1)
+            g_w2 = dw2_part.sum(dim=0)[:half].reshape(1, half)
+            return g_fc1, g_b1[:half].contiguous(), g_w2, d_logits.sum().reshape(1)
+
+        aux = ctx.aux
+        if aux is None:
+            return (d_emb,) + parameter_gradients() + (None, None, None)
+        # engine mode: the predictor's parameter gradients are produced on the auxiliary stream, later (``_flush_deferred``), and
+        # assigned to .grad there
+        ready = torch.cuda.Event()
+        ready.record()
+        params = ctx.params
+
+        def on_aux():
+            with torch.cuda.stream(aux):
+                aux.wait_event(ready)
+                for p, g in zip(params, parameter_gradients()):
+                    p.grad = g if p.grad is None else p.grad + g
+            for t in (d_h, d_hsum, emb, h, d_logits, dw2_part):
+                t.record_stream(aux)
+
+        _defer(dev, on_aux)
+        return d_emb, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ small modules
@@ -473,7 +522,8 @@ class MergeLayer(nn.Module):
         """fc2(relu(fc1(cat[a, b]))) for the positive and the negative pair of every edge, read straight from the row blocks of the
         padded embeddings ``emb`` [rows, 176] (``lstep_head_fwd``); ``layout`` = row offsets (pos_first, pos_second, neg_first,
         neg_second).  Returns the 2 n logits (positive pairs first)."""
-        return _Head.apply(emb, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, int(n), tuple(int(x) for x in layout))
+        aux = _aux_stream(emb.device) if (self.__dict__.get("aux_wgrad_stream", False) and torch.is_grad_enabled()) else None
+        return _Head.apply(emb, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, int(n), tuple(int(x) for x in layout), aux)
 
     def fused_ok(self, emb: torch.Tensor) -> bool:
         return (emb.is_cuda and emb.shape[1] == 176 and tuple(self.fc1.weight.shape) == (172, 344) and tuple(self.fc2.weight.shape) == (1, 172)
@@ -635,6 +685,7 @@ class _GatherAggregate(torch.autograd.Function):
                                                          nat.ptr(g_self), mod.ld_edge, mod.ld_pe, ctx.ld_self,
                                                          nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
                                                          nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
+        _flush_deferred(dev)     # the critical kernel is out: now launch the postponed auxiliary-stream work
         if use_slot:
             grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self, ctx.self_groups)
         g_w = slot_dot.sum(dim=0) if slot_dot is not None else None
@@ -894,6 +945,7 @@ class LSTEP(nn.Module):
     def join_aux_stream(self):
         """Make the current stream wait for the weight-gradient work that ``aux_wgrad_stream = True`` put on the auxiliary stream
         (call after ``backward()`` and before anything reads the parameter gradients)."""
+        _flush_deferred()
         for dev, st in _AUX_STREAMS.items():     # keyed by the tensors' device (always indexed, unlike a bare "cuda")
             torch.cuda.current_stream(dev).wait_stream(st)
 
