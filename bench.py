@@ -148,13 +148,13 @@ def main():
         lo = start + i * B * world
         src, dst, ts, eid = wl.stream.batch(lo, lo + B * world)
         neg = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
-        if args.mode == "eval":
-            neg_src = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
-            with torch.no_grad():
-                return runner.eval_iteration(1000 + i, src, dst, ts, eid, neg_src, neg)
         nxt = None
         if lo + 2 * B * world <= wl.num_edges:     # the edge stream is known ahead: let the engine group the next batch's endpoints early
             nxt = wl.stream.batch(lo + B * world, lo + 2 * B * world)[:2]
+        if args.mode == "eval":
+            neg_src = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
+            with torch.no_grad():
+                return runner.eval_iteration(1000 + i, src, dst, ts, eid, neg_src, neg, lookahead=nxt)
         return runner.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg, lookahead=nxt)
 
     def barrier():

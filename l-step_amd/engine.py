@@ -336,19 +336,23 @@ class LstepEngine:
         return out
 
     # ---- evaluate_model_utils.py:38-142 (call under torch.no_grad())
-    def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst):
+    def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
         bb, ring = self.backbone, self.ring
-        batch_nodes = torch.unique(torch.cat([src, dst]))
+        batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)    # sorted unique, like the reference's torch.unique
         self._batch_groups = None
         cur, _ = self._splice(batch_nodes, batch_idx)
-        self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
+        self.slot_of.index_fill_(0, batch_nodes, -1)
         n = src.numel()
-        emb = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_src, neg_dst]), torch.cat([ts, ts, ts, ts]), self.K, self.G)
-        p_pos = self._probabilities(emb[:n], emb[n:2 * n])
-        p_neg = self._probabilities(emb[2 * n:3 * n], emb[3 * n:])
-        predicts = torch.cat([p_pos, p_neg], dim=0)
-        labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
+        emb_p = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_src, neg_dst]), torch.cat([ts, ts, ts, ts]), self.K, self.G, padded=True)
+        if self.predictor.fused_ok(emb_p):      # both predictor calls of evaluate_model_utils.py:100-101 in one launch, no concatenation
+            predicts = self.predictor.pair_logits(emb_p, n, (0, n, 2 * n, 3 * n)).sigmoid().clamp(0, 1)
+        else:
+            emb = emb_p[:, :bb.feat_dim]
+            predicts = torch.cat([self._probabilities(emb[:n], emb[n:2 * n]), self._probabilities(emb[2 * n:3 * n], emb[3 * n:])], dim=0)
+        labels = self._labels(n)
+        if lookahead is not None:
+            self.prefetch_batch_nodes(*lookahead)
         bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                     node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G)
+                     node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G, presorted=presorted)
         ring.commit()
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

@@ -317,7 +317,7 @@ class DistributedLstep:
         return out
 
     # ---- evaluate_model_utils.py:38-142 on a global batch (call under torch.no_grad())
-    def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst):
+    def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
         n_glob = src.numel()
         b = n_glob // self.W
         sl = slice(self.rank * b, (self.rank + 1) * b)
