@@ -234,7 +234,7 @@ class LstepEngine:
         If ``prefetch_batch_nodes`` was called for exactly these tensors, its result is picked up: the only host wait is for the
         prefetched counts, which were copied out long ago."""
         pre = self.__dict__.pop("_prefetched_group", None)
-        if pre is not None and pre[0] == (src.data_ptr(), dst.data_ptr(), src.numel(), dst.numel()):
+        if pre is not None and pre[0] == self._batch_key(src, dst):
             order, seg, uniq, counts = pre[1]
             n_unique = counts.get()[0]
         else:
@@ -246,11 +246,18 @@ class LstepEngine:
         """Group the NEXT batch's endpoints now (the edge stream is known ahead).  Its kernels queue up behind the current forward pass
         and its counts travel to the host asynchronously, so the next ``train_iteration`` starts without draining the GPU: the host
         can enqueue the next forward while the current backward is still running."""
-        self._prefetched_group = ((src.data_ptr(), dst.data_ptr(), src.numel(), dst.numel()), self._group_batch(src, dst, wait=False))
+        self._prefetched_group = (self._batch_key(src, dst), self._group_batch(src, dst, wait=False))
+
+    @staticmethod
+    def _batch_key(src, dst):
+        """Identity of a batch's endpoint tensors: same memory, same length, and not written since (version counters are shared by
+        all views of a buffer).  The prefetched grouping is only picked up for exactly these tensors."""
+        return (src.data_ptr(), dst.data_ptr(), src.numel(), dst.numel(), src._version, dst._version)
 
     # ---- train:204-311
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
-        """``lookahead = (src, dst)`` of the next batch (optional): see ``prefetch_batch_nodes``."""
+        """``lookahead = (src, dst)`` of the next batch (optional): see ``prefetch_batch_nodes``.  The grouping made from them is used by
+        the next call only if it receives the same (unmodified) tensors; otherwise it is recomputed."""
         bb, ring = self.backbone, self.ring
         out, loss = None, None
         bb.prepare_step()
