@@ -693,3 +693,45 @@ def test_fft_coefficient_kernels_match_complex128_formulation(hip, monkeypatch, 
     for x, y in zip(*res):
         scale = max(1.0, float(np.abs(y).max()))
         np.testing.assert_allclose(x, y, rtol=0, atol=2e-6 * scale)
+
+
+def test_engine_lookahead_and_streams_do_not_change_results(hip, monkeypatch):
+    """The engine's scheduling devices -- grouping the next batch ahead of time (lookahead), the auxiliary stream for parameter
+    gradients, the replayed weight composition, update_pe on its own thread -- against the plain serial schedule: same losses, same
+    PE tables, same final weights after 5 training iterations."""
+    from lstep_amd import synth
+    from lstep_amd.engine import EdgeStream, LstepEngine
+    from lstep_amd.optim import FusedAdam
+    from lstep_amd.sampler import NeighborSampler
+    from lstep_amd.smoke import build_hip_model
+    g = synth.make_temporal_graph(num_nodes=400, num_edges=8000, seed=9)
+    node_raw, edge_raw = synth.make_features(400, 8000, seed=9)
+    K, T, B = 20, 4, 256
+    out = []
+    for plain in (False, True):
+        for var in ("LSTEP_NO_GRAPH", "LSTEP_NO_AUX_STREAM", "LSTEP_NO_OVERLAP"):
+            if plain:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
+        sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=400, device=DEV)
+        model = build_hip_model(node_raw, edge_raw, sampler, K, T, synth.make_state_dict(K, T), DEV)
+        model.train()
+        eng = LstepEngine(model[0], model[1], K, 2000)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+        init = torch.from_numpy(synth.make_initial_pe(400, seed=9)).to(DEV)
+        losses = []
+        for b in range(6):
+            lo = 4000 + b * B
+            neg = torch.from_numpy(synth.make_negatives(400, B, seed=b)).to(DEV)
+            nxt = None if plain else stream.batch(lo + B, lo + 2 * B)[:2]
+            res = eng.train_iteration(opt, b, *stream.batch(lo, lo + B), neg, initial_pe=init, lookahead=nxt)
+            if res is not None:
+                losses.append([res["loss"].item(), res["lp_loss"].item(), res["pe_loss"].item()])
+        weights = torch.cat([torch.view_as_real(p.detach()).reshape(-1) if p.is_complex() else p.detach().reshape(-1) for p in model.parameters()])
+        out.append((np.array(losses), eng.ring.last().clone(), weights.clone()))
+    (la, ta, wa), (lb, tb, wb) = out
+    np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ta.cpu().numpy(), tb.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(wa.cpu().numpy(), wb.cpu().numpy(), rtol=0, atol=5e-5)     # Adam, lr 1e-3, 5 steps: sign-sensitive early on
