@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 14
+#define LSTEP_ABI_VERSION 15
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -131,8 +131,10 @@ int lstep_history_filter_bwd(const float* hist, int64_t node_stride, int64_t tim
  *   out[s, W:W+D] = sum_e cos(ent_dt[e] * time_w + time_b)            (time_dim D may be 0: no time part, ent_dt unused)
  * `out` (row stride ld_out) MUST be zero-initialised by the caller: rows that own no entry stay zero, and a segment that
  * straddles a 64-entry chunk boundary is accumulated with float atomics (long segments = hub nodes); all other
- * segments are plain stores summed in entry order (deterministic).  accumulate != 0: the sums are ADDED to what `out`
- * already holds (a second reduction into the same rows, e.g. neighbour + self gradients).  Uses:
+ * segments are plain stores summed in entry order (deterministic).  accumulate = 1: the sums are ADDED to what `out`
+ * already holds (a second reduction into the same rows, e.g. neighbour + self gradients).  accumulate = 2: `out` is UNINITIALISED
+ * memory and (width + time_dim) a multiple of 4 -- a pre-pass zeroes just the straddling segments' rows, every other row that owns
+ * entries is written whole, rows without entries stay undefined (update_pe: every row owns entries; saves a 356 MB memset).  Uses:
  *   update_pe U1/U2 (models/LSTEP.py:282-290, 319-322) with table = pe, D = time dim: replaces both dense [N+1, P+D]
  *   torch_scatter targets;  gather backward: table = grad of the PE aggregate, D = 0, segment = spliced PE row. */
 int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,

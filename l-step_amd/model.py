@@ -1057,16 +1057,22 @@ class LSTEP(nn.Module):
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
-    def _segment_sum(self, pe, nseg, ent_seg, ent_row, ent_dt):
-        """out[s] = sum over the entries of segment s of cat[pe[ent_row], time_feat(ent_dt)]  (lstep_segment_rows_sum);
-        rows are bucketed (``_bucket_rows``) and row-padded like the gather outputs, everything past the data is zero."""
+    def _segment_sum(self, pe, nseg, ent_seg, ent_row, ent_dt, exact: bool = False):
+        """out[s] = sum over the entries of segment s of cat[pe[ent_row], time_feat(ent_dt)]  (lstep_segment_rows_sum).
+        Library-GEMM consumers: rows are bucketed (``_bucket_rows``) and everything past the data is zero.  ``exact`` (the fused
+        ``lstep_update_rows`` consumer, which reads exactly ``nseg`` rows): no bucket rows and NO memset -- every segment owns entries, so
+        the kernel writes every row whole and zeroes only the rows it accumulates with atomics (356 MB less traffic in phase 2)."""
         lib = nat.load_library()
         P, D = self.pe_dim, self.time_dim
-        out = torch.zeros((self._bucket_rows(nseg), self.ld_pe), dtype=torch.float32, device=pe.device)
+        exact = exact and self.ld_pe == P + D
+        if exact:
+            out = torch.empty((nseg, self.ld_pe), dtype=torch.float32, device=pe.device)
+        else:
+            out = torch.zeros((self._bucket_rows(nseg), self.ld_pe), dtype=torch.float32, device=pe.device)
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_segment_rows_sum(nat.ptr(pe), P, P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
-                                                 nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), ent_row.numel(), nat.ptr(out), self.ld_pe, 0,
-                                                 nat.current_stream()))
+                                                 nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), ent_row.numel(), nat.ptr(out), self.ld_pe,
+                                                 2 if exact else 0, nat.current_stream()))
         return out
 
     MLP_ROW_BLOCK = 65536   # hipBLASLt's fp32 rate for these skinny GEMMs swings 50-115 TFLOP/s with M; 65536-row blocks sit at ~100 (tools/gemm_m.py)
@@ -1173,7 +1179,9 @@ class LSTEP(nn.Module):
             ids = ids[mine]
         if presorted is None or shard is not None:
             ent_seg, ent_row, ent_dt = ent_seg[keep_e], ent_row[keep_e], ent_dt[keep_e]
-        agg = self._segment_sum(pe, ids.numel(), ent_seg.to(torch.int32), ent_row.to(torch.int32), ent_dt.contiguous())
+        # exact (no memset) only when every listed node is known to own entries: the engine's presorted batch-node set
+        agg = self._segment_sum(pe, ids.numel(), ent_seg.to(torch.int32), ent_row.to(torch.int32), ent_dt.contiguous(),
+                                exact=fused and presorted is not None)
         n = ids.numel()
         if fused:   # MLP + self term + tanh + residual + in-place row write in one launch
             self._update_rows(pe, ids, agg, with_self=True)
@@ -1219,7 +1227,8 @@ class LSTEP(nn.Module):
             # row 0 collects cat[pe[source], 0] from every padded slot: a weighted column sum instead of a hot segment.
             # It goes first (ids are sorted): segment 0 has no entries and its aggregate is filled in afterwards.
             touched = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), touched])
-            agg2 = self._segment_sum(pe, nseg + 1, inverse + 1, ent_row, ent_dt)
+            agg2 = self._segment_sum(pe, nseg + 1, inverse + 1, ent_row, ent_dt, exact=fused)
+            agg2[0].zero_()          # segment 0 (row 0) has no entries of its own: its aggregate is the padding sum below
             lib = nat.load_library()
             part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(U)), P), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):   # sum over the rows of (their number of padded slots) * pe[source row]
@@ -1227,7 +1236,7 @@ class LSTEP(nn.Module):
                                                      nat.ptr(part), nat.current_stream()))
             agg2[0, :P] = part.sum(dim=0)
         else:
-            agg2 = self._segment_sum(pe, nseg, inverse, ent_row, ent_dt)
+            agg2 = self._segment_sum(pe, nseg, inverse, ent_row, ent_dt, exact=fused)
         if fused:
             self._update_rows(pe, touched, agg2, with_self=False)
             return touched
