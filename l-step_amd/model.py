@@ -152,8 +152,14 @@ def _tail_weights_backward(dims, K, b1, W2, b2, Wn, bn, Wo, a_sum, M, gW1p, gb1p
     d_Wo = torch.cat([dWo_a, dWo_b], dim=1)
     out = (gW1p[:C, :C], d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, dc, gWq[:P, :P], gbq[:P], gWn1p[:P, :CP],
            gbn1p[:P], gWq[:P, Pp:Pp + P], gbq[:P])
-    if dense:   # the graph path assigns these to .grad itself: dense, parameter-shaped, pairwise distinct storage (free inside a graph)
-        out = tuple(t.clone(memory_format=torch.contiguous_format) for t in out)
+    if dense:   # the graph path assigns these to .grad itself: dense, parameter-shaped, pairwise distinct storage
+        seen, res = set(), []
+        for t in out:
+            if not t.is_contiguous() or t.data_ptr() in seen:
+                t = t.clone(memory_format=torch.contiguous_format)
+            seen.add(t.data_ptr())
+            res.append(t)
+        out = tuple(res)
     return out
 
 
