@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 15
+#define LSTEP_ABI_VERSION 16
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -231,7 +231,7 @@ int lstep_head_fwd(const float* emb, int64_t n, int64_t pos_first, int64_t pos_s
  * three row blocks: directly the grad_out of lstep_tail_bwd), d_h [2 n, 176] (pre-activation gradient) and d_hsum [n, 176] =
  * d_h[pos] + d_h[neg], the dy operands of the weight gradient: dw[:, :176] = d_hsum^T emb[0:n], dw[:, 176:] = d_h^T emb[n:3n],
  * db1 = column sums of d_h (lstep_linear_wgrad); dw2_partial [ceil(n / 16), 176]: per-slab partial sums of d_logit * h, whose column
- * sums are the gradient of fc2.weight. */
+ * sums are the gradient of fc2.weight (columns 0..171) and, in column 172, the sum of d_logit = the gradient of fc2.bias. */
 int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float* wt, const float* w2, float* d_emb, float* d_h,
                    float* d_hsum, float* dw2_partial, void* stream);
 
@@ -268,6 +268,13 @@ int lstep_fft_coef_fwd(const float* filter_weight, const float* agg_weight, cons
  * scratch float64 [T, 2]. */
 int lstep_fft_coef_bwd(const float* grad_coef, const float* filter_weight, const double* c, const double* mask, int32_t t_len, int32_t pe_dim,
                        float* grad_filter, float* grad_agg, double* scratch, void* stream);
+
+/* c[i, j] = alpha * sum_k a[i, k] b[k, j] + beta * c[i, j] for weight-sized fp32 matrices (a few hundred rows / columns), with
+ * ELEMENT strides for every operand (a[i, k] at a + i * sa_i + k * sa_k, ...), so transposed and sliced views need no copy.
+ * One wave per 16 x 16 output tile on the fp32 matrix cores.  Used for the weight composition of the dense tail (out_node_emb .
+ * node_mlp . edge_mlp_2, models/LSTEP.py:170,219,264) and its backward. */
+int lstep_small_gemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c, int64_t sc_i,
+                     int64_t sc_j, int32_t m, int32_t n, int32_t k, float alpha, float beta, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 15
+ABI_VERSION = 16
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "lstep_sort_live": (C.c_int, [_P, _I64, _I32, _P, _I64, _P, _P, C.POINTER(C.c_int64), _P]),
     "lstep_linear_wgrad_workspace": (_I64, [_I64, _I32, _I32]),
     "lstep_linear_wgrad": (C.c_int, [_P, _I32, _P, _I32, _I64, _I32, _I32, _P, _I32, _P, _P, _I64, _P]),
+    "lstep_small_gemm": (C.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.c_float, C.c_float, _P]),
     "lstep_tail_fwd": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "lstep_tail_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),
 }
@@ -180,6 +181,24 @@ def sort_live(keys, key_bits: int):
             check(lib.lstep_sort_live(ptr(keys), n, int(key_bits), ptr(ws), ws.numel(), ptr(sorted_keys), ptr(order), C.byref(live),
                                       current_stream()))
     return sorted_keys, order, int(live.value)
+
+
+def small_mm(a, b, out=None, beta: float = 0.0):
+    """``a @ b`` (2-D fp32 device tensors, any strides) through ``lstep_small_gemm``; ``out`` (any strides) receives
+    ``a @ b + beta * out``.  For weight-sized operands: one wave per 16 x 16 output tile."""
+    import torch
+
+    lib = load_library()
+    m, k = a.shape
+    n = b.shape[1]
+    if b.shape[0] != k or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError("small_mm: fp32 [m, k] @ [k, n] expected")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib.lstep_small_gemm(ptr(a), a.stride(0), a.stride(1), ptr(b), b.stride(0), b.stride(1), ptr(out), out.stride(0), out.stride(1),
+                                   m, n, k, 1.0, float(beta), current_stream()))
+    return out
 
 
 def linear_wgrad(dy, x, want_bias: bool = True, out=None):

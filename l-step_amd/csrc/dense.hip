@@ -233,3 +233,66 @@ extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, 
                        pl.bias_off, dw, ld_dw, db);
     return check_launch("lstep_linear_wgrad");
 }
+
+// ---- small dense products between weight-sized matrices (<= a few hundred rows / columns): the weight composition of the dense
+// tail and its backward (model._TailWeights).  The library runs these 8 - 25 MFLOP products as ONE workgroup (53 - 60 us each); here
+// every 16 x 16 output tile is its own wave on the fp32 matrix cores.  General element strides, so transposes are free.
+namespace lstep {
+
+struct SmallGemmParams {
+    const float *a, *b;
+    float* c;
+    int32_t m, n, k;
+    int64_t sa_i, sa_k, sb_k, sb_j, sc_i, sc_j;
+    float alpha, beta;
+};
+
+__global__ __launch_bounds__(kBlock) void small_gemm_kernel(const SmallGemmParams p) {
+    const int lane = lane_id();
+    const int tiles_n = (p.n + 15) / 16;
+    const int tile = blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (tile >= tiles_n * ((p.m + 15) / 16)) return;
+    const int i0 = (tile / tiles_n) * 16, j0 = (tile % tiles_n) * 16;
+    const int r = lane & 15, q = lane >> 4;
+    const int ai = min(i0 + r, p.m - 1), bj = min(j0 + r, p.n - 1);   // clamped: out-of-range rows / columns are computed and dropped
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kSteps = 8;     // 8 k-steps (32 k values) of operands in flight: the loop is latency-bound otherwise
+    const float* pa = p.a + ai * p.sa_i;
+    const float* pb = p.b + bj * p.sb_j;
+    for (int k0 = 0; k0 < p.k; k0 += 4 * kSteps) {
+        float av[kSteps], bv[kSteps];
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) {
+            const int kk = k0 + 4 * u + q;
+            const bool ok = kk < p.k;
+            const int kc = ok ? kk : p.k - 1;
+            av[u] = pa[kc * p.sa_k];
+            bv[u] = pb[kc * p.sb_k];
+            if (!ok) av[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i = i0 + 4 * q + v, j = j0 + r;
+        if (i < p.m && j < p.n) {
+            float* dst = p.c + i * p.sc_i + j * p.sc_j;
+            *dst = p.beta == 0.f ? p.alpha * acc[v] : p.alpha * acc[v] + p.beta * *dst;
+        }
+    }
+}
+
+}  // namespace lstep
+
+extern "C" int lstep_small_gemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c, int64_t sc_i,
+                                int64_t sc_j, int32_t m, int32_t n, int32_t k, float alpha, float beta, void* stream) {
+    if (m < 0 || n < 0 || k < 0) return set_error(LSTEP_EINVAL, "lstep_small_gemm: negative size");
+    if (m == 0 || n == 0) return LSTEP_OK;
+    if (!c || (k > 0 && (!a || !b))) return set_error(LSTEP_EINVAL, "lstep_small_gemm: NULL pointer");
+    if (k == 0) return set_error(LSTEP_EINVAL, "lstep_small_gemm: empty contraction");
+    SmallGemmParams p{a, b, c, m, n, k, sa_i, sa_k, sb_k, sb_j, sc_i, sc_j, alpha, beta};
+    const int tiles = ((m + 15) / 16) * ((n + 15) / 16);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, p);
+    return check_launch("lstep_small_gemm");
+}

@@ -106,6 +106,13 @@ __global__ __launch_bounds__(kBlock, 1) void head_bwd_kernel(const HeadParams p)
             x += __shfl_xor(x, 1, kWave); x += __shfl_xor(x, 2, kWave); x += __shfl_xor(x, 4, kWave); x += __shfl_xor(x, 8, kWave);
             gw[v] = x;
         }
+        // the padded hidden columns are identically 0, so their slots of the partial row are free: column 172 carries the slab's
+        // sum of d_logit, the gradient of fc2.bias
+        if (16 * t + 4 * g == 172) {
+            float x = live ? dl[0] + dl[1] : 0.f;
+            x += __shfl_xor(x, 1, kWave); x += __shfl_xor(x, 2, kWave); x += __shfl_xor(x, 4, kWave); x += __shfl_xor(x, 8, kWave);
+            gw[0] = x;
+        }
         if (i == 0) *reinterpret_cast<f32x4*>(p.dw2_part + wave_id * kHd + 16 * t + 4 * g) = gw;
         dsum[t][0] = dh[t][0] + dh[t][1];
         if (live) *reinterpret_cast<f32x4*>(p.d_hsum + e * kHd + 16 * t + 4 * g) = dsum[t][0];

@@ -104,6 +104,17 @@ def fast_linear(x, w, b=None, relu=False):
     return _Linear.apply(x, w, b, relu)
 
 
+def _mm(a, b, out=None):
+    """Weight-sized product: the native one-wave-per-tile kernel on the GPU (the library runs these as a single workgroup, 50-60 us
+    each), torch.mm elsewhere."""
+    if a.is_cuda and os.environ.get("LSTEP_TORCH_SMALL_MM") != "1":
+        return nat.small_mm(a, b, out=out)
+    if out is None:
+        return a @ b
+    out.copy_(a @ b)
+    return out
+
+
 def _tail_weights_forward(dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2):
     """Padded / pre-multiplied weights of the dense tail (see ``_TailWeights``).  Returns (the 8 operands, their 4 transposes for the
     backward kernel, (a_sum, M) for the hand-derived backward)."""
@@ -124,9 +135,9 @@ def _tail_weights_forward(dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, 
     torch.add(bs, bn2, out=bq[:P])
     wo_a, wo_b = Wo[:, :Fd], Wo[:, Fd:]
     wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
-    M = wo_a @ wn_b                                           # [F, C]
-    Wall[:Fd, :Fd] = wo_a @ wn_a
-    Wall[:Fd, Fn:Fn + C] = M @ W2
+    M = _mm(wo_a, wn_b)                                       # [F, C]
+    _mm(wo_a, wn_a, out=Wall[:Fd, :Fd])
+    _mm(M, W2, out=Wall[:Fd, Fn:Fn + C])
     Wall[:Fd, Fn + Ce:Fn + Ce + P] = wo_b
     constp[:Fd] = torch.addmv(torch.addmv(bo, M, b2), wo_a, bn)
     transposed = (W1p.t().contiguous(), Wn1p.t().contiguous(), Wq.t().contiguous(), Wall.t().contiguous())
@@ -143,13 +154,22 @@ def _tail_weights_backward(dims, K, b1, W2, b2, Wn, bn, Wo, a_sum, M, gW1p, gb1p
     wo_a = Wo[:, :Fd]
     wn_a, wn_b = Wn[:, :Fd], Wn[:, Fd:]
     dA1, dA2, dWo_b, dc = gWall[:Fd, :Fd], gWall[:Fd, Fn:Fn + C], gWall[:Fd, Fn + Ce:Fn + Ce + P], gconst[:Fd]
-    dM = torch.addr(dA2 @ W2.t(), dc, b2)                     # from A2 = M W2 and const = M b2 + ...
-    d_W2 = M.t() @ dA2
+    dM = torch.addr(_mm(dA2, W2.t()), dc, b2)                 # from A2 = M W2 and const = M b2 + ...
+    d_W2 = _mm(M.t(), dA2)
     d_b2 = M.t() @ dc
-    dWo_a = torch.addr(dA1 @ wn_a.t() + dM @ wn_b.t(), dc, bn)
-    d_Wn = torch.cat([wo_a.t() @ dA1, wo_a.t() @ dM], dim=1)
+    d_Wo = torch.empty_like(Wo)
+    d_Wo[:, Fd:] = dWo_b
+    dWo_a = d_Wo[:, :Fd]
+    _mm(dA1, wn_a.t(), out=dWo_a)
+    if dM.is_cuda and os.environ.get("LSTEP_TORCH_SMALL_MM") != "1":
+        nat.small_mm(dM, wn_b.t(), out=dWo_a, beta=1.0)
+    else:
+        dWo_a += dM @ wn_b.t()
+    dWo_a.addr_(dc, bn)
+    d_Wn = torch.empty_like(Wn)
+    _mm(wo_a.t(), dA1, out=d_Wn[:, :Fd])
+    _mm(wo_a.t(), dM, out=d_Wn[:, Fd:])
     d_bn = wo_a.t() @ dc
-    d_Wo = torch.cat([dWo_a, dWo_b], dim=1)
     out = (gW1p[:C, :C], d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, dc, gWq[:P, :P], gbq[:P], gWn1p[:P, :CP],
            gbn1p[:P], gWq[:P, Pp:Pp + P], gbq[:P])
     if dense:   # the graph path assigns these to .grad itself: dense, parameter-shaped, pairwise distinct storage
@@ -463,8 +483,8 @@ class _Head(torch.autograd.Function):
             g_first, _ = nat.linear_wgrad(d_hsum, emb[:n], want_bias=False)
             g_second, g_b1 = nat.linear_wgrad(d_h, emb[n:3 * n])
             g_fc1 = torch.cat([g_first[:half, :half], g_second[:half, :half]], dim=1)
-            g_w2 = dw2_part.sum(dim=0)[:half].reshape(1, half)
-            return g_fc1, g_b1[:half].contiguous(), g_w2, d_logits.sum().reshape(1)
+            col = dw2_part.sum(dim=0)                        # [:172] d fc2.weight, [172] d fc2.bias (lstep_head_bwd)
+            return g_fc1, g_b1[:half].contiguous(), col[:half].reshape(1, half), col[half:half + 1]
 
         aux = ctx.aux
         if aux is None:

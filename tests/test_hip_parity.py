@@ -734,4 +734,28 @@ def test_engine_lookahead_and_streams_do_not_change_results(hip, monkeypatch):
     (la, ta, wa), (lb, tb, wb) = out
     np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
     np.testing.assert_allclose(ta.cpu().numpy(), tb.cpu().numpy(), rtol=0, atol=2e-5)
-    np.testing.assert_allclose(wa.cpu().numpy(), wb.cpu().numpy(), rtol=0, atol=5e-5)     # Adam, lr 1e-3, 5 steps: sign-sensitive early on
+    # Adam normalises every element's step to ~lr: an element whose gradient is rounding noise (the loss kernel's float atomics sum in
+    # varying order) may move by lr in either direction, so single elements can differ by a few lr after five steps
+    d = (wa - wb).abs()
+    assert float(d.max()) <= 5e-3 and float((d > 5e-5).float().mean()) <= 1e-3
+
+
+def test_small_gemm_vs_float64(hip):
+    """lstep_small_gemm (one wave per 16 x 16 tile, element strides) on transposed / sliced operands and accumulating outputs."""
+    from lstep_amd import _native as nat
+    g = torch.Generator().manual_seed(21)
+    for (m, n, k) in [(172, 272, 172), (172, 172, 172), (172, 272, 272), (5, 3, 7), (1, 33, 4), (40, 1, 100)]:
+        a = torch.randn(k, m + 3, generator=g).to(DEV)[:, 3:].t()            # [m, k]: transposed + offset view
+        b = torch.randn(k, 2 * n, generator=g).to(DEV)[:, ::2]               # [k, n]: strided columns
+        ref = a.double() @ b.double()
+        tol = 2e-6 * max(1.0, float(ref.abs().max()))
+        got = nat.small_mm(a, b)
+        assert float((got.double() - ref).abs().max()) <= tol
+        wide = torch.randn(m + 2, n + 5, generator=g).to(DEV)
+        view = wide[1:1 + m, 2:2 + n]
+        before = view.clone()
+        nat.small_mm(a, b, out=view, beta=1.0)                                # accumulate into a sub-block of a wider matrix
+        assert float((view.double() - (before.double() + ref)).abs().max()) <= tol
+        untouched = wide.clone()
+        untouched[1:1 + m, 2:2 + n] = 0
+        assert float(untouched[0].abs().max()) > 0 and torch.equal(wide[0], untouched[0]) and torch.equal(wide[:, :2], untouched[:, :2])
