@@ -175,10 +175,11 @@ class DistributedLstep:
         self.device = dev
         rows = self.bb.node_raw_features.shape[0]
         self.num_rows = rows
-        self.ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
+        self._ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
         self.table = torch.zeros((rows, self.bb.pe_dim), dtype=torch.float32, device=dev)  # replicated current PE
         self.slot_of = engine.slot_of
         engine.ring = None  # the unsharded ring is not used (and must not be allocated at scale)
+        self._copy_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
         # update_pe's layers are forward-only (no gradient ever reaches them): they stay out of the bucket
         frozen = {id(p) for m in (self.bb.pe_mlp_1, self.bb.pe_mlp_2, self.bb.self_update_pe) for p in m.parameters()}
         self._trainable = [p for p in list(self.bb.parameters()) + list(self.predictor.parameters()) if id(p) not in frozen]
@@ -191,12 +192,34 @@ class DistributedLstep:
             self.table.copy_(history[:, -1, :])
 
     def _append_snapshot(self):
-        self.ring.spare().copy_(self.table[self.rank::self.W])
-        self.ring.commit()
+        """This rank's rows of the finished table become the newest snapshot of its ring shard.  The strided copy (N / W rows of 688 B)
+        runs on a copy stream; the next history read waits for it (``_wait_snapshot``)."""
+        if self.table.is_cuda:
+            main = torch.cuda.current_stream(self.device)
+            self._copy_stream.wait_stream(main)
+            with torch.cuda.stream(self._copy_stream):
+                self._ring.spare().copy_(self.table[self.rank::self.W])
+            self.table.record_stream(self._copy_stream)
+            self._snapshot_pending = True
+        else:
+            self._ring.spare().copy_(self.table[self.rank::self.W])
+        self._ring.commit()
+
+    @property
+    def ring(self) -> HistoryRing:
+        """The ring shard, safe to read on the current stream (a pending snapshot copy is waited for first)."""
+        self._wait_snapshot()
+        return self._ring
+
+    def _wait_snapshot(self):
+        if getattr(self, "_snapshot_pending", False):
+            torch.cuda.current_stream(self.device).wait_stream(self._copy_stream)
+            self._snapshot_pending = False
 
     # ---- pieces
     def _splice(self, bn: torch.Tensor, batch_idx: int):
         """Owner-sharded FFT filter + all-gather of the filtered rows; returns (local rows with grad, leaf of all rows, perm)."""
+        self._wait_snapshot()
         owner = bn % self.W
         counts = torch.bincount(owner, minlength=self.W).tolist()      # every rank derives the same counts: no size exchange
         mine = bn[owner == self.rank]
@@ -263,6 +286,7 @@ class DistributedLstep:
         assert n_glob % self.W == 0, "global batch must divide by the world size"
         b = n_glob // self.W
         sl = slice(self.rank * b, (self.rank + 1) * b)
+        self.bb.prepare_step()
         bn, presorted = self.eng.batch_nodes_and_segments(src, dst)
         out, loss = None, None
         owner_counts = None
@@ -290,6 +314,8 @@ class DistributedLstep:
                 pe_loss = F.mse_loss(e_src, _lookup_rows(self.table, spliced, d_)) - self.eng.neg_sample_weight * F.mse_loss(e_src, _lookup_rows(self.table, spliced, n_))
                 loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
+        if lookahead is not None:
+            self.eng.prefetch_batch_nodes(*lookahead)      # the next global batch's endpoints, grouped while this one runs
         # update_pe: the all-gather of the phase-2 rows (the largest collective, ~0.7 KB per touched node) stays in flight
         # while the backward pass runs; neither reads what the other writes
         pending = self._update_start(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts)
