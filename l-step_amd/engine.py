@@ -295,7 +295,7 @@ class LstepEngine:
 
         def update_and_append():
             bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                         node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G,
+                         node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G,
                          presorted=presorted)
             if batch_idx == 0 and initial_pe is not None:
                 initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
@@ -360,6 +360,6 @@ class LstepEngine:
         if lookahead is not None:
             self.prefetch_batch_nodes(*lookahead)
         bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                     node_interact_times=ts, current_time=float(ts.max().item()), num_neighbors=self.K, time_gap=self.G, presorted=presorted)
+                     node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted)
         ring.commit()
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

@@ -1179,7 +1179,8 @@ class LSTEP(nn.Module):
         ``lstep_update_rows`` and returns ids only); ``shard=(W, r)`` restricts the work to
         nodes with id % W == r; ``presorted=(order, inverse, counts)`` reuses the caller's stable sort of cat[src, dst]
         (the engine derives the batch-node set and the segments from one sort; then ``bn`` must be that node set)."""
-        dt1 = (now32 - t).to(torch.float32)                       # float32 scalar - float64 -> float64 -> .float()
+        # float32 scalar - float64 -> float64 -> .float(); now32 may be a 0-d float32 device tensor (no host round trip)
+        dt1 = ((now32.to(torch.float64) if isinstance(now32, torch.Tensor) else now32) - t).to(torch.float32)
         if presorted is None:
             keys_s, order = torch.sort(torch.cat([src, dst]), stable=True)
             nodes, inverse, counts = torch.unique_consecutive(keys_s, return_inverse=True, return_counts=True)
@@ -1246,7 +1247,7 @@ class LSTEP(nn.Module):
         inverse = seg[:n_real]
         touched = uniq[:nseg].long()
         ent_row = bn[src_e // num_neighbors].to(torch.int32)
-        now_t = torch.tensor(now32, dtype=torch.float32, device=dev)
+        now_t = now32 if isinstance(now32, torch.Tensor) else torch.tensor(now32, dtype=torch.float32, device=dev)
         ent_dt = now_t - nt.reshape(-1)[src_e]                   # float32 - float32 (LSTEP.py:314)
         nseg = touched.numel()
         if own_row0 and n_zero > 0:
@@ -1279,7 +1280,9 @@ class LSTEP(nn.Module):
         bn = self._ids(node_ids)
         src, dst = self._ids(batch_src_node_ids), self._ids(batch_dst_node_ids)
         t = self._times(node_interact_times)
-        now32 = float(np.float32(current_time))  # torch.Tensor([current_time]) rounds to float32 first (LSTEP.py:277)
+        # torch.Tensor([current_time]) rounds to float32 first (LSTEP.py:277); a tensor current_time (e.g. ts.max()) stays on the device
+        now32 = current_time.detach().to(device=pe.device, dtype=torch.float32).reshape(()) if isinstance(current_time, torch.Tensor) \
+            else float(np.float32(current_time))
         if self._fused_tail_ok() and os.environ.get("LSTEP_TORCH_UPDATE") != "1":
             self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted, fused=True)
             self.update_pe_phase2(pe, bn, t, now32, num_neighbors, fused=True)

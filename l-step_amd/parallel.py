@@ -252,7 +252,7 @@ class DistributedLstep:
         """Phase 1 completely (its rows feed phase 2), phase 2 up to the all-gather of its rows, which is left in flight.
         Fused path (default widths): every rank updates the rows it owns IN PLACE (``lstep_update_rows``) and the new rows are
         all-gathered; library path: the pre-activation rows z are gathered and every replica applies pe += tanh(z)."""
-        now32 = float(np.float32(float(ts.max().item())))
+        now32 = ts.max().to(torch.float32)       # torch.Tensor([current_time]) of the reference: float32-rounded, kept on the device
         shard = (self.W, self.rank)
         P = self.bb.pe_dim
         fused = self.bb._fused_tail_ok() and os.environ.get("LSTEP_TORCH_UPDATE") != "1"

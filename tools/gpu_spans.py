@@ -33,6 +33,35 @@ def backward(self, *a, **k):
     return r
 
 
+from lstep_amd import model as M
+orig_join = M.LSTEP.join_aux_stream
+tails = []
+
+
+def join_aux(self):
+    M._flush_deferred()
+    # where the other two streams are when the critical stream has finished its backward kernels
+    e_main = torch.cuda.Event(enable_timing=True); e_main.record()
+    e_aux = torch.cuda.Event(enable_timing=True); e_aux.record(M._aux_stream(dev))
+    tails.append((e_main, e_aux, None))
+    return orig_join(self)
+
+
+M.LSTEP.join_aux_stream = join_aux
+orig_tjoin = threading.Thread.join
+
+
+def tjoin(self, *a, **k):
+    r = orig_tjoin(self, *a, **k)
+    if self.name == "lstep-update-pe" and tails:
+        e_upd = torch.cuda.Event(enable_timing=True); e_upd.record(eng._update_stream)
+        tails[-1] = (tails[-1][0], tails[-1][1], e_upd)
+    return r
+
+
+threading.Thread.join = tjoin
+
+
 def step(self):
     ev("before_adam")
     r = orig_step(self)
@@ -55,7 +84,7 @@ def run(i):
 for i in range(5):
     run(i)
 torch.cuda.synchronize()
-marks.clear()
+marks.clear(); tails.clear()
 import gc; gc.collect(); gc.freeze()
 for i in range(iters):
     run(5 + i)
@@ -71,3 +100,6 @@ for k, v in acc.items():
     print(f"  {k:28s} {v / iters:7.3f} ms (GPU time between the two points of the critical stream)")
     tot += v / iters
 print(f"  sum {tot:.3f} ms")
+aux = sum(a.elapsed_time(b) for a, b, c in tails) / len(tails)
+upd = sum(a.elapsed_time(c) for a, b, c in tails if c is not None) / max(1, sum(1 for t in tails if t[2] is not None))
+print(f"  after the critical stream's last backward kernel: auxiliary stream finishes {aux:+.3f} ms later, update stream {upd:+.3f} ms later")
