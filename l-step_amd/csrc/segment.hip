@@ -102,15 +102,16 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
 
 // Pre-pass for an UNINITIALISED output: only the rows of segments that straddle a chunk boundary are accumulated with atomics and need
 // zeros; every other row that owns entries is written whole by one wave.  One thread per chunk boundary.
-__global__ void segment_zero_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t num_entries, float* __restrict__ out, int ld_out,
-                                               int width) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;      // boundary between chunk c - 1 and chunk c
+__global__ __launch_bounds__(kBlock) void segment_zero_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t num_entries,
+                                                                         float* __restrict__ out, int ld_out, int width) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block() + 1;   // boundary between chunk c - 1 and chunk c: one wave each
     const int64_t e = c * kChunk;
     if (e >= num_entries) return;
     const int sg = ent_seg[e];
     if (ent_seg[e - 1] != sg) return;
     float* o = out + (int64_t)sg * ld_out;
-    for (int k = 0; k < width; k += 4) st4(o + k, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int k = lane * 4; k < width; k += kWave * 4) st4(o + k, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(float* __restrict__ table, int W, const int64_t* __restrict__ ids,
@@ -202,8 +203,8 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     if (accumulate == 2 && chunks > 1)   // uninitialised output: zero just the rows the atomics will add to
-        hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3((unsigned)((chunks - 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ent_seg,
-                           num_entries, out, (int)ld_out, (int)(width + time_dim));
+        hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3((unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, ent_seg, num_entries, out, (int)ld_out, (int)(width + time_dim));
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
                        time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1);
     return check_launch("segment_rows_sum_kernel");
