@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 16
+#define LSTEP_ABI_VERSION 17
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -275,6 +275,22 @@ int lstep_fft_coef_bwd(const float* grad_coef, const float* filter_weight, const
  * node_mlp . edge_mlp_2, models/LSTEP.py:170,219,264) and its backward. */
 int lstep_small_gemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c, int64_t sc_i,
                      int64_t sc_j, int32_t m, int32_t n, int32_t k, float alpha, float beta, void* stream);
+
+/* U1 / U2 -- the message lists of update_pe, one kernel each (models/LSTEP.py:277-290, 305-324).
+ * _p1: order int32 [num_entries <= 2 batch] = positions of cat[src, dst] grouped by receiving endpoint (lstep_group_by_key);
+ *      ent_row[e] = the other endpoint, ent_dt[e] = float(double(now32) - times[.]) with now32 a float32 DEVICE scalar (the reference
+ *      rounds the current time to float32 first, LSTEP.py:277).
+ * _keys_p2: int32 keys of the sampled neighbour slots nbr int64 [n]: the neighbour id, or `sentinel` for padding slots (id 0) and, when
+ *      world > 1, for neighbours owned by another rank (id % world != rank).
+ * _p2: for the n_real grouped live slots (order / seg from lstep_group_by_key on those keys): ent_row = bn[slot / K], ent_dt = now32 -
+ *      nt[slot] (float32 - float32, LSTEP.py:314), ent_seg = seg + shift; touched int64 [shift + nseg] = [0 if shift] + uniq[:nseg]
+ *      (shift = 1 when padding slots exist: row 0 is updated too and takes segment 0, LSTEP.py:317-324). */
+int lstep_update_entries_p1(const int32_t* order, int64_t num_entries, const int64_t* src, const int64_t* dst, const double* times,
+                            const float* now32, int64_t batch, int32_t* ent_row, float* ent_dt, void* stream);
+int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank, int32_t* keys, void* stream);
+int lstep_update_entries_p2(const int32_t* order, const int32_t* seg, int64_t n_real, const int64_t* bn, const float* nt, const float* now32,
+                            int32_t num_neighbors, int32_t shift, const int32_t* uniq, int64_t nseg, int32_t* ent_row, float* ent_dt,
+                            int32_t* ent_seg, int64_t* touched, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
-SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip"]
+SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip", "update.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 16
+ABI_VERSION = 17
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -87,6 +87,9 @@ SIGNATURES = {
     "lstep_padding_rows_sum_blocks": (_I64, [_I64]),
     "lstep_padding_rows_sum": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _I32, _P, _P]),
     "lstep_scatter_add_rows": (C.c_int, [_P, _I32, _I32, _P, _I64, _P, _I32, _P]),
+    "lstep_update_entries_p1": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "lstep_update_keys_p2": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
+    "lstep_update_entries_p2": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_update_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "lstep_head_fwd": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_bwd": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),

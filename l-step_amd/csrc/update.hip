@@ -1,0 +1,90 @@
+// update_pe's message lists (models/LSTEP.py:277-290, 305-324) built on the device in one kernel each, instead of a dozen framework
+// index / cat / cast launches per phase (each of which queues behind the backward pass's big kernels on the update stream).
+//   phase 1: every batch edge sends cat[pe[other endpoint], time_feat(now - t)] to both endpoints; the entries are the positions of
+//            cat[src, dst] grouped by receiving endpoint (lstep_group_by_key's `order`).
+//   phase 2: every sampled neighbour slot (row r of the batch-node set, slot j) sends cat[pe[bn[r]], time_feat(now - nt[r, j])] to the
+//            neighbour; slots with neighbour 0 are padding (they feed row 0, lstep_padding_rows_sum).
+#include "lstep_common.h"
+
+namespace lstep {
+
+// ent_row[e] = the OTHER endpoint of entry order[e] of cat[src, dst];  ent_dt[e] = float(double(now32) - t)   (LSTEP.py:277: float32 now)
+__global__ void update_entries_p1_kernel(const int32_t* __restrict__ order, int64_t n2, const int64_t* __restrict__ src,
+                                         const int64_t* __restrict__ dst, const double* __restrict__ t, const float* __restrict__ now32,
+                                         int64_t b, int32_t* __restrict__ ent_row, float* __restrict__ ent_dt) {
+    const double now = (double)now32[0];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = order[e];
+        const bool first = o < b;                    // entry of src: the message comes from dst
+        const int64_t i = first ? o : o - b;
+        ent_row[e] = (int32_t)(first ? dst[i] : src[i]);
+        ent_dt[e] = (float)(now - t[i]);
+    }
+}
+
+// keys[i] = nbr[i] if it is a real neighbour owned by this shard, else `sentinel` (sorts last, dropped by lstep_group_by_key's limit)
+__global__ void update_keys_p2_kernel(const int64_t* __restrict__ nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank,
+                                      int32_t* __restrict__ keys) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = nbr[i];
+        const bool real = k != 0 && (world <= 1 || (k % world) == rank);
+        keys[i] = real ? (int32_t)k : sentinel;
+    }
+}
+
+// for the n_real leading (grouped) slots: source row, time delta (float32 - float32, LSTEP.py:314), segment (+ shift when row 0 takes
+// segment 0); and the touched-row list: [0 if shift] + uniq[:nseg]
+__global__ void update_entries_p2_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ seg, int64_t n_real,
+                                         const int64_t* __restrict__ bn, const float* __restrict__ nt, const float* __restrict__ now32, int32_t k,
+                                         int32_t shift, const int32_t* __restrict__ uniq, int64_t nseg, int32_t* __restrict__ ent_row,
+                                         float* __restrict__ ent_dt, int32_t* __restrict__ ent_seg, int64_t* __restrict__ touched) {
+    const float now = now32[0];
+    const int64_t total = n_real > nseg ? n_real : nseg;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < n_real) {
+            const int64_t o = order[e];
+            ent_row[e] = (int32_t)bn[o / k];
+            ent_dt[e] = now - nt[o];
+            ent_seg[e] = seg[e] + shift;
+        }
+        if (e < nseg) touched[shift + e] = uniq[e];
+        if (e == 0 && shift) touched[0] = 0;
+    }
+}
+
+static unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+}  // namespace lstep
+
+using namespace lstep;
+
+extern "C" int lstep_update_entries_p1(const int32_t* order, int64_t num_entries, const int64_t* src, const int64_t* dst, const double* times,
+                                       const float* now32, int64_t batch, int32_t* ent_row, float* ent_dt, void* stream) {
+    if (num_entries < 0 || batch < 0 || num_entries > 2 * batch) return set_error(LSTEP_EINVAL, "lstep_update_entries_p1: bad sizes");
+    if (num_entries == 0) return LSTEP_OK;
+    if (!order || !src || !dst || !times || !now32 || !ent_row || !ent_dt) return set_error(LSTEP_EINVAL, "lstep_update_entries_p1: NULL pointer");
+    hipLaunchKernelGGL(update_entries_p1_kernel, dim3(grid_for(num_entries)), dim3(256), 0, (hipStream_t)stream, order, num_entries, src, dst, times,
+                       now32, batch, ent_row, ent_dt);
+    return check_launch("update_entries_p1_kernel");
+}
+
+extern "C" int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank, int32_t* keys, void* stream) {
+    if (n < 0 || world < 1 || rank < 0 || rank >= world) return set_error(LSTEP_EINVAL, "lstep_update_keys_p2: bad sizes");
+    if (n == 0) return LSTEP_OK;
+    if (!nbr || !keys) return set_error(LSTEP_EINVAL, "lstep_update_keys_p2: NULL pointer");
+    hipLaunchKernelGGL(update_keys_p2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, nbr, n, sentinel, world, rank, keys);
+    return check_launch("update_keys_p2_kernel");
+}
+
+extern "C" int lstep_update_entries_p2(const int32_t* order, const int32_t* seg, int64_t n_real, const int64_t* bn, const float* nt,
+                                       const float* now32, int32_t num_neighbors, int32_t shift, const int32_t* uniq, int64_t nseg, int32_t* ent_row,
+                                       float* ent_dt, int32_t* ent_seg, int64_t* touched, void* stream) {
+    if (n_real < 0 || nseg < 0 || num_neighbors <= 0 || shift < 0 || shift > 1) return set_error(LSTEP_EINVAL, "lstep_update_entries_p2: bad sizes");
+    if (n_real == 0 && nseg == 0 && !shift) return LSTEP_OK;
+    if (!now32 || !touched || (n_real > 0 && (!order || !seg || !bn || !nt || !ent_row || !ent_dt || !ent_seg)) || (nseg > 0 && !uniq))
+        return set_error(LSTEP_EINVAL, "lstep_update_entries_p2: NULL pointer");
+    const int64_t total = (n_real > nseg ? n_real : nseg) > 0 ? (n_real > nseg ? n_real : nseg) : 1;
+    hipLaunchKernelGGL(update_entries_p2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, order, seg, n_real, bn, nt, now32,
+                       num_neighbors, shift, uniq, nseg, ent_row, ent_dt, ent_seg, touched);
+    return check_launch("update_entries_p2_kernel");
+}

@@ -240,7 +240,7 @@ class LstepEngine:
         else:
             order, seg, uniq, (n_unique, _, _) = self._group_batch(src, dst, wait=True)
         self._batch_groups = (seg, order)          # int32: the batch rows cat[src, dst] grouped by batch node = by spliced row
-        return uniq[:n_unique].long(), (order.long(), seg.long(), None)
+        return uniq[:n_unique].long(), (order, seg, None)     # int32 order / segment ids (update_pe's phase 1 consumes them as they are)
 
     def prefetch_batch_nodes(self, src, dst):
         """Group the NEXT batch's endpoints now (the edge stream is known ahead).  Its kernels queue up behind the current forward pass

@@ -1179,6 +1179,21 @@ class LSTEP(nn.Module):
         ``lstep_update_rows`` and returns ids only); ``shard=(W, r)`` restricts the work to
         nodes with id % W == r; ``presorted=(order, inverse, counts)`` reuses the caller's stable sort of cat[src, dst]
         (the engine derives the batch-node set and the segments from one sort; then ``bn`` must be that node set)."""
+        if (fused and presorted is not None and shard is None and isinstance(now32, torch.Tensor) and presorted[0].dtype == torch.int32
+                and os.environ.get("LSTEP_TORCH_ENTRIES") != "1"):
+            # engine fast path: the grouping of cat[src, dst] by batch node is already there (int32 order / segment ids); one kernel
+            # builds the message list, one sums the segments, one applies the MLP and writes the rows
+            lib = nat.load_library()
+            order32, seg32 = presorted[0], presorted[1]
+            n2 = order32.numel()
+            ent_row = torch.empty(n2, dtype=torch.int32, device=pe.device)
+            ent_dt = torch.empty(n2, dtype=torch.float32, device=pe.device)
+            with torch.cuda.device(pe.device):
+                nat.check(lib.lstep_update_entries_p1(nat.ptr(order32), n2, nat.ptr(src), nat.ptr(dst), nat.ptr(t), nat.ptr(now32), src.numel(),
+                                                      nat.ptr(ent_row), nat.ptr(ent_dt), nat.current_stream()))
+            agg = self._segment_sum(pe, bn.numel(), seg32, ent_row, ent_dt, exact=True)
+            self._update_rows(pe, bn, agg, with_self=True)
+            return bn
         # float32 scalar - float64 -> float64 -> .float(); now32 may be a 0-d float32 device tensor (no host round trip)
         dt1 = ((now32.to(torch.float64) if isinstance(now32, torch.Tensor) else now32) - t).to(torch.float32)
         if presorted is None:
@@ -1235,6 +1250,8 @@ class LSTEP(nn.Module):
         key = nbr.reshape(-1)
         rows = pe.shape[0]
         pe[0].zero_()
+        if fused and isinstance(now32, torch.Tensor) and os.environ.get("LSTEP_TORCH_ENTRIES") != "1":
+            return self._phase2_native(pe, bn, nbr, nt, now32, num_neighbors, shard)
         real = key != 0
         if shard is not None:
             real = real & ((key % shard[0]) == shard[1])
@@ -1268,6 +1285,42 @@ class LSTEP(nn.Module):
             self._update_rows(pe, touched, agg2, with_self=False)
             return touched
         return touched, self._update_mlp(agg2)[:touched.numel()]
+
+    def _phase2_native(self, pe, bn, nbr, nt, now32, num_neighbors, shard):
+        """Phase 2 with the key / entry lists built by native kernels (lstep_update_keys_p2, lstep_update_entries_p2): ~10 launches
+        instead of ~35 framework ones; same grouping, same order of summation."""
+        lib = nat.load_library()
+        dev, P, U = pe.device, self.pe_dim, bn.numel()
+        rows = pe.shape[0]
+        n = nbr.numel()
+        world, rank = shard if shard is not None else (1, 0)
+        own_row0 = rank == 0                                     # row 0 belongs to shard 0
+        keys32 = torch.empty(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_update_keys_p2(nat.ptr(nbr), n, rows, world, rank, nat.ptr(keys32), nat.current_stream()))
+        _, order, seg, uniq, (_, n_real, nseg) = nat.group_by_key(keys32, max(1, int(rows + 1).bit_length()), rows)
+        n_zero = (n - n_real) if shard is None else (int((nbr == 0).sum()) if own_row0 else 0)
+        shift = 1 if (own_row0 and n_zero > 0) else 0
+        ent_row = torch.empty(n_real, dtype=torch.int32, device=dev)
+        ent_dt = torch.empty(n_real, dtype=torch.float32, device=dev)
+        ent_seg = torch.empty(n_real, dtype=torch.int32, device=dev)
+        touched = torch.empty(nseg + shift, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_update_entries_p2(nat.ptr(order), nat.ptr(seg), n_real, nat.ptr(bn), nat.ptr(nt), nat.ptr(now32), int(num_neighbors),
+                                                  shift, nat.ptr(uniq), nseg, nat.ptr(ent_row), nat.ptr(ent_dt), nat.ptr(ent_seg), nat.ptr(touched),
+                                                  nat.current_stream()))
+        agg2 = self._segment_sum(pe, nseg + shift, ent_seg, ent_row, ent_dt, exact=True)
+        if shift:
+            # row 0 collects cat[pe[source], 0] from every padded slot: segment 0 has no entries of its own, its aggregate is the sum
+            # over the rows of (their number of padded slots) * pe[source row]
+            agg2[0].zero_()
+            part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(U)), P), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), int(num_neighbors), nat.ptr(bn), U, nat.ptr(pe), P, int(pe.stride(0)),
+                                                     nat.ptr(part), nat.current_stream()))
+            agg2[0, :P] = part.sum(dim=0)
+        self._update_rows(pe, touched, agg2, with_self=False)
+        return touched
 
     @torch.no_grad()
     def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
