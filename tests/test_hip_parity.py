@@ -629,7 +629,8 @@ def test_fused_dense_kernels_match_library_path(hip, monkeypatch):
     K, T, B = 20, 4, 500
     results = []
     for torch_path in (False, True):
-        for var in ("LSTEP_TORCH_TAIL", "LSTEP_TORCH_HEAD", "LSTEP_TORCH_LOSS", "LSTEP_TORCH_UPDATE", "LSTEP_TORCH_WGRAD"):
+        for var in ("LSTEP_TORCH_TAIL", "LSTEP_TORCH_HEAD", "LSTEP_TORCH_LOSS", "LSTEP_TORCH_UPDATE", "LSTEP_TORCH_WGRAD", "LSTEP_TORCH_ENTRIES",
+                    "LSTEP_TORCH_FFTCOEF", "LSTEP_TORCH_SMALL_MM"):
             if torch_path:
                 monkeypatch.setenv(var, "1")
             else:
@@ -759,3 +760,35 @@ def test_small_gemm_vs_float64(hip):
         untouched = wide.clone()
         untouched[1:1 + m, 2:2 + n] = 0
         assert float(untouched[0].abs().max()) > 0 and torch.equal(wide[0], untouched[0]) and torch.equal(wide[:, :2], untouched[:, :2])
+
+
+def test_update_entry_kernels_match_framework_path(hip, monkeypatch):
+    """update_pe with its message lists built by the native kernels (lstep_update_entries_p1 / _keys_p2 / _entries_p2, device-side
+    current time, int32 grouping) against the same fused update with the lists built by framework ops: identical tables, on a graph
+    with padded neighbourhoods (row 0 is updated) and hub nodes."""
+    from lstep_amd import synth
+    from lstep_amd.engine import LstepEngine, EdgeStream
+    from lstep_amd.sampler import NeighborSampler
+    from lstep_amd.smoke import build_hip_model
+    g = synth.make_temporal_graph(num_nodes=500, num_edges=5000, seed=3, zipf=1.2)
+    node_raw, edge_raw = synth.make_features(500, 5000, seed=3)
+    K, T, B = 20, 4, 300
+    tables = []
+    for framework in (False, True):
+        if framework:
+            monkeypatch.setenv("LSTEP_TORCH_ENTRIES", "1")
+        else:
+            monkeypatch.delenv("LSTEP_TORCH_ENTRIES", raising=False)
+        sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=500, device=DEV)
+        model = build_hip_model(node_raw, edge_raw, sampler, K, T, synth.make_state_dict(K, T), DEV)
+        eng = LstepEngine(model[0], model[1], K, 2000)
+        stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+        pe = torch.from_numpy(synth.make_initial_pe(500, seed=3)).to(DEV).clone()
+        for lo in (200, 2500):          # early batch: most neighbourhoods are padded; later batch: mostly full
+            src, dst, ts, eid = stream.batch(lo, lo + B)
+            bn, presorted = eng.batch_nodes_and_segments(src, dst)
+            model[0].update_pe(pe=pe, node_ids=bn, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst, node_interact_times=ts,
+                               current_time=ts.max(), num_neighbors=K, time_gap=2000, presorted=presorted)
+        tables.append(pe.clone())
+    np.testing.assert_allclose(tables[0].cpu().numpy(), tables[1].cpu().numpy(), rtol=0, atol=1e-5)   # hub segments: float atomics
+    assert float(tables[0][0].abs().max()) > 0          # row 0 did take part
