@@ -22,7 +22,7 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for (m, n, k) in ((49152, 176, 288), (49152, 288, 288), (49152, 176, 352), (49152, 176, 640), (32768, 172, 344), (49153, 176, 288), (1000, 64, 48),
+for (m, n, k) in ((49152, 176, 272), (49152, 272, 272), (49152, 176, 352), (49152, 176, 624), (32768, 172, 344), (49153, 176, 272), (4100, 176, 272), (1000, 64, 48),
                   (7, 16, 16), (16384, 176, 640)):
     dy = torch.randn(m, n, device=dev)
     x = torch.randn(m, k, device=dev)
