@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="eval = evaluate_model_utils.py:38-142 iteration (4x combine, no backward)")
     ap.add_argument("--zipf", type=float, default=None, help="power-law endpoint popularity exponent (hub-skew variant)")
+    ap.add_argument("--history", choices=["evolved", "random"], default="evolved",
+                    help="state of the T-snapshot PE history when the run starts: evolved = built by the algorithm itself over the T batches "
+                         "before the first one (snapshots are clones of their predecessor plus the rows the batch wrote, as in the reference); "
+                         "random = T independent random tables (every row differs between snapshots: the worst case for the filter)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,6 +147,10 @@ def main():
     start = min(wl.num_edges // 2, wl.num_edges - need)   # from the middle of the stream when it fits
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)
+    prerolled = 0
+    if args.history == "evolved":
+        from lstep_amd.workload import evolve_history
+        prerolled = evolve_history(runner, wl.stream, start, B * world, wl.num_nodes)
 
     def step(i):
         lo = start + i * B * world
@@ -212,7 +220,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.describe() + (f", zipf {args.zipf} endpoints" if args.zipf else ""), "global_batch": B * world, "parallelism": f"owner-sharded history + row-sharded batch x{world} (RCCL)" if use_dist else "single GPU"},
+            "config": {"workload": wl.describe() + (f", zipf {args.zipf} endpoints" if args.zipf else ""), "global_batch": B * world,
+                       "history": (f"evolved: {prerolled} pre-roll batches through the engine's own eval iteration" if args.history == "evolved"
+                                   else "random: T independent snapshots"),
+                       "parallelism": f"owner-sharded history + row-sharded batch x{world} (RCCL)" if use_dist else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "lstep::gather_aggregate_fwd_kernel<true, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),

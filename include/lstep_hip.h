@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 17
+#define LSTEP_ABI_VERSION 18
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -124,6 +124,31 @@ int64_t lstep_history_filter_bwd_chunks(int64_t num_ids);
 int lstep_history_filter_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots,
                              int32_t time_rot, int32_t t_len, int32_t pe_dim, const int64_t* node_ids, int64_t num_ids,
                              const float* grad_out, float* out_partial, void* stream);
+
+/* F over a history of table CLONES (train_link_prediction.py:229 clones the newest snapshot, :301 appends it): a node's row in
+ * snapshot s equals its row in snapshot s-1 unless the batch in between wrote it.  A device ring records that in a change mask,
+ * uint32 [num_rows, mask_words] over its PHYSICAL slots (bit ph of row n: "slot ph of node n differs from slot ph-1"; at most 128 slots),
+ * and the *_runs_* kernels read one row per run of equal rows -- same sums as lstep_history_filter_fwd / _bwd on the same data,
+ * different order of summation.  The mask is maintained with
+ *   lstep_history_slot_bits  set (value 1) or clear (0) the bit of `slot` in every row: start of a new snapshot.  Row 0 (the padding row,
+ *                            zeroed and rewritten by every update_pe, models/LSTEP.py:317) is always marked as changed.
+ *   lstep_history_mark       set the bit of `slot` for the listed node ids; world > 1: only ids with id % world == rank, at row id / world
+ *                            (owner-sharded rings); ids outside [0, num_rows) are ignored.
+ * A bit that is set for an unchanged row costs one extra row read, a bit that is missing for a changed row gives wrong results. */
+int lstep_history_slot_bits(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, int32_t value, void* stream);
+int lstep_history_mark(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, const int64_t* ids, int64_t num_ids,
+                       int32_t world, int32_t rank, void* stream);
+/* workspace: lstep_history_filter_runs_workspace(t_len, pe_dim) bytes, 16-byte aligned (float64 prefix sums of coef) */
+int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe_dim);
+int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
+                                  int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
+                                  int64_t num_ids, const float* coef, void* workspace, float* out, void* stream);
+/* out_partial [lstep_history_filter_bwd_chunks(num_ids), t_len, P] holds per-chunk DIFFERENCE sums; the caller adds them over dim 0 and
+ * passes the [t_len, P] result to lstep_history_filter_runs_finish, which turns it into d(coef) (running sums in float64). */
+int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
+                                  int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
+                                  int64_t num_ids, const float* grad_out, float* out_partial, void* stream);
+int lstep_history_filter_runs_finish(const float* partial_sum, int32_t t_len, int32_t pe_dim, float* dcoef, void* stream);
 
 /* Segmented row sums.  Entry e = 0..num_entries-1 belongs to output row ent_seg[e]; entries of one segment must be
  * adjacent (ent_seg grouped, e.g. sorted); for every segment s that occurs

@@ -86,6 +86,209 @@ __global__ __launch_bounds__(kBlock) void history_filter_bwd_kernel(HistView h, 
         if (s0 + i < t_len) st4(partial + (chunk * t_len + s0 + i) * (int64_t)P + lane * 4, acc[i]);
 }
 
+// ---- change-aware variants ------------------------------------------------------------------------------------------------
+// The reference appends a CLONE of the whole PE table per batch (train_link_prediction.py:229,301), so a node's row in snapshot s is
+// bit-identical to its row in snapshot s-1 unless the batch in between wrote it (splice, update_pe phase 1 / 2).  The device ring
+// records exactly that in a per-node bit mask over its PHYSICAL slots (bit ph = "slot ph differs from slot ph-1"), and the filter
+// only reads the first row of every run of equal rows:
+//   fwd  out[u]   = sum_runs (cpre[run end] - cpre[run begin]) * row(run begin),   cpre[s] = sum_{s' < s} coef[s']  (float64 table)
+//   bwd  D[b]     = sum_u g[u] * (row(b) - row(previous run's begin))  at every run begin b;   dcoef = cumsum_s(D)
+// Same sums as the dense kernels, one row read per run instead of one per snapshot.
+
+struct ChangeBits {   // logical-order view of a node's change mask: bit s = "snapshot s of the window differs from snapshot s-1"
+    uint64_t lo, hi;
+    __device__ __forceinline__ bool test(int s) const { return ((s < 64 ? lo >> s : hi >> (s - 64)) & 1ull) != 0; }
+    // first set bit at position >= s, or `limit` when there is none below it
+    __device__ __forceinline__ int next(int s, int limit) const {
+        if (s >= limit) return limit;
+        if (s < 64) {
+            const uint64_t m = lo >> s;
+            if (m) { const int r = s + __builtin_ctzll(m); return r < limit ? r : limit; }
+            s = 64;
+            if (s >= limit) return limit;
+        }
+        const uint64_t m = hi >> (s - 64);
+        if (!m) return limit;
+        const int r = s + __builtin_ctzll(m);
+        return r < limit ? r : limit;
+    }
+};
+
+__device__ __forceinline__ void shr128(uint64_t& lo, uint64_t& hi, int n) {   // 0 <= n < 128
+    if (n >= 64) { lo = hi >> (n - 64); hi = 0; }
+    else if (n > 0) { lo = (lo >> n) | (hi << (64 - n)); hi >>= n; }
+}
+__device__ __forceinline__ void shl128(uint64_t& lo, uint64_t& hi, int n) {   // 0 <= n <= 128
+    if (n >= 128) { lo = 0; hi = 0; }
+    else if (n >= 64) { hi = lo << (n - 64); lo = 0; }
+    else if (n > 0) { hi = (hi << n) | (lo >> (64 - n)); lo <<= n; }
+}
+
+// every lane of the wave holds the same node id: move it to scalar registers, so row addresses are scalar base + lane offset
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// all lanes of the wave read the same 4 * words bytes; the result lives in scalar registers
+__device__ __forceinline__ ChangeBits load_change_bits(const uint32_t* __restrict__ mask, int words, int64_t node, int slots, int rot) {
+    const uint32_t* m = mask + node * words;
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = i < words ? (uint32_t)__builtin_amdgcn_readfirstlane((int)m[i]) : 0u;
+    uint64_t alo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), ahi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    uint64_t blo = alo, bhi = ahi;
+    shr128(alo, ahi, rot);            // physical slots rot .. slots-1  -> logical 0 ..
+    shl128(blo, bhi, slots - rot);    // physical slots 0 .. rot-1      -> logical slots-rot ..
+    return ChangeBits{alo | blo, ahi | bhi};
+}
+
+struct alignas(16) double2_ { double x, y; };
+
+constexpr int kRunsInFlight = 8;
+
+__global__ __launch_bounds__(kBlock) void history_filter_runs_fwd_kernel(HistView h, int t_len, int P, const uint32_t* __restrict__ mask, int words,
+                                                                          const int64_t* __restrict__ ids, int64_t num_ids,
+                                                                          const double* __restrict__ cpre, float* __restrict__ out) {
+    const int lane = lane_id();
+    const int64_t u = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (u >= num_ids) return;
+    const int64_t node = uniform_i64(ids[u]);
+    const ChangeBits bits = load_change_bits(mask, words, node, h.slots, h.rot);
+    if (lane >= (P >> 2)) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cur = 0;                                  // the oldest snapshot always starts a run
+    while (cur < t_len) {
+        int st[kRunsInFlight + 1];
+        st[0] = cur;
+#pragma unroll
+        for (int i = 1; i <= kRunsInFlight; ++i) st[i] = bits.next(st[i - 1] + 1, t_len);
+        float4 x[kRunsInFlight];
+        double2_ c[kRunsInFlight + 1][2];
+#pragma unroll
+        for (int i = 0; i < kRunsInFlight; ++i)
+            x[i] = st[i] < t_len ? ld4_stream(h.row(node, st[i]) + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i <= kRunsInFlight; ++i) {
+            const double2_* cp = reinterpret_cast<const double2_*>(cpre + (int64_t)st[i] * P + lane * 4);   // cpre has t_len + 1 rows
+            c[i][0] = cp[0];
+            c[i][1] = cp[1];
+        }
+#pragma unroll
+        for (int i = 0; i < kRunsInFlight; ++i) {
+            acc.x = fmaf((float)(c[i + 1][0].x - c[i][0].x), x[i].x, acc.x);
+            acc.y = fmaf((float)(c[i + 1][0].y - c[i][0].y), x[i].y, acc.y);
+            acc.z = fmaf((float)(c[i + 1][1].x - c[i][1].x), x[i].z, acc.z);
+            acc.w = fmaf((float)(c[i + 1][1].y - c[i][1].y), x[i].w, acc.w);
+        }
+        cur = st[kRunsInFlight];
+    }
+    st4(out + u * (int64_t)P + lane * 4, acc);
+}
+
+// cpre[s, p] = sum_{s' < s} coef[s', p] in float64, rows 0 .. t_len
+__global__ __launch_bounds__(kBlock) void coef_prefix_kernel(const float* __restrict__ coef, int t_len, int P, double* __restrict__ cpre) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    double run = 0.0;
+    cpre[p] = 0.0;
+    for (int s = 0; s < t_len; ++s) {
+        run += (double)coef[(int64_t)s * P + p];
+        cpre[(int64_t)(s + 1) * P + p] = run;
+    }
+}
+
+constexpr int kRunsTimeGroup = 16;   // snapshots per wave of the backward pass: one forced read per group, runs in between
+
+// wave = (node chunk, group of 16 snapshots).  partial[chunk, s] = sum over the chunk's nodes of g * (row(s) - previous run's row) at the
+// run begins s of the group (the group's first snapshot counts as a run begin with "previous row" = 0), zero elsewhere.
+__global__ __launch_bounds__(kBlock) void history_filter_runs_bwd_kernel(HistView h, int t_len, int P, const uint32_t* __restrict__ mask, int words,
+                                                                          const int64_t* __restrict__ ids, int64_t num_ids,
+                                                                          const float* __restrict__ grad, float* __restrict__ partial, int groups) {
+    const int lane = lane_id();
+    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    const int64_t chunk = w / groups;
+    const int grp = (int)(w - chunk * groups);
+    const int64_t u0 = chunk * kBwdNodesPerChunk;
+    if (u0 >= num_ids) return;
+    const int s0 = grp * kRunsTimeGroup;
+    const int64_t u1 = (u0 + kBwdNodesPerChunk < num_ids) ? u0 + kBwdNodesPerChunk : num_ids;
+    const bool active = lane < (P >> 2);
+    const int col = active ? lane * 4 : 0;
+    float4 acc[kRunsTimeGroup];
+#pragma unroll
+    for (int i = 0; i < kRunsTimeGroup; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t valid = t_len - s0 >= kRunsTimeGroup ? 0xFFFFu : (1u << (t_len - s0)) - 1u;   // s0 < t_len: groups = ceil(t_len / 16)
+    int64_t node = uniform_i64(ids[u0]);
+    ChangeBits bits = load_change_bits(mask, words, node, h.slots, h.rot);
+    for (int64_t u = u0; u < u1; ++u) {
+        const int64_t node_now = node;
+        const ChangeBits b = bits;
+        if (u + 1 < u1) {     // next node's id and mask travel while this node's rows do
+            node = uniform_i64(ids[u + 1]);
+            bits = load_change_bits(mask, words, node, h.slots, h.rot);
+        }
+        const float4 g = ld4(grad + u * (int64_t)P + col);
+        float4 x[kRunsTimeGroup];
+        // run begins of this group as one scalar bit field (s0 is a multiple of 16: the field never straddles the two mask halves)
+        const uint32_t begins = (((uint32_t)(s0 < 64 ? b.lo >> s0 : b.hi >> (s0 - 64)) & valid) | 1u);
+#pragma unroll
+        for (int i = 0; i < kRunsTimeGroup; ++i) {
+            x[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (defined on both paths: otherwise the merge costs a copy and a wait per load)
+            if ((begins >> i) & 1u) x[i] = ld4_stream(h.row(node_now, s0 + i) + col);
+        }
+        float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < kRunsTimeGroup; ++i) {
+            if ((begins >> i) & 1u) {
+                acc[i].x = fmaf(g.x, x[i].x - prev.x, acc[i].x);
+                acc[i].y = fmaf(g.y, x[i].y - prev.y, acc[i].y);
+                acc[i].z = fmaf(g.z, x[i].z - prev.z, acc[i].z);
+                acc[i].w = fmaf(g.w, x[i].w - prev.w, acc[i].w);
+                prev = x[i];
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int i = 0; i < kRunsTimeGroup; ++i)
+        if (s0 + i < t_len) st4(partial + (chunk * t_len + s0 + i) * (int64_t)P + col, acc[i]);
+}
+
+// dcoef[s] = sum of D[s'] over the snapshots s' <= s of s's group (float64 running sum)
+__global__ __launch_bounds__(kBlock) void history_runs_finish_kernel(const float* __restrict__ dsum, int t_len, int P, int groups, float* __restrict__ dcoef) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= groups * P) return;
+    const int grp = i / P, p = i - grp * P;
+    double run = 0.0;
+    for (int s = grp * kRunsTimeGroup; s < (grp + 1) * kRunsTimeGroup && s < t_len; ++s) {
+        run += (double)dsum[(int64_t)s * P + p];
+        dcoef[(int64_t)s * P + p] = (float)run;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void history_mark_kernel(uint32_t* __restrict__ mask, int words, int64_t num_rows, int slot,
+                                                               const int64_t* __restrict__ ids, int64_t num_ids, int world, int rank) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_ids) return;
+    int64_t node = ids[i];
+    if (world > 1) {
+        if (node % world != rank) return;
+        node /= world;
+    }
+    if (node < 0 || node >= num_rows) return;
+    atomicOr(mask + node * words + (slot >> 5), 1u << (slot & 31));
+}
+
+__global__ __launch_bounds__(kBlock) void history_slot_bits_kernel(uint32_t* __restrict__ mask, int words, int64_t num_rows, int slot, int value) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_rows) return;
+    uint32_t* w = mask + i * words + (slot >> 5);
+    const uint32_t bit = 1u << (slot & 31);
+    *w = (value || i == 0) ? (*w | bit) : (*w & ~bit);   // row 0 = the padding row: every update_pe rewrites it (LSTEP.py:317)
+}
+
 static int check_hist(const char* who, const float* hist, int64_t node_stride, int64_t time_stride, int slots, int rot, int t_len, int P) {
     if (!hist) return set_error(LSTEP_EINVAL, "%s: NULL history", who);
     if (P <= 0 || (P & 3) || P > 4 * kMaxRowVec) return set_error(LSTEP_EINVAL, "%s: unsupported pe_dim %d", who, P);
@@ -130,4 +333,82 @@ extern "C" int lstep_history_filter_bwd(const float* hist, int64_t node_stride, 
     hipLaunchKernelGGL(history_filter_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim, node_ids,
                        num_ids, grad_out, out_partial, groups);
     return check_launch("history_filter_bwd_kernel");
+}
+
+static int check_mask(const char* who, const uint32_t* mask, int32_t words, int32_t slots) {
+    if (!mask) return set_error(LSTEP_EINVAL, "%s: NULL change mask", who);
+    if (words < 1 || words > 4 || slots > 32 * words) return set_error(LSTEP_EINVAL, "%s: %d mask words cannot hold %d slots (at most 128)", who, words, slots);
+    return LSTEP_OK;
+}
+
+extern "C" int lstep_history_mark(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, const int64_t* ids, int64_t num_ids,
+                                  int32_t world, int32_t rank, void* stream) {
+    if (num_ids < 0 || num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_history_mark: negative count");
+    if (num_ids == 0) return LSTEP_OK;
+    if (int rc = check_mask("lstep_history_mark", mask, mask_words, slot + 1)) return rc;
+    if (slot < 0 || !ids || world < 1 || rank < 0 || rank >= world) return set_error(LSTEP_EINVAL, "lstep_history_mark: bad argument");
+    const unsigned grid = (unsigned)((num_ids + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(history_mark_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, mask, (int)mask_words, num_rows, (int)slot, ids, num_ids,
+                       (int)world, (int)rank);
+    return check_launch("history_mark_kernel");
+}
+
+extern "C" int lstep_history_slot_bits(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, int32_t value, void* stream) {
+    if (num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_history_slot_bits: negative count");
+    if (num_rows == 0) return LSTEP_OK;
+    if (int rc = check_mask("lstep_history_slot_bits", mask, mask_words, slot + 1)) return rc;
+    if (slot < 0) return set_error(LSTEP_EINVAL, "lstep_history_slot_bits: negative slot");
+    const unsigned grid = (unsigned)((num_rows + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(history_slot_bits_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, mask, (int)mask_words, num_rows, (int)slot, (int)value);
+    return check_launch("history_slot_bits_kernel");
+}
+
+extern "C" int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe_dim) {
+    return t_len < 0 || pe_dim <= 0 ? 0 : (int64_t)(t_len + 1) * pe_dim * (int64_t)sizeof(double);
+}
+
+extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
+                                             int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
+                                             int64_t num_ids, const float* coef, void* workspace, float* out, void* stream) {
+    if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: negative count");
+    if (num_ids == 0) return LSTEP_OK;
+    if (int rc = check_hist("lstep_history_filter_runs_fwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
+    if (int rc = check_mask("lstep_history_filter_runs_fwd", mask, mask_words, time_slots)) return rc;
+    if (!node_ids || !coef || !out || !workspace || (((uintptr_t)workspace) & 15))
+        return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: NULL or misaligned pointer");
+    HistView h{hist, node_stride, time_stride, time_slots, time_rot};
+    double* cpre = (double*)workspace;
+    hipLaunchKernelGGL(coef_prefix_kernel, dim3((unsigned)((pe_dim + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coef, (int)t_len,
+                       (int)pe_dim, cpre);
+    const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(history_filter_runs_fwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim, mask,
+                       (int)mask_words, node_ids, num_ids, cpre, out);
+    return check_launch("history_filter_runs_fwd_kernel");
+}
+
+extern "C" int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
+                                             int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
+                                             int64_t num_ids, const float* grad_out, float* out_partial, void* stream) {
+    if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_bwd: negative count");
+    if (num_ids == 0 || t_len == 0) return LSTEP_OK;
+    if (int rc = check_hist("lstep_history_filter_runs_bwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
+    if (int rc = check_mask("lstep_history_filter_runs_bwd", mask, mask_words, time_slots)) return rc;
+    if (!node_ids || !grad_out || !out_partial) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_bwd: NULL pointer");
+    HistView h{hist, node_stride, time_stride, time_slots, time_rot};
+    const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
+    const int64_t waves = lstep_history_filter_bwd_chunks(num_ids) * groups;
+    const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(history_filter_runs_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim, mask,
+                       (int)mask_words, node_ids, num_ids, grad_out, out_partial, groups);
+    return check_launch("history_filter_runs_bwd_kernel");
+}
+
+extern "C" int lstep_history_filter_runs_finish(const float* partial_sum, int32_t t_len, int32_t pe_dim, float* dcoef, void* stream) {
+    if (t_len < 0 || pe_dim <= 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_finish: bad shape");
+    if (t_len == 0) return LSTEP_OK;
+    if (!partial_sum || !dcoef) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_finish: NULL pointer");
+    const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
+    const unsigned grid = (unsigned)((groups * pe_dim + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(history_runs_finish_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, partial_sum, (int)t_len, (int)pe_dim, groups, dcoef);
+    return check_launch("history_runs_finish_kernel");
 }

@@ -61,6 +61,32 @@ class HistoryRing:
         self.len = 0     # snapshots in the window (<= T)
         self._copy_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self._prefetched = None  # (slot index, event) of a base copy issued ahead of time
+        # Change bits: every snapshot is a clone of the one before it plus the rows its batch wrote (train:229,301), so bit `slot` of
+        # row n says "node n's row in physical slot `slot` differs from the slot before"; the FFT filter then reads one row per run of
+        # equal snapshots (lstep_history_filter_runs_*).  Whoever writes rows of the snapshot being built must call ``mark``.
+        # LSTEP_DENSE_HISTORY=1 (A/B switch) or more than 128 slots: no mask, the dense kernels read every snapshot.
+        self.words = (self.S + 31) // 32
+        on = torch.device(device).type == "cuda" and self.words <= 4 and os.environ.get("LSTEP_DENSE_HISTORY") != "1"
+        self.mask = torch.zeros((self.rows, self.words), dtype=torch.int32, device=device) if on else None
+
+    def begin_slot(self, slot: int = None, all_changed: bool = False):
+        """Reset the change bits of the snapshot about to be built (on the current stream): nothing changed yet, or everything."""
+        if self.mask is None:
+            return
+        slot = (self.start + self.len) % self.S if slot is None else slot
+        with torch.cuda.device(self.mask.device):
+            nat.check(nat.load_library().lstep_history_slot_bits(nat.ptr(self.mask), self.words, self.rows, int(slot), int(all_changed),
+                                                                 nat.current_stream()))
+
+    def mark(self, ids: torch.Tensor, world: int = 1, rank: int = 0):
+        """Rows ``ids`` (int64 node ids; ``world > 1``: only those owned by ``rank``, stored at row id // world) of the snapshot being built
+        were written."""
+        if self.mask is None or ids.numel() == 0:
+            return
+        slot = (self.start + self.len) % self.S
+        with torch.cuda.device(self.mask.device):
+            nat.check(nat.load_library().lstep_history_mark(nat.ptr(self.mask), self.words, self.rows, slot, nat.ptr(ids), ids.numel(),
+                                                            int(world), int(rank), nat.current_stream()))
 
     def geom(self):
         """(node_stride, time_stride, slots, rot, t_len, P) for ``lstep_history_filter_*`` (element strides)."""
@@ -89,6 +115,7 @@ class HistoryRing:
         self._copy_stream.wait_stream(main)
         with torch.cuda.stream(self._copy_stream):
             self.buf[slot].copy_(self.last(), non_blocking=True)
+            self.begin_slot(slot)
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
         self._prefetched = (slot, ev)
@@ -102,6 +129,7 @@ class HistoryRing:
             torch.cuda.current_stream(self.buf.device).wait_event(self._prefetched[1])
         else:
             cur.copy_(self.last())
+            self.begin_slot(slot)
         self._prefetched = None
         return cur
 
@@ -113,6 +141,22 @@ class HistoryRing:
         self._prefetched = None
         if keep:
             self.buf[:keep].copy_(history[:, t - keep:, :].permute(1, 0, 2))
+        self.recompute_mask()
+
+    def recompute_mask(self):
+        """Change bits of the whole window from the stored rows (after ``load`` or any direct write into ``buf``)."""
+        if self.mask is None:
+            return
+        self.mask.zero_()
+        for i in range(self.len):
+            ph = (self.start + i) % self.S
+            if i == 0:
+                differs = torch.ones(self.rows, dtype=torch.bool, device=self.buf.device)
+            else:
+                differs = (self.buf[ph] != self.buf[(ph - 1) % self.S]).any(dim=1)
+                differs[:1] = True
+            bit = 1 << (ph % 32)
+            self.mask[:, ph // 32] |= differs.to(torch.int32) * (bit - (1 << 32) if bit >= (1 << 31) else bit)
 
     def as_reference_tensor(self) -> torch.Tensor:
         """``[N+1, t, P]`` copy of the window, oldest first (tests / checkpoint parity with ``EarlyStopping.save_pe``)."""
@@ -205,9 +249,9 @@ class LstepEngine:
     def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):
         """FFT-filter the batch rows over the ring window and build the current PE in the spare slot (train:224-230)."""
         ring = self.ring
-        rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx)
+        rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask)
         cur = ring.base_for_next()
-        cur.index_copy_(0, batch_nodes, rows.detach())
+        cur.index_copy_(0, batch_nodes, rows.detach())   # (these rows are marked as changed by update_pe's phase 1: same node set)
         self.slot_of[batch_nodes] = torch.arange(batch_nodes.numel(), dtype=torch.int32, device=self.device)
         # the engine's gather rows are cat[src, dst, neg]: their first 2B rows are the entries batch_nodes_and_segments grouped
         return cur, SplicedRows(rows, self.slot_of, getattr(self, "_batch_groups", None))
@@ -265,6 +309,7 @@ class LstepEngine:
         if batch_idx == 0:
             cur = ring.spare()
             cur.copy_(initial_pe)
+            ring.begin_slot(all_changed=True)
             spliced = None
         else:
             cur, spliced = self._splice(batch_nodes, batch_idx)
@@ -296,7 +341,7 @@ class LstepEngine:
         def update_and_append():
             bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
                          node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G,
-                         presorted=presorted)
+                         presorted=presorted, changed=ring.mark)
             if batch_idx == 0 and initial_pe is not None:
                 initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
             ring.commit()
@@ -360,6 +405,7 @@ class LstepEngine:
         if lookahead is not None:
             self.prefetch_batch_nodes(*lookahead)
         bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                     node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted)
+                     node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted,
+                     changed=ring.mark)
         ring.commit()
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

@@ -784,22 +784,30 @@ class _FftCoefficients(torch.autograd.Function):
 
 
 class _HistoryFilter(torch.autograd.Function):
-    """out[u] = sum_s coef[s] * hist[ids[u], s]  (lstep_history_filter_fwd / _bwd); gradient only w.r.t. ``coef``."""
+    """out[u] = sum_s coef[s] * hist[ids[u], s]  (lstep_history_filter_fwd / _bwd); gradient only w.r.t. ``coef``.
+    With a change ``mask`` (int32 [rows, words], maintained by the device ring: which snapshots of a node differ from the one before)
+    the ``*_runs_*`` kernels read one row per run of equal snapshots instead of one per snapshot."""
 
     @staticmethod
-    def forward(ctx, coef, hist_base, geom, ids):
+    def forward(ctx, coef, hist_base, geom, ids, mask=None):
         lib = nat.load_library()
         node_stride, time_stride, slots, rot, t_len, P = geom
         U = ids.numel()
         out = torch.empty((U, P), dtype=torch.float32, device=ids.device)
         cc = coef.detach().contiguous()
         with torch.cuda.device(ids.device):
-            nat.check(lib.lstep_history_filter_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(ids), U,
-                                                   nat.ptr(cc), nat.ptr(out), nat.current_stream()))
+            if mask is None:
+                nat.check(lib.lstep_history_filter_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(ids), U,
+                                                       nat.ptr(cc), nat.ptr(out), nat.current_stream()))
+            else:
+                ws = nat._workspace(ids.device, int(lib.lstep_history_filter_runs_workspace(t_len, P)))
+                nat.check(lib.lstep_history_filter_runs_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(mask),
+                                                            int(mask.shape[1]), nat.ptr(ids), U, nat.ptr(cc), nat.ptr(ws), nat.ptr(out),
+                                                            nat.current_stream()))
         ctx.geom, ctx.coef_shape = geom, tuple(coef.shape)
         # NOT save_for_backward: the device ring appends its next snapshot (a slot outside this window) in place
-        # before backward runs; the window itself is guaranteed untouched by HistoryRing (engine.py).
-        ctx.hist = hist_base
+        # before backward runs; the window itself (rows and mask bits) is guaranteed untouched by HistoryRing (engine.py).
+        ctx.hist, ctx.mask = hist_base, mask
         ctx.save_for_backward(ids)
         return out
 
@@ -807,7 +815,7 @@ class _HistoryFilter(torch.autograd.Function):
     def backward(ctx, g_out):
         lib = nat.load_library()
         (ids,) = ctx.saved_tensors
-        hist_base = ctx.hist
+        hist_base, mask = ctx.hist, ctx.mask
         node_stride, time_stride, slots, rot, t_len, P = ctx.geom
         U = ids.numel()
         g_coef = torch.zeros(ctx.coef_shape, dtype=torch.float32, device=ids.device)
@@ -816,10 +824,17 @@ class _HistoryFilter(torch.autograd.Function):
             partial = torch.empty((chunks, t_len, P), dtype=torch.float32, device=ids.device)
             g = g_out.contiguous()
             with torch.cuda.device(ids.device):
-                nat.check(lib.lstep_history_filter_bwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(ids), U,
-                                                       nat.ptr(g), nat.ptr(partial), nat.current_stream()))
-            g_coef[:t_len] = partial.sum(dim=0)
-        return g_coef, None, None, None
+                if mask is None:
+                    nat.check(lib.lstep_history_filter_bwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(ids), U,
+                                                           nat.ptr(g), nat.ptr(partial), nat.current_stream()))
+                    g_coef[:t_len] = partial.sum(dim=0)
+                else:
+                    nat.check(lib.lstep_history_filter_runs_bwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P,
+                                                                nat.ptr(mask), int(mask.shape[1]), nat.ptr(ids), U, nat.ptr(g),
+                                                                nat.ptr(partial), nat.current_stream()))
+                    diff = partial.sum(dim=0)
+                    nat.check(lib.lstep_history_filter_runs_finish(nat.ptr(diff), t_len, P, nat.ptr(g_coef), nat.current_stream()))
+        return g_coef, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ backbone
@@ -1074,10 +1089,11 @@ class LSTEP(nn.Module):
         geom = (int(hist.stride(0)), int(hist.stride(1)), t_len, 0, t_len, self.pe_dim)
         return self.filter_history(hist, geom, self._ids(node_ids), batch_idx)
 
-    def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int):
-        """Shared by the drop-in method above and the device ring of ``lstep_amd.engine`` (geom = strides/rotation)."""
+    def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int, mask: torch.Tensor = None):
+        """Shared by the drop-in method above and the device ring of ``lstep_amd.engine`` (geom = strides/rotation; ``mask`` = the
+        ring's change bits, see ``HistoryRing``)."""
         coef = self.fft_coefficients(geom[4], batch_idx)
-        return _HistoryFilter.apply(coef, hist_base, geom, ids)
+        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask)
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
@@ -1322,7 +1338,8 @@ class LSTEP(nn.Module):
 
     @torch.no_grad()
     def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
-                  num_neighbors: int = 30, time_gap: int = 2000, presorted=None):
+                  num_neighbors: int = 30, time_gap: int = 2000, presorted=None, changed=None):
+        """``changed`` (optional callable): receives the int64 ids of the rows each phase wrote (the device ring's change mask)."""
         if not (pe.is_cuda and pe.dtype == torch.float32 and pe.is_contiguous()):
             raise ValueError("update_pe needs a contiguous float32 GPU table (it is mutated in place)")
         if pe.dim() != 2 or pe.shape[1] != self.pe_dim or pe.shape[0] < self.neighbor_sampler.num_rows:
@@ -1335,11 +1352,19 @@ class LSTEP(nn.Module):
         now32 = current_time.detach().to(device=pe.device, dtype=torch.float32).reshape(()) if isinstance(current_time, torch.Tensor) \
             else float(np.float32(current_time))
         if self._fused_tail_ok() and os.environ.get("LSTEP_TORCH_UPDATE") != "1":
-            self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted, fused=True)
-            self.update_pe_phase2(pe, bn, t, now32, num_neighbors, fused=True)
+            ids = self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted, fused=True)
+            if changed is not None:
+                changed(ids)
+            ids = self.update_pe_phase2(pe, bn, t, now32, num_neighbors, fused=True)
+            if changed is not None:
+                changed(ids)
             return pe
         ids, z = self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted)
         self.apply_residual_tanh(pe, ids, z)
+        if changed is not None:
+            changed(ids)
         ids, z = self.update_pe_phase2(pe, bn, t, now32, num_neighbors)
         self.apply_residual_tanh(pe, ids, z)
+        if changed is not None:
+            changed(ids)
         return pe

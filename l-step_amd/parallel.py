@@ -223,7 +223,7 @@ class DistributedLstep:
         owner = bn % self.W
         counts = torch.bincount(owner, minlength=self.W).tolist()      # every rank derives the same counts: no size exchange
         mine = bn[owner == self.rank]
-        rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx)
+        rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx, mask=self.ring.mask)
         gathered, _ = all_gather_var(rows_mine.detach(), self.group, counts=counts)
         # gathered is ordered by (owner rank, node id); bn is ordered by node id
         order = torch.argsort(owner, stable=True)
@@ -248,7 +248,7 @@ class DistributedLstep:
         P = self.bb.pe_dim
         self.table.index_copy_(0, unpack_ids(z_all, P), z_all[:, :P])
 
-    def _update_start(self, bn, src, dst, ts, presorted=None, owner_counts=None):
+    def _update_start(self, bn, src, dst, ts, presorted=None, owner_counts=None, first: bool = False):
         """Phase 1 completely (its rows feed phase 2), phase 2 up to the all-gather of its rows, which is left in flight.
         Fused path (default widths): every rank updates the rows it owns IN PLACE (``lstep_update_rows``) and the new rows are
         all-gathered; library path: the pre-activation rows z are gathered and every replica applies pe += tanh(z)."""
@@ -256,17 +256,24 @@ class DistributedLstep:
         shard = (self.W, self.rank)
         P = self.bb.pe_dim
         fused = self.bb._fused_tail_ok() and os.environ.get("LSTEP_TORCH_UPDATE") != "1"
+        # change bits of the snapshot this batch builds: the owned rows among the batch nodes (spliced rows, phase 1) and the owned rows
+        # phase 2 touches (each rank computes exactly the rows it owns)
+        ring = self._ring
+        ring.begin_slot(all_changed=first)
+        ring.mark(bn, self.W, self.rank)
         if fused:
             ids = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted, fused=True)
             if self.W > 1:
                 self._write_rows(all_gather_var(self._rows_with_ids(ids), self.group, counts=owner_counts)[0])
             ids = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard, fused=True)
+            ring.mark(ids, self.W, self.rank)
             return ("rows", PendingGather(self._rows_with_ids(ids), self.group) if self.W > 1 else None)
         ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
         # ids ride in z's padding columns: one collective per phase; phase-1 row counts are known locally
         z_all, _ = all_gather_var(pack_ids(z, ids, P), self.group, counts=owner_counts)
         self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)       # every replica applies the same update
         ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
+        ring.mark(ids, self.W, self.rank)
         return ("z", PendingGather(pack_ids(z, ids, P), self.group))
 
     def _update_finish(self, pending):
@@ -318,7 +325,7 @@ class DistributedLstep:
             self.eng.prefetch_batch_nodes(*lookahead)      # the next global batch's endpoints, grouped while this one runs
         # update_pe: the all-gather of the phase-2 rows (the largest collective, ~0.7 KB per touched node) stays in flight
         # while the backward pass runs; neither reads what the other writes
-        pending = self._update_start(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts)
+        pending = self._update_start(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts, first=batch_idx == 0)
         if loss is None:
             self._update_finish(pending)
             if batch_idx == 0 and initial_pe is not None:

@@ -83,6 +83,7 @@ def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int
         for s in range(ring.T):
             ring.buf[s].normal_(0.0, 0.1, generator=gen)
         ring.start, ring.len = 0, ring.T
+        ring.recompute_mask()       # random snapshots: every row differs from the one before (the dense worst case; see evolve_history)
     return Workload(name, n, e, b, k, time_gap, num_fft_batches, EdgeStream(src, dst, ts, eid), model, eng, sampler)
 
 
@@ -97,3 +98,24 @@ def prefill_distributed(dl, seed: int = 0):
         ring.buf[s].normal_(0.0, 0.1, generator=gen)
     ring.buf[ring.T - 1].copy_(dl.table[dl.rank::dl.W])  # newest snapshot = the current table's owned rows
     ring.start, ring.len = 0, ring.T
+    ring.recompute_mask()
+
+
+def evolve_history(runner, stream: EdgeStream, first_edge: int, batch: int, num_nodes: int, seed: int = 4321) -> int:
+    """Replace the random pre-fill by what the algorithm itself produces: run the engine's own evaluation iteration (splice, update_pe,
+    snapshot append; ``runner`` = LstepEngine or DistributedLstep) over the up-to-T batches of ``batch`` edges that END at
+    ``first_edge``.  As in the reference, each snapshot is then a clone of the previous one plus the rows its batch wrote.
+    Returns the number of batches run."""
+    ring = runner.ring
+    n = min(ring.T, first_edge // batch)
+    dev = stream.src.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    with torch.no_grad():
+        for j in range(n):
+            lo = first_edge - (n - j) * batch
+            src, dst, ts, eid = stream.batch(lo, lo + batch)
+            neg_src = torch.randint(1, num_nodes + 1, (batch,), generator=gen, device=dev)
+            neg_dst = torch.randint(1, num_nodes + 1, (batch,), generator=gen, device=dev)
+            runner.eval_iteration(1000 + j, src, dst, ts, eid, neg_src, neg_dst)
+    return n
