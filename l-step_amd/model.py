@@ -1187,14 +1187,16 @@ class LSTEP(nn.Module):
                                                    nat.current_stream()))
 
     @torch.no_grad()
-    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None, fused: bool = False):
+    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None, fused: bool = False, owned_idx=None):
         """U1 (LSTEP.py:277-303): every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints.
         Returns (ids, z) with the new row = pe[ids] + tanh(z), WITHOUT writing (``fused=True``: writes the rows in place with
         ``lstep_update_rows`` and returns ids only); ``shard=(W, r)`` restricts the work to
         nodes with id % W == r; ``presorted=(order, inverse, counts)`` reuses the caller's stable sort of cat[src, dst]
-        (the engine derives the batch-node set and the segments from one sort; then ``bn`` must be that node set)."""
-        if (fused and presorted is not None and shard is None and isinstance(now32, torch.Tensor) and presorted[0].dtype == torch.int32
-                and os.environ.get("LSTEP_TORCH_ENTRIES") != "1"):
+        (the engine derives the batch-node set and the segments from one sort; then ``bn`` must be that node set);
+        ``owned_idx`` (with ``shard``): the positions in ``bn`` of the nodes this rank owns, if the caller already has them -- the
+        sharded update then needs no host synchronisation either."""
+        if (fused and presorted is not None and (shard is None or owned_idx is not None) and isinstance(now32, torch.Tensor)
+                and presorted[0].dtype == torch.int32 and os.environ.get("LSTEP_TORCH_ENTRIES") != "1"):
             # engine fast path: the grouping of cat[src, dst] by batch node is already there (int32 order / segment ids); one kernel
             # builds the message list, one sums the segments, one applies the MLP and writes the rows
             lib = nat.load_library()
@@ -1206,8 +1208,14 @@ class LSTEP(nn.Module):
                 nat.check(lib.lstep_update_entries_p1(nat.ptr(order32), n2, nat.ptr(src), nat.ptr(dst), nat.ptr(t), nat.ptr(now32), src.numel(),
                                                       nat.ptr(ent_row), nat.ptr(ent_dt), nat.current_stream()))
             agg = self._segment_sum(pe, bn.numel(), seg32, ent_row, ent_dt, exact=True)
-            self._update_rows(pe, bn, agg, with_self=True)
-            return bn
+            if shard is None:
+                self._update_rows(pe, bn, agg, with_self=True)
+                return bn
+            # sharded: the message sums of all batch nodes are cheap (2 rows per batch edge) and every rank has the inputs; only the
+            # rows this rank owns go through the MLP and are written
+            ids = bn[owned_idx]
+            self._update_rows(pe, ids, agg[owned_idx], with_self=True)
+            return ids
         # float32 scalar - float64 -> float64 -> .float(); now32 may be a 0-d float32 device tensor (no host round trip)
         dt1 = ((now32.to(torch.float64) if isinstance(now32, torch.Tensor) else now32) - t).to(torch.float32)
         if presorted is None:

@@ -217,16 +217,43 @@ class DistributedLstep:
             self._snapshot_pending = False
 
     # ---- pieces
-    def _splice(self, bn: torch.Tensor, batch_idx: int):
+    def _prefetch(self, lookahead):
+        """Group the next global batch's endpoints now (``LstepEngine.prefetch_batch_nodes``) and send the number of its batch nodes per
+        owner rank to the host behind it, so the next iteration starts without waiting for the GPU."""
+        self.eng.prefetch_batch_nodes(*lookahead)
+        key, (_, _, uniq, pending) = self.eng._prefetched_group
+        valid = torch.arange(uniq.numel(), device=uniq.device) < pending._keep[0]       # entries past n_unique are uninitialised
+        ranks = torch.arange(self.W, device=uniq.device, dtype=uniq.dtype)
+        # (not torch.bincount: it reads the largest value back to size its output, a host synchronisation)
+        per_owner = ((torch.remainder(uniq, self.W).unsqueeze(1) == ranks) & valid.unsqueeze(1)).sum(dim=0)
+        host = torch.empty(self.W, dtype=torch.int64, pin_memory=True)
+        host.copy_(per_owner, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self._owner_prefetch = (key, host, done, per_owner)
+
+    def _prefetched_owner_counts(self, src, dst):
+        pre = self.__dict__.pop("_owner_prefetch", None)
+        if pre is None or pre[0] != self.eng._batch_key(src, dst):
+            return None
+        pre[2].synchronize()
+        return [int(c) for c in pre[1].tolist()]
+
+    def _splice(self, bn: torch.Tensor, batch_idx: int, owner_counts=None):
         """Owner-sharded FFT filter + all-gather of the filtered rows; returns (local rows with grad, leaf of all rows, perm)."""
         self._wait_snapshot()
         owner = bn % self.W
-        counts = torch.bincount(owner, minlength=self.W).tolist()      # every rank derives the same counts: no size exchange
-        mine = bn[owner == self.rank]
+        # every rank derives the same counts: no size exchange.  With a look-ahead they were computed one iteration ago and are already
+        # on the host (``_prefetch``); otherwise this is a host synchronisation.
+        counts = owner_counts if owner_counts is not None else torch.bincount(owner, minlength=self.W).tolist()
+        order = torch.argsort(owner, stable=True)                      # bn is sorted by id: this orders it by (owner rank, node id)
+        first = sum(counts[:self.rank])
+        owned_idx = order[first:first + counts[self.rank]]             # positions in bn of the nodes this rank owns
+        self._owned_idx = owned_idx
+        mine = bn[owned_idx]                                           # (sizes known on the host: no boolean-mask compaction)
         rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx, mask=self.ring.mask)
         gathered, _ = all_gather_var(rows_mine.detach(), self.group, counts=counts)
         # gathered is ordered by (owner rank, node id); bn is ordered by node id
-        order = torch.argsort(owner, stable=True)
         rows_all = torch.empty_like(gathered)
         rows_all[order] = gathered
         self.table.index_copy_(0, bn, rows_all)
@@ -248,8 +275,8 @@ class DistributedLstep:
         P = self.bb.pe_dim
         self.table.index_copy_(0, unpack_ids(z_all, P), z_all[:, :P])
 
-    def _update_start(self, bn, src, dst, ts, presorted=None, owner_counts=None, first: bool = False):
-        """Phase 1 completely (its rows feed phase 2), phase 2 up to the all-gather of its rows, which is left in flight.
+    def _update_phase1(self, bn, src, dst, ts, presorted=None, owner_counts=None, first: bool = False, owned_idx=None):
+        """update_pe phase 1 completely (its rows feed phase 2); no host synchronisation on the engine's fast path.
         Fused path (default widths): every rank updates the rows it owns IN PLACE (``lstep_update_rows``) and the new rows are
         all-gathered; library path: the pre-activation rows z are gathered and every replica applies pe += tanh(z)."""
         now32 = ts.max().to(torch.float32)       # torch.Tensor([current_time]) of the reference: float32-rounded, kept on the device
@@ -262,19 +289,32 @@ class DistributedLstep:
         ring.begin_slot(all_changed=first)
         ring.mark(bn, self.W, self.rank)
         if fused:
-            ids = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted, fused=True)
+            ids = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted, fused=True,
+                                           owned_idx=owned_idx)
             if self.W > 1:
                 self._write_rows(all_gather_var(self._rows_with_ids(ids), self.group, counts=owner_counts)[0])
+        else:
+            ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
+            # ids ride in z's padding columns: one collective per phase; phase-1 row counts are known locally
+            z_all, _ = all_gather_var(pack_ids(z, ids, P), self.group, counts=owner_counts)
+            self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)       # every replica applies the same update
+        return now32, fused
+
+    def _update_phase2(self, bn, ts, state):
+        """update_pe phase 2 up to the all-gather of its rows, which is left in flight."""
+        now32, fused = state
+        shard = (self.W, self.rank)
+        ring = self._ring
+        if fused:
             ids = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard, fused=True)
             ring.mark(ids, self.W, self.rank)
             return ("rows", PendingGather(self._rows_with_ids(ids), self.group) if self.W > 1 else None)
-        ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
-        # ids ride in z's padding columns: one collective per phase; phase-1 row counts are known locally
-        z_all, _ = all_gather_var(pack_ids(z, ids, P), self.group, counts=owner_counts)
-        self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)       # every replica applies the same update
         ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
         ring.mark(ids, self.W, self.rank)
-        return ("z", PendingGather(pack_ids(z, ids, P), self.group))
+        return ("z", PendingGather(pack_ids(z, ids, self.bb.pe_dim), self.group))
+
+    def _update_start(self, bn, src, dst, ts, presorted=None, owner_counts=None, first: bool = False):
+        return self._update_phase2(bn, ts, self._update_phase1(bn, src, dst, ts, presorted, owner_counts, first))
 
     def _update_finish(self, pending):
         """Apply the gathered phase-2 rows on every replica and append the snapshot to this rank's ring shard."""
@@ -294,13 +334,14 @@ class DistributedLstep:
         b = n_glob // self.W
         sl = slice(self.rank * b, (self.rank + 1) * b)
         self.bb.prepare_step()
+        owner_counts = self._prefetched_owner_counts(src, dst)      # (before the grouping below consumes the engine's prefetch)
         bn, presorted = self.eng.batch_nodes_and_segments(src, dst)
         out, loss = None, None
-        owner_counts = None
         if batch_idx == 0:
             self.table.copy_(initial_pe)
+            owner_counts = None
         else:
-            rows_mine, leaf, (owner_order, owner_counts) = self._splice(bn, batch_idx)
+            rows_mine, leaf, (owner_order, owner_counts) = self._splice(bn, batch_idx, owner_counts)
             spliced = SplicedRows(leaf, self.slot_of)
             s_, d_, n_, t_ = src[sl], dst[sl], neg_dst[sl], ts[sl]
             ids3 = torch.cat([s_, d_, n_])
@@ -322,10 +363,25 @@ class DistributedLstep:
                 loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
         if lookahead is not None:
-            self.eng.prefetch_batch_nodes(*lookahead)      # the next global batch's endpoints, grouped while this one runs
+            self._prefetch(lookahead)                      # the next global batch's endpoints, grouped while this one runs
         # update_pe: the all-gather of the phase-2 rows (the largest collective, ~0.7 KB per touched node) stays in flight
         # while the backward pass runs; neither reads what the other writes
-        pending = self._update_start(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts, first=batch_idx == 0)
+        # With a loss to differentiate, update_pe's kernels go to a side stream, issued from this same thread (so every rank still posts
+        # its collectives in the same order): they read and write only the PE table, which the backward pass never touches.  The host
+        # waits once inside phase 2 (segment counts), i.e. until the forward pass, phase 1 and the neighbour grouping have run; the
+        # rest of update_pe (and the all-gather of its rows) then runs underneath the backward pass.  (Enqueueing phase 2 after the
+        # backward pass was measured too, 4.9-5.0 ms/step either way at W = 1: with one host thread the step is bound by the ~230
+        # launches it issues, not by the GPU.)
+        overlap = loss is not None and self.eng.overlap_update
+        if overlap:
+            main, side = torch.cuda.current_stream(self.device), self.eng._update_stream
+            side.wait_stream(main)       # after the forward pass: it reads the table update_pe is about to rewrite
+            with torch.cuda.stream(side):
+                state = self._update_phase1(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts, first=batch_idx == 0,
+                                            owned_idx=self._owned_idx)
+                pending = self._update_phase2(bn, ts, state)
+        else:
+            pending = self._update_start(bn, src, dst, ts, presorted=presorted, owner_counts=owner_counts, first=batch_idx == 0)
         if loss is None:
             self._update_finish(pending)
             if batch_idx == 0 and initial_pe is not None:
@@ -340,7 +396,12 @@ class DistributedLstep:
             if rows_mine.numel():
                 rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
             all_reduce_gradients(self._trainable, self.group)
-            self._update_finish(pending)
+            if overlap:
+                with torch.cuda.stream(side):
+                    self._update_finish(pending)
+                main.wait_stream(side)       # the optimiser may only step once update_pe has read its weights
+            else:
+                self._update_finish(pending)
             optimizer.step()
             self.slot_of.index_fill_(0, bn, -1)
             # losses reported as global means (one collective for the three scalars)

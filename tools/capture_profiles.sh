@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r --output-format csv -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-python $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) --top 60 > $OUT/${TAG}_kernel_trace_per_iter.txt
+python $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) --top 60 --last 9 > $OUT/${TAG}_kernel_trace_per_iter.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o f --output-format csv -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o w --output-format csv -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-python $ROOT/tools/pmc_summary.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) --out $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt
+python $ROOT/tools/pmc_summary.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) --last 6 --out $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt
 cd $ROOT && python bench.py > $OUT/${TAG}_bench_line.json 2>/dev/null
 tail -c 1500 $OUT/${TAG}_bench_line.json

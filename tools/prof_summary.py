@@ -3,7 +3,7 @@
 
 Iterations are delimited by launches of the forward gather kernel (one per iteration in the engine); the first
 `--skip` iterations (warm-up) are dropped.  Prints per-kernel time per iteration, sorted, plus the total.
-usage: python tools/prof_summary.py <kernel_trace.csv> [--skip 3] [--top 40]
+usage: python tools/prof_summary.py <kernel_trace.csv> [--skip 3 | --last 9] [--top 40]
 """
 import argparse
 import csv
@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--skip", type=int, default=3)
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--marker", default="gather_aggregate_fwd_kernel")
+    ap.add_argument("--last", type=int, default=0, help="use only the last N iterations (the bench's history pre-roll runs up to T evaluation "
+                    "iterations before the training steps)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -31,6 +33,8 @@ def main():
     if len(marks) <= a.skip + 1:
         raise SystemExit("not enough iterations in trace")
     # iteration i spans [first kernel after previous iteration's end ... ]: use marker-to-marker windows
+    if a.last:
+        a.skip = max(a.skip, len(marks) - 1 - a.last)
     lo, hi = marks[a.skip], marks[-1]
     n_iter = len(marks) - 1 - a.skip
     agg = collections.defaultdict(lambda: [0.0, 0])

@@ -14,6 +14,8 @@ model.train()
 opt = FusedAdam(model.parameters(), lr=1e-4)
 gen = torch.Generator(device=dev); gen.manual_seed(1)
 start = wl.num_edges // 2
+from lstep_amd.workload import evolve_history
+evolve_history(eng, wl.stream, start, B, wl.num_nodes)   # the history the algorithm itself produces (as bench.py does)
 def run(i):
     lo = start + i * B
     src, dst, ts, eid = wl.stream.batch(lo, lo + B)
