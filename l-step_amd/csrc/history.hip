@@ -2,6 +2,8 @@
 //   fwd  out[u, :]   = sum_s coef[s, :] * hist[node_u, s, :]          streams U * t_len rows of P floats once
 //   bwd  dcoef[s, :] = sum_u grad[u, :] * hist[node_u, s, :]          streams the same rows once more
 // Both are pure HBM streams of 4P-byte rows (688 B for P = 172); coef / grad rows are re-read from L2.
+#include <cstdlib>
+
 #include "lstep_common.h"
 
 namespace lstep {
@@ -147,56 +149,105 @@ __device__ __forceinline__ ChangeBits load_change_bits(const uint32_t* __restric
 struct alignas(16) double2_ { double x, y; };
 
 constexpr int kRunsInFlight = 8;
+constexpr int kRunsLdsLimit = 160 * 1024 - 512;   // bytes of LDS one workgroup may take on gfx950 (160 KB per CU)
+constexpr int kRunsFwdBlocks = 256 * 4;   // persistent grid of the forward kernel: 4 workgroups (16 waves: 118 registers each) per CU
 
-__global__ __launch_bounds__(kBlock) void history_filter_runs_fwd_kernel(HistView h, int t_len, int P, const uint32_t* __restrict__ mask, int words,
-                                                                          const int64_t* __restrict__ ids, int64_t num_ids,
-                                                                          const double* __restrict__ cpre, float* __restrict__ out) {
+
+// persistent waves: wave w handles nodes w, w + waves, ...; the next node's id and mask are fetched while the current node's rows travel.
+// IN_LDS: the workgroup (16 waves, one per CU) first builds the float64 prefix table of coef in LDS ((t_len + 1) * P * 8 bytes, 139 KB for
+// T = 100, P = 172) and reads the run weights from there: with the table in L2 every run costs 1376 B of L1 fills next to its 688-B row,
+// and the kernel was bound by that (245 us against 155 us with the weights faked).  Otherwise cpre is the table coef_prefix_kernel made.
+template <bool IN_LDS>
+__global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fwd_kernel(HistView h, int t_len, int P, const uint32_t* __restrict__ mask,
+                                                                                         int words, const int64_t* __restrict__ ids, int64_t num_ids,
+                                                                                         const float* __restrict__ coef, const double* __restrict__ cpre,
+                                                                                         float* __restrict__ out) {
+    extern __shared__ double cpre_lds[];
     const int lane = lane_id();
-    const int64_t u = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (u >= num_ids) return;
-    const int64_t node = uniform_i64(ids[u]);
-    const ChangeBits bits = load_change_bits(mask, words, node, h.slots, h.rot);
-    if (lane >= (P >> 2)) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int cur = 0;                                  // the oldest snapshot always starts a run
-    while (cur < t_len) {
-        int st[kRunsInFlight + 1];
-        st[0] = cur;
-#pragma unroll
-        for (int i = 1; i <= kRunsInFlight; ++i) st[i] = bits.next(st[i - 1] + 1, t_len);
-        float4 x[kRunsInFlight];
-        double2_ c[kRunsInFlight + 1][2];
-#pragma unroll
-        for (int i = 0; i < kRunsInFlight; ++i)
-            x[i] = st[i] < t_len ? ld4_stream(h.row(node, st[i]) + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i <= kRunsInFlight; ++i) {
-            const double2_* cp = reinterpret_cast<const double2_*>(cpre + (int64_t)st[i] * P + lane * 4);   // cpre has t_len + 1 rows
-            c[i][0] = cp[0];
-            c[i][1] = cp[1];
+    const int waves_per_block = (int)(blockDim.x >> 6);
+    if (IN_LDS) {
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            double run = 0.0;
+            cpre_lds[p] = 0.0;
+            for (int s = 0; s < t_len; ++s) {
+                run += (double)coef[(int64_t)s * P + p];
+                cpre_lds[(s + 1) * P + p] = run;
+            }
         }
-#pragma unroll
-        for (int i = 0; i < kRunsInFlight; ++i) {
-            acc.x = fmaf((float)(c[i + 1][0].x - c[i][0].x), x[i].x, acc.x);
-            acc.y = fmaf((float)(c[i + 1][0].y - c[i][0].y), x[i].y, acc.y);
-            acc.z = fmaf((float)(c[i + 1][1].x - c[i][1].x), x[i].z, acc.z);
-            acc.w = fmaf((float)(c[i + 1][1].y - c[i][1].y), x[i].w, acc.w);
-        }
-        cur = st[kRunsInFlight];
+        __syncthreads();
     }
-    st4(out + u * (int64_t)P + lane * 4, acc);
+    const int64_t waves = (int64_t)gridDim.x * waves_per_block;
+    int64_t u = (int64_t)blockIdx.x * waves_per_block + wave_in_block();
+    if (u >= num_ids) return;
+    const bool active = lane < (P >> 2);
+    const int col = active ? lane * 4 : 0;
+    int64_t node = uniform_i64(ids[u]);
+    ChangeBits bits = load_change_bits(mask, words, node, h.slots, h.rot);
+    for (; u < num_ids; u += waves) {
+        const int64_t node_now = node;
+        const ChangeBits b = bits;
+        if (u + waves < num_ids) {
+            node = uniform_i64(ids[u + waves]);
+            bits = load_change_bits(mask, words, node, h.slots, h.rot);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cur = 0;                                  // the oldest snapshot always starts a run
+        while (cur < t_len) {
+            int st[kRunsInFlight + 1];
+            st[0] = cur;
+#pragma unroll
+            for (int i = 1; i <= kRunsInFlight; ++i) st[i] = b.next(st[i - 1] + 1, t_len);
+            float4 x[kRunsInFlight];
+            double2_ c[kRunsInFlight + 1][2];
+#pragma unroll
+            for (int i = 0; i < kRunsInFlight; ++i) {
+                x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (st[i] < t_len) x[i] = ld4_stream(h.row(node_now, st[i]) + col);
+            }
+#pragma unroll
+            for (int i = 0; i <= kRunsInFlight; ++i) {      // the prefix table has t_len + 1 rows
+                const double2_* cp = IN_LDS ? reinterpret_cast<const double2_*>(cpre_lds + st[i] * P + col)
+                                            : reinterpret_cast<const double2_*>(cpre + (int64_t)st[i] * P + col);
+                c[i][0] = cp[0];
+                c[i][1] = cp[1];
+            }
+#pragma unroll
+            for (int i = 0; i < kRunsInFlight; ++i) {
+                acc.x = fmaf((float)(c[i + 1][0].x - c[i][0].x), x[i].x, acc.x);
+                acc.y = fmaf((float)(c[i + 1][0].y - c[i][0].y), x[i].y, acc.y);
+                acc.z = fmaf((float)(c[i + 1][1].x - c[i][1].x), x[i].z, acc.z);
+                acc.w = fmaf((float)(c[i + 1][1].y - c[i][1].y), x[i].w, acc.w);
+            }
+            cur = st[kRunsInFlight];
+        }
+        if (active) st4(out + u * (int64_t)P + col, acc);
+    }
 }
 
-// cpre[s, p] = sum_{s' < s} coef[s', p] in float64, rows 0 .. t_len
+// cpre[s, p] = sum_{s' < s} coef[s', p] in float64, rows 0 .. t_len.  One wave per column: lane l owns snapshots [l * per, (l + 1) * per)
+// (per = ceil(t_len / 64)), a wave-wide exclusive scan of the lane sums gives each lane its offset.
 __global__ __launch_bounds__(kBlock) void coef_prefix_kernel(const float* __restrict__ coef, int t_len, int P, double* __restrict__ cpre) {
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = lane_id();
+    const int p = blockIdx.x * kWavesPerBlock + wave_in_block();
     if (p >= P) return;
-    double run = 0.0;
-    cpre[p] = 0.0;
-    for (int s = 0; s < t_len; ++s) {
-        run += (double)coef[(int64_t)s * P + p];
-        cpre[(int64_t)(s + 1) * P + p] = run;
+    const int per = (t_len + kWave - 1) / kWave;
+    const int s0 = lane * per;
+    double sum = 0.0;
+    for (int i = 0; i < per; ++i)
+        if (s0 + i < t_len) sum += (double)coef[(int64_t)(s0 + i) * P + p];
+    double incl = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double up = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += up;
     }
+    double run = incl - sum;                    // exclusive prefix of this lane's block
+    if (lane == 0) cpre[p] = 0.0;
+    for (int i = 0; i < per; ++i)
+        if (s0 + i < t_len) {
+            run += (double)coef[(int64_t)(s0 + i) * P + p];
+            cpre[(int64_t)(s0 + i + 1) * P + p] = run;
+        }
 }
 
 constexpr int kRunsTimeGroup = 16;   // snapshots per wave of the backward pass: one forced read per group, runs in between
@@ -378,11 +429,23 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
         return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: NULL or misaligned pointer");
     HistView h{hist, node_stride, time_stride, time_slots, time_rot};
     double* cpre = (double*)workspace;
-    hipLaunchKernelGGL(coef_prefix_kernel, dim3((unsigned)((pe_dim + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coef, (int)t_len,
-                       (int)pe_dim, cpre);
-    const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(history_filter_runs_fwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim, mask,
-                       (int)mask_words, node_ids, num_ids, cpre, out);
+    const size_t lds_bytes = (size_t)(t_len + 1) * pe_dim * sizeof(double);
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&history_filter_runs_fwd_kernel<true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kRunsLdsLimit) == hipSuccess;
+    if (big_lds && lds_bytes <= (size_t)kRunsLdsLimit && num_ids >= 2048 && !getenv("LSTEP_RUNS_NO_LDS")) {
+        // one 16-wave workgroup per CU, prefix table in LDS
+        int64_t blocks = (num_ids + 15) / 16;
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(history_filter_runs_fwd_kernel<true>, dim3((unsigned)blocks), dim3(1024), lds_bytes, (hipStream_t)stream, h, (int)t_len,
+                           (int)pe_dim, mask, (int)mask_words, node_ids, num_ids, coef, (const double*)nullptr, out);
+        return check_launch("history_filter_runs_fwd_kernel<lds>");
+    }
+    hipLaunchKernelGGL(coef_prefix_kernel, dim3((unsigned)((pe_dim + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       coef, (int)t_len, (int)pe_dim, cpre);
+    int64_t blocks = (num_ids + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > kRunsFwdBlocks) blocks = kRunsFwdBlocks;
+    hipLaunchKernelGGL(history_filter_runs_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim,
+                       mask, (int)mask_words, node_ids, num_ids, coef, (const double*)cpre, out);
     return check_launch("history_filter_runs_fwd_kernel");
 }
 
