@@ -32,8 +32,6 @@ struct WgradParams {
 template <int NT, int KTW, int DEPTH>
 __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const WgradParams p) {
     struct Operands { float a[NT]; float b[KTW]; };
-    constexpr int kInFlight = (DEPTH - 1) * (NT + KTW);
-    static_assert(kInFlight <= 63, "vmcnt is a 6-bit counter");
 
     const int lane = lane_id(), wave = wave_in_block();
     const int kk = lane >> 4, c = lane & 15;
@@ -53,25 +51,19 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const WgradPar
     for (int b = 0; b < KTW; ++b) colB[b] = min(k0 + 16 * b + c, p.k - 1);
 
     // Loads of one 4-row step; rows past the slice are clamped to its last row (consume() masks them).
-    // They are asm statements: hipcc's own wait-count insertion loses track across the loop back-edge and waits for all but
-    // the newest step (pipeline depth 1 in effect); with asm loads the waits are placed by hand (landed()).
+    // Plain loads: the compiler places the wait counts.  (An earlier version issued them as inline-asm `global_load_dword` with
+    // hand-placed `s_waitcnt vmcnt(N)`: exact when the kernel ran alone, but garbage in the products whenever another stream kept the
+    // memory system busy -- the compiler cannot see asm loads in flight when it assigns registers -- `tools/wgrad_race.py`.  With the
+    // sched barriers below the compiler-managed version keeps the same software pipeline and runs at the same speed.)
     auto issue = [&](Operands& o, int64_t r) {
         int64_t row = r + kk;
         if (row > r_end - 1) row = r_end - 1;
         const float* ra = p.dy + row * p.ldy;
         const float* rb = p.x + row * p.ldx;
 #pragma unroll
-        for (int a = 0; a < NT; ++a) asm volatile("global_load_dword %0, %1, off" : "=v"(o.a[a]) : "v"(ra + colA[a]));
+        for (int a = 0; a < NT; ++a) o.a[a] = ra[colA[a]];
 #pragma unroll
-        for (int b = 0; b < KTW; ++b) asm volatile("global_load_dword %0, %1, off" : "=v"(o.b[b]) : "v"(rb + colB[b]));
-    };
-    // wait until only the kInFlight loads issued after o's are still in flight, then hand o's registers back to the compiler
-    auto landed = [&](Operands& o) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight));
-#pragma unroll
-        for (int a = 0; a < NT; ++a) asm volatile("" : "+v"(o.a[a]));
-#pragma unroll
-        for (int b = 0; b < KTW; ++b) asm volatile("" : "+v"(o.b[b]));
+        for (int b = 0; b < KTW; ++b) o.b[b] = rb[colB[b]];
     };
 
     f32x4 acc[NT][KTW];
@@ -94,7 +86,6 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const WgradPar
         for (int d = 0; d < DEPTH; ++d) {
             // the sched barriers keep the loads of step s + d + DEPTH - 1 ahead of the MFMAs of step s + d
             issue(buf[(d + DEPTH - 1) % DEPTH], r_begin + 4 * (s + d + DEPTH - 1));
-            landed(buf[d]);
             __builtin_amdgcn_sched_barrier(0);
             const bool live = r_begin + 4 * (s + d) + kk < r_end;   // dead rows: zero dY operand, the products vanish
 #pragma unroll
@@ -107,7 +98,6 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const WgradPar
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)");   // the dropped prefetches of the last round
 
     // C/D layout of the 16x16 forms: lane l, register v -> row 4 * (l >> 4) + v, column l & 15
     float* out = p.part + (int64_t)blockIdx.x * p.part_stride;

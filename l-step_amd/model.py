@@ -354,6 +354,21 @@ def _aux_stream(dev):
     return st
 
 
+_AUX_PARAM_EVENT = {}   # device -> event recorded behind an optimiser step that ran on the auxiliary stream (see ``LstepEngine``)
+
+
+def note_aux_param_update(dev, event):
+    """The parameters whose gradients the auxiliary stream produces (dense tail, link predictor) were updated ON that stream: whoever
+    reads them next on another stream waits for ``event`` first (``wait_aux_param_update``)."""
+    _AUX_PARAM_EVENT[torch.device(dev)] = event
+
+
+def wait_aux_param_update(dev):
+    ev = _AUX_PARAM_EVENT.pop(torch.device(dev), None)
+    if ev is not None:
+        torch.cuda.current_stream(dev).wait_event(ev)
+
+
 _DEFERRED = {}     # device -> callables: auxiliary-stream work whose launch is postponed until the critical kernels are out
 
 
@@ -546,6 +561,7 @@ class MergeLayer(nn.Module):
         """fc2(relu(fc1(cat[a, b]))) for the positive and the negative pair of every edge, read straight from the row blocks of the
         padded embeddings ``emb`` [rows, 176] (``lstep_head_fwd``); ``layout`` = row offsets (pos_first, pos_second, neg_first,
         neg_second).  Returns the 2 n logits (positive pairs first)."""
+        wait_aux_param_update(emb.device)
         aux = _aux_stream(emb.device) if (self.__dict__.get("aux_wgrad_stream", False) and torch.is_grad_enabled()) else None
         return _Head.apply(emb, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, int(n), tuple(int(x) for x in layout), aux)
 
@@ -554,6 +570,8 @@ class MergeLayer(nn.Module):
                 and os.environ.get("LSTEP_TORCH_HEAD") != "1")
 
     def forward(self, input_1: torch.Tensor, input_2: torch.Tensor):
+        if input_1.is_cuda:
+            wait_aux_param_update(input_1.device)
         return self.fc2(fast_linear(torch.cat([input_1, input_2], dim=1), self.fc1.weight, self.fc1.bias, relu=True))
 
 
@@ -950,6 +968,7 @@ class LSTEP(nn.Module):
 
     def _pe_tail(self, x_pe, own):
         """pe_neighbor_mlp_1/2, self_update_neighbor_pe, tanh, residual (models/LSTEP.py:240-247)."""
+        wait_aux_param_update(x_pe.device)
         a = self.pe_neighbor_mlp_2(torch.relu(self.pe_neighbor_mlp_1(x_pe)))
         return own + torch.tanh(self.self_update_neighbor_pe(own) + a)
 
@@ -987,6 +1006,7 @@ class LSTEP(nn.Module):
         _flush_deferred()
         for dev, st in _AUX_STREAMS.items():     # keyed by the tensors' device (always indexed, unlike a bare "cuda")
             torch.cuda.current_stream(dev).wait_stream(st)
+            _AUX_PARAM_EVENT.pop(dev, None)
 
     def _fused_tail_ok(self) -> bool:
         """The single-launch tail is compiled for the default widths (feature / PE dim 172, time dim 100); other shapes (and
@@ -1007,6 +1027,7 @@ class LSTEP(nn.Module):
         parameters; state_dict is unchanged.  Exact in real arithmetic, <= 1e-6 in fp32 (golden-checked).
         All operands are zero-padded to 16-aligned widths (inputs by the gather kernel, weights here): the padding
         columns stay exactly 0 through relu / tanh / residual, so results are unchanged."""
+        wait_aux_param_update(x_edge.device)     # (an optimiser step of these layers may still be running on the auxiliary stream)
         Fd, P, D = self.feat_dim, self.pe_dim, self.time_dim
         Ce, Fn, Cp, Pp = self.ld_edge, self.ld_node, self.ld_pe, self.ld_self   # 16-aligned widths (272, 176, 272, 176)
         dims = (Fd, D + Fd, P, P + D, Ce, Fn, Cp, Pp)

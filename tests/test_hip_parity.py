@@ -933,3 +933,75 @@ def test_engine_change_mask_equals_dense_history(hip, monkeypatch):
     (la, ha), (lb, hb) = out
     np.testing.assert_allclose(la, lb, rtol=0, atol=5e-6)
     np.testing.assert_allclose(ha, hb, rtol=0, atol=5e-5)     # (Adam at lr 1e-3 amplifies the re-ordered sums of the two filters)
+
+
+# ------------------------------------------------------------------------------------------------ kernels beside a busy memory system
+@pytest.mark.parametrize("m,n,k", [(16384, 176, 176), (49152, 176, 272), (20000, 272, 272)])
+def test_linear_wgrad_is_exact_while_another_stream_copies(hip, m, n, k):
+    """The engine runs the weight-gradient products beside a 1.4 GB snapshot copy and the HBM-bound backward kernels.  The first
+    software pipeline of ``wgrad_partial_kernel`` (inline-asm loads, hand-placed wait counts) was exact alone and produced garbage
+    with a concurrent copy; this is its regression test."""
+    from lstep_amd import _native as nat
+    torch.manual_seed(m)
+    src = torch.randn(200_000_000, device=DEV)
+    dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    dy = torch.randn(m, n, device=DEV) * 1e-3
+    x = torch.randn(m, k, device=DEV)
+    ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+    for rep in range(6):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            dst.copy_(src, non_blocking=True)
+            dst.copy_(src, non_blocking=True)
+        dw, db = nat.linear_wgrad(dy, x)
+        torch.cuda.synchronize()
+        assert float((dw.double() - ref_w).abs().max()) <= 2e-6 * float(ref_w.abs().max()) * (m / 4096) ** 0.5 + 1e-9
+        assert float((db.double() - ref_b).abs().max()) <= 2e-6 * float(ref_b.abs().max()) * (m / 4096) ** 0.5 + 1e-9
+
+
+def test_engine_gradients_do_not_depend_on_stream_overlap(hip, monkeypatch):
+    """Parameter gradients of a training iteration at a size where the streams really overlap (B = 8192 on a 200 k-node graph, T = 20:
+    snapshot copies of 138 MB on the copy stream, update_pe on its own thread, weight gradients on the auxiliary stream) against the
+    serial schedule (LSTEP_NO_GRAPH / _NO_AUX_STREAM / _NO_OVERLAP / _NO_PREFETCH = 1): same gradients for every parameter."""
+    from lstep_amd.optim import FusedAdam
+    from lstep_amd.workload import WORKLOADS, build_workload, evolve_history
+    monkeypatch.setitem(WORKLOADS, "overlap-test", (200_000, 4_000_000, 8192, 20))
+    grads = []
+    for serial in (True, False):
+        for var in ("LSTEP_NO_GRAPH", "LSTEP_NO_AUX_STREAM", "LSTEP_NO_OVERLAP", "LSTEP_NO_PREFETCH"):
+            if serial:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
+        wl = build_workload("overlap-test", torch.device(DEV), num_fft_batches=20, seed=3)
+        eng, model = wl.engine, wl.model
+        model.train()
+
+        class NoStep(FusedAdam):       # keep the weights fixed: every iteration of both runs sees the same parameters
+            def step(self):
+                pass
+
+        opt = NoStep(model.parameters(), lr=1e-4)
+        start, B = wl.num_edges // 2, wl.batch
+        evolve_history(eng, wl.stream, start, B, wl.num_nodes)
+        gen = torch.Generator(device=DEV)
+        gen.manual_seed(1)
+        per_iter = []
+        for i in range(3):
+            lo = start + i * B
+            src, dst, ts, eid = wl.stream.batch(lo, lo + B)
+            neg = torch.randint(1, wl.num_nodes + 1, (B,), generator=gen, device=DEV)
+            nxt = None if serial else wl.stream.batch(lo + B, lo + 2 * B)[:2]
+            eng.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg, lookahead=nxt)
+            torch.cuda.synchronize()
+            per_iter.append({n: (torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad).detach().clone()
+                             for n, p in model.named_parameters() if p.grad is not None})
+        grads.append(per_iter)
+        del wl, eng, model, opt
+        torch.cuda.empty_cache()
+    for it, (a, b) in enumerate(zip(*grads)):
+        assert a.keys() == b.keys()
+        for name in a:
+            scale = float(a[name].abs().max())
+            assert float((a[name] - b[name]).abs().max()) <= 1e-4 * scale + 1e-9, f"iteration {it}: gradient of {name} depends on the schedule"
