@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void history_filter_fwd_kernel(HistView h, 
     st4(out + u * (int64_t)P + lane * 4, acc);
 }
 
-constexpr int kBwdNodesPerChunk = 64;
+constexpr int kBwdNodesPerChunk = 128;
 constexpr int kBwdTimeGroup = 8;
 
 // wave = (node chunk, group of 8 time steps): 8 float4 accumulators, one pass over the chunk's nodes
