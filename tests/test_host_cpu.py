@@ -52,7 +52,7 @@ def test_abi_argument_validation_without_gpu(lib):
     assert lib.lstep_gather_aggregate_fwd(ctypes.byref(csr), None, None, None, 170, 172, None, None, 100, None, None, None, 4, 5, 8, 3,
                                           None, None, None, None, 0, 0, 0, 0, None, None) == nat.LSTEP_EINVAL
     assert b"unsupported widths" in lib.lstep_last_error()
-    assert lib.lstep_history_filter_bwd_chunks(0) == 0 and lib.lstep_history_filter_bwd_chunks(65) == 2
+    assert lib.lstep_history_filter_bwd_chunks(0) == 0 and lib.lstep_history_filter_bwd_chunks(129) == 2
     assert lib.lstep_sample_recent(ctypes.byref(csr), None, 0, None, 0, 5, None, None, None, None, None) == nat.LSTEP_OK  # empty batch
 
 
