@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 18
+#define LSTEP_ABI_VERSION 19
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -140,14 +140,24 @@ int lstep_history_mark(uint32_t* mask, int32_t mask_words, int64_t num_rows, int
                        int32_t world, int32_t rank, void* stream);
 /* workspace: lstep_history_filter_runs_workspace(t_len, pe_dim) bytes, 16-byte aligned (float64 prefix sums of coef) */
 int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe_dim);
+/* oldest (optional, [num_rows, node_stride]): the window's oldest snapshot.  With it the slots need not be full clones: a slot only has to hold
+ * the rows its batch wrote (the marked ones), the kernels read nothing else -- the ring then appends lstep_copy_rows of the written rows per
+ * batch instead of cloning the table, and moves `oldest` on with lstep_history_advance_oldest when the window slides. */
 int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
-                                  int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
-                                  int64_t num_ids, const float* coef, void* workspace, float* out, void* stream);
+                                  int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
+                                  const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out, void* stream);
 /* out_partial [lstep_history_filter_bwd_chunks(num_ids), t_len, P] holds per-chunk DIFFERENCE sums; the caller adds them over dim 0 and
  * passes the [t_len, P] result to lstep_history_filter_runs_finish, which turns it into d(coef) (running sums in float64). */
 int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
-                                  int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
-                                  int64_t num_ids, const float* grad_out, float* out_partial, void* stream);
+                                  int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
+                                  const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial, void* stream);
+/* dst[r, :width] = src[r, :width] for r in ids (row stride ld floats; rows outside [0, num_rows) ignored): the rows a batch wrote, copied
+ * from the current PE table into the batch's history slot (train_link_prediction.py:301 appends the whole table). */
+int lstep_copy_rows(float* dst, const float* src, int32_t width, int64_t ld, const int64_t* ids, int64_t num_ids, int64_t num_rows, void* stream);
+/* oldest[r] = slot_rows[r] for every row r whose bit of `slot` is set in the change mask: the window's oldest snapshot moves to that slot
+ * (the trim of train_link_prediction.py:224-225). */
+int lstep_history_advance_oldest(float* oldest, const float* slot_rows, int32_t width, int64_t ld, const uint32_t* mask, int32_t mask_words,
+                                 int32_t slot, int64_t num_rows, void* stream);
 int lstep_history_filter_runs_finish(const float* partial_sum, int32_t t_len, int32_t pe_dim, float* dcoef, void* stream);
 
 /* Segmented row sums.  Entry e = 0..num_entries-1 belongs to output row ent_seg[e]; entries of one segment must be

@@ -12,10 +12,15 @@ struct HistView {
     const float* base;
     int64_t node_stride, time_stride;
     int slots, rot;
+    const float* oldest;   // optional [rows, node_stride] table holding the window's oldest snapshot (rings whose slots only store changed rows)
     __device__ __forceinline__ const float* row(int64_t node, int s) const {
         int ph = s + rot;
         if (ph >= slots) ph -= slots;
         return base + node * node_stride + (int64_t)ph * time_stride;
+    }
+    // the row of the run that begins at snapshot s (s = 0: the window's oldest snapshot)
+    __device__ __forceinline__ const float* begin_row(int64_t node, int s) const {
+        return (s == 0 && oldest) ? oldest + node * node_stride : row(node, s);
     }
 };
 
@@ -100,6 +105,16 @@ __global__ __launch_bounds__(kBlock) void history_filter_bwd_kernel(HistView h, 
 struct ChangeBits {   // logical-order view of a node's change mask: bit s = "snapshot s of the window differs from snapshot s-1"
     uint64_t lo, hi;
     __device__ __forceinline__ bool test(int s) const { return ((s < 64 ? lo >> s : hi >> (s - 64)) & 1ull) != 0; }
+    // last set bit at a position in [1, s] (s >= 1), or 0 when there is none: the begin of the run that snapshot s belongs to
+    __device__ __forceinline__ int prev(int s) const {
+        if (s >= 64) {
+            const uint64_t m = s - 64 >= 63 ? hi : hi & ((2ull << (s - 64)) - 1ull);
+            if (m) return 127 - __builtin_clzll(m);
+            s = 63;
+        }
+        const uint64_t m = (s >= 63 ? lo : lo & ((2ull << s) - 1ull)) & ~1ull;
+        return m ? 63 - __builtin_clzll(m) : 0;
+    }
     // first set bit at position >= s, or `limit` when there is none below it
     __device__ __forceinline__ int next(int s, int limit) const {
         if (s >= limit) return limit;
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fw
 #pragma unroll
             for (int i = 0; i < kRunsInFlight; ++i) {
                 x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (st[i] < t_len) x[i] = ld4_stream(h.row(node_now, st[i]) + col);
+                if (st[i] < t_len) x[i] = ld4_stream(h.begin_row(node_now, st[i]) + col);
             }
 #pragma unroll
             for (int i = 0; i <= kRunsInFlight; ++i) {      // the prefix table has t_len + 1 rows
@@ -284,10 +299,12 @@ __global__ __launch_bounds__(kBlock) void history_filter_runs_bwd_kernel(HistVie
         float4 x[kRunsTimeGroup];
         // run begins of this group as one scalar bit field (s0 is a multiple of 16: the field never straddles the two mask halves)
         const uint32_t begins = (((uint32_t)(s0 < 64 ? b.lo >> s0 : b.hi >> (s0 - 64)) & valid) | 1u);
+        // the group's first snapshot: its own row if it begins a run (or if every slot holds a full clone), else the row its run began with
+        const int first = (h.oldest == nullptr || s0 == 0 || b.test(s0)) ? s0 : b.prev(s0);
 #pragma unroll
         for (int i = 0; i < kRunsTimeGroup; ++i) {
             x[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (defined on both paths: otherwise the merge costs a copy and a wait per load)
-            if ((begins >> i) & 1u) x[i] = ld4_stream(h.row(node_now, s0 + i) + col);
+            if ((begins >> i) & 1u) x[i] = ld4_stream(h.begin_row(node_now, i == 0 ? first : s0 + i) + col);
         }
         float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -332,6 +349,27 @@ __global__ __launch_bounds__(kBlock) void history_mark_kernel(uint32_t* __restri
     atomicOr(mask + node * words + (slot >> 5), 1u << (slot & 31));
 }
 
+// dst[r] = src[r] for the listed rows r (wave per row; rows outside [0, num_rows) are ignored)
+__global__ __launch_bounds__(kBlock) void copy_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, int width, int64_t ld,
+                                                            const int64_t* __restrict__ ids, int64_t num_ids, int64_t num_rows) {
+    const int lane = lane_id();
+    const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (i >= num_ids) return;
+    const int64_t r = ids[i];
+    if (r < 0 || r >= num_rows) return;
+    for (int c = lane * 4; c < width; c += kWave * 4) st4(dst + r * ld + c, ld4(src + r * ld + c));
+}
+
+// oldest[r] = slot_rows[r] for every row whose bit of `slot` is set: the window's oldest snapshot moves on by one batch
+__global__ __launch_bounds__(kBlock) void history_advance_oldest_kernel(float* __restrict__ oldest, const float* __restrict__ slot_rows, int width, int64_t ld,
+                                                                         const uint32_t* __restrict__ mask, int words, int slot, int64_t num_rows) {
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (r >= num_rows) return;
+    if (!((mask[r * words + (slot >> 5)] >> (slot & 31)) & 1u)) return;
+    for (int c = lane * 4; c < width; c += kWave * 4) st4(oldest + r * ld + c, ld4_stream(slot_rows + r * ld + c));
+}
+
 __global__ __launch_bounds__(kBlock) void history_slot_bits_kernel(uint32_t* __restrict__ mask, int words, int64_t num_rows, int slot, int value) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_rows) return;
@@ -359,7 +397,7 @@ extern "C" int lstep_history_filter_fwd(const float* hist, int64_t node_stride, 
     if (num_ids == 0) return LSTEP_OK;
     if (int rc = check_hist("lstep_history_filter_fwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
     if (!node_ids || !coef || !out) return set_error(LSTEP_EINVAL, "lstep_history_filter_fwd: NULL pointer");
-    HistView h{hist, node_stride, time_stride, time_slots, time_rot};
+    HistView h{hist, node_stride, time_stride, time_slots, time_rot, nullptr};
     const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(history_filter_fwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim, node_ids,
                        num_ids, coef, out);
@@ -377,7 +415,7 @@ extern "C" int lstep_history_filter_bwd(const float* hist, int64_t node_stride, 
     if (num_ids == 0 || t_len == 0) return LSTEP_OK;
     if (int rc = check_hist("lstep_history_filter_bwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
     if (!node_ids || !grad_out || !out_partial) return set_error(LSTEP_EINVAL, "lstep_history_filter_bwd: NULL pointer");
-    HistView h{hist, node_stride, time_stride, time_slots, time_rot};
+    HistView h{hist, node_stride, time_stride, time_slots, time_rot, nullptr};
     const int groups = (t_len + kBwdTimeGroup - 1) / kBwdTimeGroup;
     const int64_t waves = lstep_history_filter_bwd_chunks(num_ids) * groups;
     const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -419,15 +457,16 @@ extern "C" int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe
 }
 
 extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
-                                             int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
-                                             int64_t num_ids, const float* coef, void* workspace, float* out, void* stream) {
+                                             int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
+                                             const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out,
+                                             void* stream) {
     if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: negative count");
     if (num_ids == 0) return LSTEP_OK;
     if (int rc = check_hist("lstep_history_filter_runs_fwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
     if (int rc = check_mask("lstep_history_filter_runs_fwd", mask, mask_words, time_slots)) return rc;
-    if (!node_ids || !coef || !out || !workspace || (((uintptr_t)workspace) & 15))
+    if (!node_ids || !coef || !out || !workspace || (((uintptr_t)workspace) & 15) || (((uintptr_t)oldest) & 15))
         return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: NULL or misaligned pointer");
-    HistView h{hist, node_stride, time_stride, time_slots, time_rot};
+    HistView h{hist, node_stride, time_stride, time_slots, time_rot, oldest};
     double* cpre = (double*)workspace;
     const size_t lds_bytes = (size_t)(t_len + 1) * pe_dim * sizeof(double);
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&history_filter_runs_fwd_kernel<true>),
@@ -450,14 +489,14 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
 }
 
 extern "C" int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
-                                             int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const int64_t* node_ids,
-                                             int64_t num_ids, const float* grad_out, float* out_partial, void* stream) {
+                                             int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
+                                             const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial, void* stream) {
     if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_bwd: negative count");
     if (num_ids == 0 || t_len == 0) return LSTEP_OK;
     if (int rc = check_hist("lstep_history_filter_runs_bwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
     if (int rc = check_mask("lstep_history_filter_runs_bwd", mask, mask_words, time_slots)) return rc;
-    if (!node_ids || !grad_out || !out_partial) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_bwd: NULL pointer");
-    HistView h{hist, node_stride, time_stride, time_slots, time_rot};
+    if (!node_ids || !grad_out || !out_partial || (((uintptr_t)oldest) & 15)) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_bwd: NULL or misaligned pointer");
+    HistView h{hist, node_stride, time_stride, time_slots, time_rot, oldest};
     const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
     const int64_t waves = lstep_history_filter_bwd_chunks(num_ids) * groups;
     const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -474,4 +513,28 @@ extern "C" int lstep_history_filter_runs_finish(const float* partial_sum, int32_
     const unsigned grid = (unsigned)((groups * pe_dim + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(history_runs_finish_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, partial_sum, (int)t_len, (int)pe_dim, groups, dcoef);
     return check_launch("history_runs_finish_kernel");
+}
+
+extern "C" int lstep_copy_rows(float* dst, const float* src, int32_t width, int64_t ld, const int64_t* ids, int64_t num_ids, int64_t num_rows,
+                               void* stream) {
+    if (num_ids < 0 || num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_copy_rows: negative count");
+    if (num_ids == 0) return LSTEP_OK;
+    if (!dst || !src || !ids || width <= 0 || (width & 3) || ld < width || (ld & 3) || (((uintptr_t)dst | (uintptr_t)src) & 15))
+        return set_error(LSTEP_EINVAL, "lstep_copy_rows: rows must be 16-byte aligned, width a multiple of 4");
+    const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, dst, src, (int)width, ld, ids, num_ids, num_rows);
+    return check_launch("copy_rows_kernel");
+}
+
+extern "C" int lstep_history_advance_oldest(float* oldest, const float* slot_rows, int32_t width, int64_t ld, const uint32_t* mask,
+                                            int32_t mask_words, int32_t slot, int64_t num_rows, void* stream) {
+    if (num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_history_advance_oldest: negative count");
+    if (num_rows == 0) return LSTEP_OK;
+    if (int rc = check_mask("lstep_history_advance_oldest", mask, mask_words, slot + 1)) return rc;
+    if (!oldest || !slot_rows || slot < 0 || width <= 0 || (width & 3) || ld < width || (ld & 3) || (((uintptr_t)oldest | (uintptr_t)slot_rows) & 15))
+        return set_error(LSTEP_EINVAL, "lstep_history_advance_oldest: rows must be 16-byte aligned, width a multiple of 4");
+    const unsigned grid = (unsigned)((num_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(history_advance_oldest_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, oldest, slot_rows, (int)width, ld, mask,
+                       (int)mask_words, (int)slot, num_rows);
+    return check_launch("history_advance_oldest_kernel");
 }

@@ -48,11 +48,24 @@ class EdgeStream:
 
 
 class HistoryRing:
-    """Last-T PE snapshots, slot-major, plus two spare slots: one for the snapshot being built and one so that the NEXT
-    snapshot's base copy can be prefetched (on a side stream, under the backward pass) without touching the window the
-    pending FFT-filter backward still reads."""
+    """Last-T PE snapshots, slot-major ``[T + 2, rows, P]``, with per-row change bits.
 
-    def __init__(self, num_rows: int, pe_dim: int, num_fft_batches: int, device="cuda"):
+    Every snapshot of the reference is a clone of the one before it plus the rows its batch wrote (train:229,301): bit ``slot`` of row
+    n says "node n's row in physical slot ``slot`` differs from the slot before", and the FFT filter reads one row per run of equal
+    snapshots (``lstep_history_filter_runs_*``).  Whoever writes rows of the snapshot being built must call ``mark``.
+
+    Two ways of keeping the slots:
+    * **sparse** (the single-GPU engine's default): the current PE lives in ``table`` and is updated in place; ``commit`` copies only the
+      rows the batch wrote into the batch's slot (``lstep_copy_rows``, ~21 % of the table on the c4 workload) -- the run kernels never
+      read any other row of a slot -- and ``oldest`` holds the window's oldest snapshot, moved on by ``lstep_history_advance_oldest`` when
+      the window slides (``apply_advance``: after the pending backward pass, which still reads the old window).  ~0.6 GB of row traffic
+      per batch instead of the 2.8 GB of a whole-table clone.
+    * **clones** (``sparse=False``: the owner-sharded rings of ``lstep_amd.parallel``, ``LSTEP_CLONE_HISTORY=1``, and whenever there is
+      no mask -- ``LSTEP_DENSE_HISTORY=1`` or more than 128 slots): every slot is a full snapshot; the snapshot being built lives in a
+      spare slot, and a second spare slot lets the next clone be prefetched on a copy stream under the backward pass without touching
+      the window the pending FFT-filter backward still reads."""
+
+    def __init__(self, num_rows: int, pe_dim: int, num_fft_batches: int, device="cuda", sparse: bool = False):
         self.T = int(num_fft_batches)
         self.S = self.T + 2
         self.rows, self.P = int(num_rows), int(pe_dim)
@@ -61,18 +74,25 @@ class HistoryRing:
         self.len = 0     # snapshots in the window (<= T)
         self._copy_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self._prefetched = None  # (slot index, event) of a base copy issued ahead of time
-        # Change bits: every snapshot is a clone of the one before it plus the rows its batch wrote (train:229,301), so bit `slot` of
-        # row n says "node n's row in physical slot `slot` differs from the slot before"; the FFT filter then reads one row per run of
-        # equal snapshots (lstep_history_filter_runs_*).  Whoever writes rows of the snapshot being built must call ``mark``.
-        # LSTEP_DENSE_HISTORY=1 (A/B switch) or more than 128 slots: no mask, the dense kernels read every snapshot.
         self.words = (self.S + 31) // 32
         on = torch.device(device).type == "cuda" and self.words <= 4 and os.environ.get("LSTEP_DENSE_HISTORY") != "1"
         self.mask = torch.zeros((self.rows, self.words), dtype=torch.int32, device=device) if on else None
+        self.sparse = bool(sparse) and self.mask is not None and os.environ.get("LSTEP_CLONE_HISTORY") != "1"
+        if self.sparse:
+            self.table = torch.zeros((self.rows, self.P), dtype=torch.float32, device=device)    # the current PE (= newest snapshot)
+            self.oldest = torch.zeros((self.rows, self.P), dtype=torch.float32, device=device)   # the window's oldest snapshot
+            self._row0 = torch.zeros(1, dtype=torch.int64, device=device)
+            self._written, self._all_written = [], False   # ids marked for the snapshot being built
+            self._advance, self._oldest_ready = None, None
+        else:
+            self.oldest = None
 
     def begin_slot(self, slot: int = None, all_changed: bool = False):
         """Reset the change bits of the snapshot about to be built (on the current stream): nothing changed yet, or everything."""
         if self.mask is None:
             return
+        if self.sparse and all_changed:
+            self._all_written = True
         slot = (self.start + self.len) % self.S if slot is None else slot
         with torch.cuda.device(self.mask.device):
             nat.check(nat.load_library().lstep_history_slot_bits(nat.ptr(self.mask), self.words, self.rows, int(slot), int(all_changed),
@@ -83,6 +103,8 @@ class HistoryRing:
         were written."""
         if self.mask is None or ids.numel() == 0:
             return
+        if self.sparse:
+            self._written.append(ids)
         slot = (self.start + self.len) % self.S
         with torch.cuda.device(self.mask.device):
             nat.check(nat.load_library().lstep_history_mark(nat.ptr(self.mask), self.words, self.rows, slot, nat.ptr(ids), ids.numel(),
@@ -94,21 +116,62 @@ class HistoryRing:
 
     def last(self) -> torch.Tensor:
         assert self.len > 0
-        return self.buf[(self.start + self.len - 1) % self.S]
+        return self.table if self.sparse else self.buf[(self.start + self.len - 1) % self.S]
 
     def spare(self) -> torch.Tensor:
-        return self.buf[(self.start + self.len) % self.S]
+        return self.table if self.sparse else self.buf[(self.start + self.len) % self.S]
 
     def commit(self):
-        """The spare slot now holds the newest snapshot (``train:301`` append + ``train:224-225`` trim)."""
+        """The snapshot being built is finished (``train:301`` append + ``train:224-225`` trim)."""
+        if self.sparse:
+            lib = nat.load_library()
+            slot = (self.start + self.len) % self.S
+            dst = self.buf[slot]
+            with torch.cuda.device(self.buf.device):
+                if self._all_written or self.len == 0:
+                    dst.copy_(self.table)
+                else:
+                    for ids in self._written + [self._row0]:     # (row 0 is rewritten by every update_pe and always marked)
+                        nat.check(lib.lstep_copy_rows(nat.ptr(dst), nat.ptr(self.table), self.P, self.P, nat.ptr(ids), ids.numel(), self.rows,
+                                                      nat.current_stream()))
+                if self.len == 0:
+                    self.oldest.copy_(self.table)
+            self._written, self._all_written = [], False
         if self.len < self.T:
             self.len += 1
         else:
             self.start = (self.start + 1) % self.S
+            if self.sparse:
+                assert self._advance is None, "HistoryRing.apply_advance() must follow every commit()"
+                self._advance = self.start
+        if self.sparse:
+            self.begin_slot()      # the next snapshot starts with no row written
+
+    def apply_advance(self):
+        """Sparse rings: bring ``oldest`` to the window's new first snapshot after a ``commit`` that slid the window.  Call when the
+        current stream has been given everything that still reads the OLD window (the FFT filter's backward pass): the update runs on
+        the copy stream behind that point, and the next ``wait_oldest`` makes the reader wait for it."""
+        if not self.sparse or self._advance is None:
+            return
+        slot, self._advance = self._advance, None
+        dev = self.buf.device
+        here = torch.cuda.Event()
+        here.record()
+        with torch.cuda.device(dev), torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(here)
+            nat.check(nat.load_library().lstep_history_advance_oldest(nat.ptr(self.oldest), nat.ptr(self.buf[slot]), self.P, self.P,
+                                                                      nat.ptr(self.mask), self.words, slot, self.rows, nat.current_stream()))
+            self._oldest_ready = torch.cuda.Event()
+            self._oldest_ready.record()
+
+    def wait_oldest(self):
+        if self.sparse and self._oldest_ready is not None:
+            torch.cuda.current_stream(self.buf.device).wait_event(self._oldest_ready)
+            self._oldest_ready = None
 
     def prefetch_base(self):
-        """Start copying the newest snapshot into the next spare slot on the copy stream (call right after ``commit``)."""
-        if self._copy_stream is None or self.len == 0 or os.environ.get("LSTEP_NO_PREFETCH") == "1":
+        """Clone mode: start copying the newest snapshot into the next spare slot on the copy stream (call right after ``commit``)."""
+        if self.sparse or self._copy_stream is None or self.len == 0 or os.environ.get("LSTEP_NO_PREFETCH") == "1":
             return
         slot = (self.start + self.len) % self.S
         main = torch.cuda.current_stream(self.buf.device)
@@ -121,8 +184,10 @@ class HistoryRing:
         self._prefetched = (slot, ev)
 
     def base_for_next(self) -> torch.Tensor:
-        """The spare slot holding a copy of the newest snapshot (``torch.clone(positional_encoding[:, -1, :])``, train:229):
-        the prefetched one if ``prefetch_base`` ran for this slot, otherwise copied now."""
+        """The table the next snapshot is built in, holding the newest snapshot (``torch.clone(positional_encoding[:, -1, :])``,
+        train:229).  Clone mode: the spare slot -- the prefetched copy if ``prefetch_base`` ran for it, otherwise copied now."""
+        if self.sparse:
+            return self.table
         slot = (self.start + self.len) % self.S
         cur = self.buf[slot]
         if self._prefetched is not None and self._prefetched[0] == slot:
@@ -141,10 +206,22 @@ class HistoryRing:
         self._prefetched = None
         if keep:
             self.buf[:keep].copy_(history[:, t - keep:, :].permute(1, 0, 2))
+        self.adopt_full_slots()
+
+    def adopt_full_slots(self):
+        """The window's slots were filled with FULL snapshots from outside (``load``, a synthetic pre-fill): derive the change bits from
+        them and, for a sparse ring, the ``oldest`` / current tables."""
         self.recompute_mask()
+        if self.sparse:
+            self._written, self._all_written, self._advance, self._oldest_ready = [], False, None, None
+            if self.len:
+                self.oldest.copy_(self.buf[self.start])
+                self.table.copy_(self.buf[(self.start + self.len - 1) % self.S])
+            self.begin_slot()
 
     def recompute_mask(self):
-        """Change bits of the whole window from the stored rows (after ``load`` or any direct write into ``buf``)."""
+        """Change bits of the whole window from the stored rows; only meaningful while every slot of the window holds a full snapshot
+        (clone mode, or right after ``load`` / a pre-fill)."""
         if self.mask is None:
             return
         self.mask.zero_()
@@ -161,7 +238,23 @@ class HistoryRing:
     def as_reference_tensor(self) -> torch.Tensor:
         """``[N+1, t, P]`` copy of the window, oldest first (tests / checkpoint parity with ``EarlyStopping.save_pe``)."""
         idx = [(self.start + i) % self.S for i in range(self.len)]
-        return self.buf[idx].permute(1, 0, 2).contiguous()
+        if not self.sparse:
+            return self.buf[idx].permute(1, 0, 2).contiguous()
+        torch.cuda.synchronize(self.buf.device)
+        out = torch.empty((self.rows, self.len, self.P), dtype=torch.float32, device=self.buf.device)
+        oldest = self.oldest
+        if self._advance is not None:       # the window slid but ``oldest`` has not been moved on yet
+            oldest = oldest.clone()
+            ph = self._advance
+            hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool()
+            oldest[hit] = self.buf[ph][hit]
+        for i, ph in enumerate(idx):
+            if i == 0:
+                out[:, 0] = oldest
+            else:
+                hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool()
+                out[:, i] = torch.where(hit.unsqueeze(1), self.buf[ph], out[:, i - 1])
+        return out
 
 
 class _LookupRows(torch.autograd.Function):
@@ -235,7 +328,7 @@ class LstepEngine:
         self.device = dev
         rows = backbone.node_raw_features.shape[0]
         # make_ring=False: lstep_amd.parallel.DistributedLstep owns an owner-sharded ring instead
-        self.ring = HistoryRing(rows, backbone.pe_dim, backbone.num_fft_batches, dev) if make_ring else None
+        self.ring = HistoryRing(rows, backbone.pe_dim, backbone.num_fft_batches, dev, sparse=True) if make_ring else None
         # update_pe on a side stream underneath the backward pass (LSTEP_NO_OVERLAP=1 runs the reference order serially)
         self.overlap_update = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_OVERLAP") != "1"
         self._update_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
@@ -249,7 +342,8 @@ class LstepEngine:
     def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):
         """FFT-filter the batch rows over the ring window and build the current PE in the spare slot (train:224-230)."""
         ring = self.ring
-        rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask)
+        ring.wait_oldest()
+        rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest)
         cur = ring.base_for_next()
         cur.index_copy_(0, batch_nodes, rows.detach())   # (these rows are marked as changed by update_pe's phase 1: same node set)
         self.slot_of[batch_nodes] = torch.arange(batch_nodes.numel(), dtype=torch.int32, device=self.device)
@@ -355,6 +449,7 @@ class LstepEngine:
                 bb.join_aux_stream()
                 optimizer.step()
                 self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
+            ring.apply_advance()      # (after the backward pass, which still reads the window as it was)
             return out
 
         # update_pe (forward-only, reads and writes only the current PE table) and the backward pass (never reads that table)
@@ -382,6 +477,7 @@ class LstepEngine:
         th.join()
         if err:
             raise err[0]
+        ring.apply_advance()  # the backward pass is enqueued: the window's oldest snapshot may move on behind it (copy stream)
         main.wait_stream(side)
         optimizer.step()      # after update_pe has read its weights
         self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
@@ -408,4 +504,5 @@ class LstepEngine:
                      node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted,
                      changed=ring.mark)
         ring.commit()
+        ring.apply_advance()
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

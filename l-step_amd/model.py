@@ -320,19 +320,25 @@ class _TailWeightsReplay(torch.autograd.Function):
         if aux is not None:      # the operand gradients are produced on the auxiliary stream (postponed): queue up behind them
             def on_aux():
                 with torch.cuda.stream(aux):
-                    _TailWeightsReplay._backward(ctx, tw, grads)
+                    _TailWeightsReplay._backward(ctx, tw, grads, on_aux_stream=True)
             _defer(tw.params[0].device, on_aux)
             return (None,) * (1 + len(tw.params))
         return _TailWeightsReplay._backward(ctx, tw, grads)
 
     @staticmethod
-    def _backward(ctx, tw, grads):
+    def _backward(ctx, tw, grads, on_aux_stream=False):
         for buf, g in zip(tw.gin, grads[:len(tw.gin)]):
             if g is None:
                 buf.zero_()
             elif g.data_ptr() != buf.data_ptr():
                 buf.copy_(g)
-        for p, g in zip(tw.params, tw.backward()):
+        for i, (p, g) in enumerate(zip(tw.params, tw.backward())):
+            if i == 2 and on_aux_stream:
+                # edge_agg.weight also receives a gradient through autograd (the gather stage, on the critical stream).  Autograd adds
+                # into an existing .grad IN PLACE on its own stream: if .grad were this static buffer, which the auxiliary stream
+                # fills later, that contribution would be overwritten.  The two parts meet in LSTEP.join_aux_stream instead.
+                _PENDING_AUX_GRADS.setdefault(p.device, []).append((p, g))
+                continue
             if p.grad is None:
                 p.grad = g.detach()
             else:
@@ -342,6 +348,7 @@ class _TailWeightsReplay(torch.autograd.Function):
 
 
 _AUX_STREAMS = {}
+_PENDING_AUX_GRADS = {}   # device -> [(parameter, gradient part produced on the auxiliary stream)]: added in LSTEP.join_aux_stream
 
 
 def _aux_stream(dev):
@@ -807,7 +814,7 @@ class _HistoryFilter(torch.autograd.Function):
     the ``*_runs_*`` kernels read one row per run of equal snapshots instead of one per snapshot."""
 
     @staticmethod
-    def forward(ctx, coef, hist_base, geom, ids, mask=None):
+    def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None):
         lib = nat.load_library()
         node_stride, time_stride, slots, rot, t_len, P = geom
         U = ids.numel()
@@ -820,12 +827,12 @@ class _HistoryFilter(torch.autograd.Function):
             else:
                 ws = nat._workspace(ids.device, int(lib.lstep_history_filter_runs_workspace(t_len, P)))
                 nat.check(lib.lstep_history_filter_runs_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(mask),
-                                                            int(mask.shape[1]), nat.ptr(ids), U, nat.ptr(cc), nat.ptr(ws), nat.ptr(out),
-                                                            nat.current_stream()))
+                                                            int(mask.shape[1]), nat.ptr(oldest), nat.ptr(ids), U, nat.ptr(cc), nat.ptr(ws),
+                                                            nat.ptr(out), nat.current_stream()))
         ctx.geom, ctx.coef_shape = geom, tuple(coef.shape)
         # NOT save_for_backward: the device ring appends its next snapshot (a slot outside this window) in place
         # before backward runs; the window itself (rows and mask bits) is guaranteed untouched by HistoryRing (engine.py).
-        ctx.hist, ctx.mask = hist_base, mask
+        ctx.hist, ctx.mask, ctx.oldest = hist_base, mask, oldest
         ctx.save_for_backward(ids)
         return out
 
@@ -848,11 +855,11 @@ class _HistoryFilter(torch.autograd.Function):
                     g_coef[:t_len] = partial.sum(dim=0)
                 else:
                     nat.check(lib.lstep_history_filter_runs_bwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P,
-                                                                nat.ptr(mask), int(mask.shape[1]), nat.ptr(ids), U, nat.ptr(g),
-                                                                nat.ptr(partial), nat.current_stream()))
+                                                                nat.ptr(mask), int(mask.shape[1]), nat.ptr(ctx.oldest), nat.ptr(ids), U,
+                                                                nat.ptr(g), nat.ptr(partial), nat.current_stream()))
                     diff = partial.sum(dim=0)
                     nat.check(lib.lstep_history_filter_runs_finish(nat.ptr(diff), t_len, P, nat.ptr(g_coef), nat.current_stream()))
-        return g_coef, None, None, None, None
+        return g_coef, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ backbone
@@ -1006,6 +1013,8 @@ class LSTEP(nn.Module):
         _flush_deferred()
         for dev, st in _AUX_STREAMS.items():     # keyed by the tensors' device (always indexed, unlike a bare "cuda")
             torch.cuda.current_stream(dev).wait_stream(st)
+            for p, g in _PENDING_AUX_GRADS.pop(dev, []):     # (see _TailWeightsReplay._backward)
+                p.grad = g.detach().clone() if p.grad is None else p.grad + g
             _AUX_PARAM_EVENT.pop(dev, None)
 
     def _fused_tail_ok(self) -> bool:
@@ -1110,11 +1119,13 @@ class LSTEP(nn.Module):
         geom = (int(hist.stride(0)), int(hist.stride(1)), t_len, 0, t_len, self.pe_dim)
         return self.filter_history(hist, geom, self._ids(node_ids), batch_idx)
 
-    def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int, mask: torch.Tensor = None):
+    def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int, mask: torch.Tensor = None,
+                       oldest: torch.Tensor = None):
         """Shared by the drop-in method above and the device ring of ``lstep_amd.engine`` (geom = strides/rotation; ``mask`` = the
-        ring's change bits, see ``HistoryRing``)."""
+        ring's change bits, ``oldest`` = its table of the window's oldest snapshot when the slots only hold changed rows, see
+        ``HistoryRing``)."""
         coef = self.fft_coefficients(geom[4], batch_idx)
-        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask)
+        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask, oldest)
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).

@@ -83,7 +83,7 @@ def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int
         for s in range(ring.T):
             ring.buf[s].normal_(0.0, 0.1, generator=gen)
         ring.start, ring.len = 0, ring.T
-        ring.recompute_mask()       # random snapshots: every row differs from the one before (the dense worst case; see evolve_history)
+        ring.adopt_full_slots()     # random snapshots: every row differs from the one before (the dense worst case; see evolve_history)
     return Workload(name, n, e, b, k, time_gap, num_fft_batches, EdgeStream(src, dst, ts, eid), model, eng, sampler)
 
 
@@ -98,7 +98,7 @@ def prefill_distributed(dl, seed: int = 0):
         ring.buf[s].normal_(0.0, 0.1, generator=gen)
     ring.buf[ring.T - 1].copy_(dl.table[dl.rank::dl.W])  # newest snapshot = the current table's owned rows
     ring.start, ring.len = 0, ring.T
-    ring.recompute_mask()
+    ring.adopt_full_slots()
 
 
 def evolve_history(runner, stream: EdgeStream, first_edge: int, batch: int, num_nodes: int, seed: int = 4321) -> int:

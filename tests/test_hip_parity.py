@@ -851,9 +851,13 @@ def test_history_runs_kernels_match_dense_kernels_and_float64(hip, rows, P, T, l
     coef = torch.randn(T, P, generator=g).to(DEV).requires_grad_(True)
     gout = torch.randn(U, P, generator=g).to(DEV)
     outs = []
-    for mask in (None, ring.mask):
+    # third variant: slots that only hold the rows their batch wrote (every other row poisoned with NaN) + the table of the oldest snapshot
+    sparse_buf = torch.from_numpy(np.where(changed[:, :, None], buf, np.float32("nan"))).to(DEV)
+    sparse_buf[:, 0] = torch.from_numpy(buf[:, 0]).to(DEV)          # row 0 is always marked
+    oldest = torch.from_numpy(buf[start].copy()).to(DEV)
+    for hist, mask, old in ((ring.buf, None, None), (ring.buf, ring.mask, None), (sparse_buf, ring.mask, oldest)):
         coef.grad = None
-        out = _HistoryFilter.apply(coef, ring.buf, ring.geom(), ids, mask)
+        out = _HistoryFilter.apply(coef, hist, ring.geom(), ids, mask, old)
         out.backward(gout)
         outs.append((out.detach().cpu().numpy(), coef.grad.cpu().numpy().copy()))
     hist = torch.from_numpy(buf[window]).double()[:, ids.cpu()]              # [t, U, P]
@@ -919,18 +923,20 @@ def test_engine_change_mask_equals_dense_history(hip, monkeypatch):
             if res is not None:
                 losses.append([res["loss"].item(), res["lp_loss"].item(), res["pe_loss"].item()])
         torch.cuda.synchronize()
-        if not dense:       # the maintained bits are exactly "row differs from the previous snapshot" (plus row 0), and far from all-ones
+        bits = None
+        if not dense:
             ring = eng.ring
-            kept = ring.mask.clone()
-            ring.recompute_mask()
+            assert ring.sparse      # slots hold only the rows their batch wrote; as_reference_tensor() rebuilds the snapshots from them
             window = [(ring.start + i) % ring.S for i in range(1, ring.len)]
-            unpack = lambda m: ((m.cpu().numpy().view(np.uint32)[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(ring.rows, -1)  # noqa: E731
-            a, e = unpack(kept)[:, window], unpack(ring.mask)[:, window]
-            assert (a >= e).all(), "a changed row is not marked"
-            assert a.mean() < 0.3 and (a != e).mean() < 0.02
-            ring.mask.copy_(kept)
-        out.append((np.array(losses), eng.ring.as_reference_tensor().cpu().numpy()))
-    (la, ha), (lb, hb) = out
+            bits = ((ring.mask.cpu().numpy().view(np.uint32)[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(ring.rows, -1)[:, window]
+        out.append((np.array(losses), eng.ring.as_reference_tensor().cpu().numpy(), bits))
+    (la, ha, a), (lb, hb, _) = out
+    # the maintained bits against the history of the run that stored every snapshot in full: every row that differs from the snapshot
+    # before it is marked, hardly any other row is, and the bits are far from all-ones
+    e = (hb[:, 1:] != hb[:, :-1]).any(axis=2)
+    e[0, :] = True
+    assert (a >= e).all(), "a changed row is not marked"
+    assert a.mean() < 0.3 and (a != e).mean() < 0.02
     np.testing.assert_allclose(la, lb, rtol=0, atol=5e-6)
     np.testing.assert_allclose(ha, hb, rtol=0, atol=5e-5)     # (Adam at lr 1e-3 amplifies the re-ordered sums of the two filters)
 
