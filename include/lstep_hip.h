@@ -142,7 +142,9 @@ int lstep_history_mark(uint32_t* mask, int32_t mask_words, int64_t num_rows, int
 int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe_dim);
 /* oldest (optional, [num_rows, node_stride]): the window's oldest snapshot.  With it the slots need not be full clones: a slot only has to hold
  * the rows its batch wrote (the marked ones), the kernels read nothing else -- the ring then appends lstep_copy_rows of the written rows per
- * batch instead of cloning the table, and moves `oldest` on with lstep_history_advance_oldest when the window slides. */
+ * batch instead of cloning the table, and moves `oldest` on with lstep_history_advance_oldest when the window slides.  A row whose bit
+ * of the window's first slot is set is read from that slot, not from `oldest`: `oldest` may therefore still be one slide behind (the
+ * rows it has yet to take over are exactly those), which lets the ring move it on concurrently with the next forward pass. */
 int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                   int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                   const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out, void* stream);
@@ -274,9 +276,10 @@ int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float
  * such that pe_dim + time_dim = 272):  z = w2 relu(w1 agg[r] + b1) + b2 (+ ws table[ids[r]] + bs when ws != NULL: phase 1;
  * phase 2 passes NULL, the reference discards that term), then IN PLACE table[ids[r], :] += tanh(z).
  * agg [>= n, ld_agg] = the segment sums of lstep_segment_rows_sum; ids int64 [n], unique; weights zero-padded to
- * w1 [176, 272], w2 / ws [176, 176], biases [176]. */
+ * w1 [176, 272], w2 / ws [176, 176], biases [176].  mirror (optional): a second [rows, pe_dim] table that receives the new rows as well
+ * -- the batch's history slot, so that appending the snapshot (train_link_prediction.py:301) costs no separate copy. */
 int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
-                      const float* b2, const float* ws, const float* bs, float* table, int32_t pe_dim, void* stream);
+                      const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim, void* stream);
 
 /* out[slot[i], :width] += rows[i, :width] for every i with slot[i] >= 0 (float atomics).  The stragglers of the spliced-row gradient:
  * negative-sample rows whose own node happens to be a batch node (a few hundred per batch; everything else goes through the sorted,

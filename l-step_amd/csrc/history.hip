@@ -18,9 +18,11 @@ struct HistView {
         if (ph >= slots) ph -= slots;
         return base + node * node_stride + (int64_t)ph * time_stride;
     }
-    // the row of the run that begins at snapshot s (s = 0: the window's oldest snapshot)
-    __device__ __forceinline__ const float* begin_row(int64_t node, int s) const {
-        return (s == 0 && oldest) ? oldest + node * node_stride : row(node, s);
+    // The row of the run that begins at snapshot s.  s = 0, the window's oldest snapshot: its slot holds the row if that batch wrote it
+    // (`first_written`), otherwise the row is older than the window and lives in `oldest` -- which may lag one window slide behind:
+    // the rows it still has to take over are exactly the ones read from the slot here.
+    __device__ __forceinline__ const float* begin_row(int64_t node, int s, bool first_written) const {
+        return (s == 0 && oldest && !first_written) ? oldest + node * node_stride : row(node, s);
     }
 };
 
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fw
 #pragma unroll
             for (int i = 0; i < kRunsInFlight; ++i) {
                 x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (st[i] < t_len) x[i] = ld4_stream(h.begin_row(node_now, st[i]) + col);
+                if (st[i] < t_len) x[i] = ld4_stream(h.begin_row(node_now, st[i], b.test(0)) + col);
             }
 #pragma unroll
             for (int i = 0; i <= kRunsInFlight; ++i) {      // the prefix table has t_len + 1 rows
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void history_filter_runs_bwd_kernel(HistVie
 #pragma unroll
         for (int i = 0; i < kRunsTimeGroup; ++i) {
             x[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (defined on both paths: otherwise the merge costs a copy and a wait per load)
-            if ((begins >> i) & 1u) x[i] = ld4_stream(h.begin_row(node_now, i == 0 ? first : s0 + i) + col);
+            if ((begins >> i) & 1u) x[i] = ld4_stream(h.begin_row(node_now, i == 0 ? first : s0 + i, b.test(0)) + col);
         }
         float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

@@ -83,7 +83,9 @@ class HistoryRing:
             self.oldest = torch.zeros((self.rows, self.P), dtype=torch.float32, device=device)   # the window's oldest snapshot
             self._row0 = torch.zeros(1, dtype=torch.int64, device=device)
             self._written, self._all_written = [], False   # ids marked for the snapshot being built
-            self._advance, self._oldest_ready = None, None
+            self._advance = None
+            self._advanced = [None, None]            # events of the last two ``apply_advance`` calls
+            self.advance_stream = None               # stream ``apply_advance`` runs on (default: the ring's copy stream)
         else:
             self.oldest = None
 
@@ -98,12 +100,20 @@ class HistoryRing:
             nat.check(nat.load_library().lstep_history_slot_bits(nat.ptr(self.mask), self.words, self.rows, int(slot), int(all_changed),
                                                                  nat.current_stream()))
 
-    def mark(self, ids: torch.Tensor, world: int = 1, rank: int = 0):
+    def written(self, ids: torch.Tensor, mirrored: bool = False):
+        """``update_pe``'s callback: rows ``ids`` were written (``mirrored``: into ``building()`` as well, nothing left to copy)."""
+        self.mark(ids, copy=not mirrored)
+
+    def building(self):
+        """Sparse rings: the slot of the snapshot being built, for writers that can put their rows there directly (``lstep_update_rows``)."""
+        return self.buf[(self.start + self.len) % self.S] if self.sparse else None
+
+    def mark(self, ids: torch.Tensor, world: int = 1, rank: int = 0, copy: bool = True):
         """Rows ``ids`` (int64 node ids; ``world > 1``: only those owned by ``rank``, stored at row id // world) of the snapshot being built
-        were written."""
+        were written (``copy=False``: and the writer has already put them into ``building()``)."""
         if self.mask is None or ids.numel() == 0:
             return
-        if self.sparse:
+        if self.sparse and copy:
             self._written.append(ids)
         slot = (self.start + self.len) % self.S
         with torch.cuda.device(self.mask.device):
@@ -124,6 +134,8 @@ class HistoryRing:
     def commit(self):
         """The snapshot being built is finished (``train:301`` append + ``train:224-225`` trim)."""
         if self.sparse:
+            # whatever the writers have not put into the slot themselves (update_pe's fused kernels do) is copied now: row 0, and the
+            # rows of writers without a mirror (library-GEMM update path)
             lib = nat.load_library()
             slot = (self.start + self.len) % self.S
             dst = self.buf[slot]
@@ -150,24 +162,32 @@ class HistoryRing:
     def apply_advance(self):
         """Sparse rings: bring ``oldest`` to the window's new first snapshot after a ``commit`` that slid the window.  Call when the
         current stream has been given everything that still reads the OLD window (the FFT filter's backward pass): the update runs on
-        the copy stream behind that point, and the next ``wait_oldest`` makes the reader wait for it."""
+        the copy stream behind that point.  Readers of the NEW window need not wait for it -- they take the rows it moves from the
+        first slot itself (``lstep_history_filter_runs_*``) -- only for the update before it (``wait_window``)."""
         if not self.sparse or self._advance is None:
             return
         slot, self._advance = self._advance, None
         dev = self.buf.device
         here = torch.cuda.Event()
         here.record()
-        with torch.cuda.device(dev), torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(here)
+        side = self.advance_stream or self._copy_stream
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            side.wait_event(here)
             nat.check(nat.load_library().lstep_history_advance_oldest(nat.ptr(self.oldest), nat.ptr(self.buf[slot]), self.P, self.P,
                                                                       nat.ptr(self.mask), self.words, slot, self.rows, nat.current_stream()))
-            self._oldest_ready = torch.cuda.Event()
-            self._oldest_ready.record()
+            ev = torch.cuda.Event()
+            ev.record()
+        self._advanced = [self._advanced[1], ev]
 
-    def wait_oldest(self):
-        if self.sparse and self._oldest_ready is not None:
-            torch.cuda.current_stream(self.buf.device).wait_event(self._oldest_ready)
-            self._oldest_ready = None
+    def wait_window(self):
+        """Make the current stream wait until the window can be read: ``oldest`` is at most one slide behind."""
+        if not self.sparse:
+            return
+        st = torch.cuda.current_stream(self.buf.device)
+        if self._advance is not None and self._advanced[1] is not None:     # a slide is still pending: the one before it must be done
+            st.wait_event(self._advanced[1])
+        elif self._advanced[0] is not None:
+            st.wait_event(self._advanced[0])
 
     def prefetch_base(self):
         """Clone mode: start copying the newest snapshot into the next spare slot on the copy stream (call right after ``commit``)."""
@@ -213,7 +233,7 @@ class HistoryRing:
         them and, for a sparse ring, the ``oldest`` / current tables."""
         self.recompute_mask()
         if self.sparse:
-            self._written, self._all_written, self._advance, self._oldest_ready = [], False, None, None
+            self._written, self._all_written, self._advance, self._advanced = [], False, None, [None, None]
             if self.len:
                 self.oldest.copy_(self.buf[self.start])
                 self.table.copy_(self.buf[(self.start + self.len - 1) % self.S])
@@ -242,15 +262,10 @@ class HistoryRing:
             return self.buf[idx].permute(1, 0, 2).contiguous()
         torch.cuda.synchronize(self.buf.device)
         out = torch.empty((self.rows, self.len, self.P), dtype=torch.float32, device=self.buf.device)
-        oldest = self.oldest
-        if self._advance is not None:       # the window slid but ``oldest`` has not been moved on yet
-            oldest = oldest.clone()
-            ph = self._advance
-            hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool()
-            oldest[hit] = self.buf[ph][hit]
         for i, ph in enumerate(idx):
-            if i == 0:
-                out[:, 0] = oldest
+            if i == 0:      # rows the first slot's batch wrote are in the slot (``oldest`` may not have taken them over yet)
+                hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool()
+                out[:, 0] = torch.where(hit.unsqueeze(1), self.buf[ph], self.oldest)
             else:
                 hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool()
                 out[:, i] = torch.where(hit.unsqueeze(1), self.buf[ph], out[:, i - 1])
@@ -337,12 +352,15 @@ class LstepEngine:
         # the engine joins the auxiliary stream before every optimiser step, so the model may put its weight-gradient products there
         backbone.aux_wgrad_stream = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
         predictor.aux_wgrad_stream = backbone.aux_wgrad_stream
+        if self.ring is not None and self.ring.sparse and backbone.aux_wgrad_stream:
+            from .model import _aux_stream
+            self.ring.advance_stream = _aux_stream(dev)    # idle between the weight gradients and the next weight composition
 
     # ---- shared pieces
     def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):
         """FFT-filter the batch rows over the ring window and build the current PE in the spare slot (train:224-230)."""
         ring = self.ring
-        ring.wait_oldest()
+        ring.wait_window()
         rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest)
         cur = ring.base_for_next()
         cur.index_copy_(0, batch_nodes, rows.detach())   # (these rows are marked as changed by update_pe's phase 1: same node set)
@@ -435,7 +453,7 @@ class LstepEngine:
         def update_and_append():
             bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
                          node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G,
-                         presorted=presorted, changed=ring.mark)
+                         presorted=presorted, changed=ring.written, mirror=ring.building())
             if batch_idx == 0 and initial_pe is not None:
                 initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
             ring.commit()
@@ -502,7 +520,7 @@ class LstepEngine:
             self.prefetch_batch_nodes(*lookahead)
         bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
                      node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted,
-                     changed=ring.mark)
+                     changed=ring.written, mirror=ring.building())
         ring.commit()
         ring.apply_advance()
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

@@ -1178,7 +1178,7 @@ class LSTEP(nn.Module):
         return self._padded_cached("update_mlp", (m1.weight, m1.bias, m2.weight, m2.bias), lambda: (
             _pad2(m1.weight.detach(), Pp, Cp).t(), _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).t(), _pad1(m2.bias.detach(), Pp)))
 
-    def _update_rows(self, pe, ids, agg, with_self: bool):
+    def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None):
         """``lstep_update_rows``: pe[ids] += tanh(pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(pe[ids])]) in place, one launch."""
         lib = nat.load_library()
         Pp = self.ld_self
@@ -1193,7 +1193,8 @@ class LSTEP(nn.Module):
         ids = ids.contiguous()
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_update_rows(nat.ptr(agg), int(agg.stride(0)), nat.ptr(ids), ids.numel(), nat.ptr(w1), nat.ptr(b1), nat.ptr(w2),
-                                            nat.ptr(b2), nat.ptr(ws), nat.ptr(bs), nat.ptr(pe), self.pe_dim, nat.current_stream()))
+                                            nat.ptr(b2), nat.ptr(ws), nat.ptr(bs), nat.ptr(pe), nat.ptr(mirror), self.pe_dim,
+                                            nat.current_stream()))
 
     @classmethod
     def _bucket_rows(cls, n: int) -> int:
@@ -1219,7 +1220,8 @@ class LSTEP(nn.Module):
                                                    nat.current_stream()))
 
     @torch.no_grad()
-    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None, fused: bool = False, owned_idx=None):
+    def update_pe_phase1(self, pe, bn, src, dst, t, now32: float, shard=None, presorted=None, fused: bool = False, owned_idx=None,
+                         mirror=None):
         """U1 (LSTEP.py:277-303): every batch edge sends cat[pe[other endpoint], time_feat] to both endpoints.
         Returns (ids, z) with the new row = pe[ids] + tanh(z), WITHOUT writing (``fused=True``: writes the rows in place with
         ``lstep_update_rows`` and returns ids only); ``shard=(W, r)`` restricts the work to
@@ -1241,7 +1243,7 @@ class LSTEP(nn.Module):
                                                       nat.ptr(ent_row), nat.ptr(ent_dt), nat.current_stream()))
             agg = self._segment_sum(pe, bn.numel(), seg32, ent_row, ent_dt, exact=True)
             if shard is None:
-                self._update_rows(pe, bn, agg, with_self=True)
+                self._update_rows(pe, bn, agg, with_self=True, mirror=mirror)
                 return bn
             # sharded: the message sums of all batch nodes are cheap (2 rows per batch edge) and every rank has the inputs; only the
             # rows this rank owns go through the MLP and are written
@@ -1280,7 +1282,7 @@ class LSTEP(nn.Module):
                                 exact=fused and presorted is not None)
         n = ids.numel()
         if fused:   # MLP + self term + tanh + residual + in-place row write in one launch
-            self._update_rows(pe, ids, agg, with_self=True)
+            self._update_rows(pe, ids, agg, with_self=True, mirror=mirror)
             return ids
         own = torch.zeros((agg.shape[0], self.pe_dim), dtype=torch.float32, device=pe.device)
         own[:n] = pe[ids]
@@ -1292,7 +1294,7 @@ class LSTEP(nn.Module):
         return ids, z[:n]
 
     @torch.no_grad()
-    def update_pe_phase2(self, pe, bn, t, now32: float, num_neighbors: int, shard=None, fused: bool = False):
+    def update_pe_phase2(self, pe, bn, t, now32: float, num_neighbors: int, shard=None, fused: bool = False, mirror=None):
         """U2 (LSTEP.py:305-339): push the updated PE of each batch node to its K most recent neighbours.
         ``bn`` (U rows) is zipped with the B edge times: row i uses t[i]; rows >= min(U, B) stay padding.
         Sets pe[0] = 0 (LSTEP.py:317) before reading.  Returns (touched ids, z) with new row = pe[id] + tanh(z), WITHOUT
@@ -1305,7 +1307,7 @@ class LSTEP(nn.Module):
         rows = pe.shape[0]
         pe[0].zero_()
         if fused and isinstance(now32, torch.Tensor) and os.environ.get("LSTEP_TORCH_ENTRIES") != "1":
-            return self._phase2_native(pe, bn, nbr, nt, now32, num_neighbors, shard)
+            return self._phase2_native(pe, bn, nbr, nt, now32, num_neighbors, shard, mirror)
         real = key != 0
         if shard is not None:
             real = real & ((key % shard[0]) == shard[1])
@@ -1336,11 +1338,11 @@ class LSTEP(nn.Module):
         else:
             agg2 = self._segment_sum(pe, nseg, inverse, ent_row, ent_dt, exact=fused)
         if fused:
-            self._update_rows(pe, touched, agg2, with_self=False)
+            self._update_rows(pe, touched, agg2, with_self=False, mirror=mirror)
             return touched
         return touched, self._update_mlp(agg2)[:touched.numel()]
 
-    def _phase2_native(self, pe, bn, nbr, nt, now32, num_neighbors, shard):
+    def _phase2_native(self, pe, bn, nbr, nt, now32, num_neighbors, shard, mirror=None):
         """Phase 2 with the key / entry lists built by native kernels (lstep_update_keys_p2, lstep_update_entries_p2): ~10 launches
         instead of ~35 framework ones; same grouping, same order of summation."""
         lib = nat.load_library()
@@ -1373,13 +1375,14 @@ class LSTEP(nn.Module):
                 nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), int(num_neighbors), nat.ptr(bn), U, nat.ptr(pe), P, int(pe.stride(0)),
                                                      nat.ptr(part), nat.current_stream()))
             agg2[0, :P] = part.sum(dim=0)
-        self._update_rows(pe, touched, agg2, with_self=False)
+        self._update_rows(pe, touched, agg2, with_self=False, mirror=mirror)
         return touched
 
     @torch.no_grad()
     def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,
-                  num_neighbors: int = 30, time_gap: int = 2000, presorted=None, changed=None):
-        """``changed`` (optional callable): receives the int64 ids of the rows each phase wrote (the device ring's change mask)."""
+                  num_neighbors: int = 30, time_gap: int = 2000, presorted=None, changed=None, mirror=None):
+        """``changed`` (optional callable): receives the int64 ids of the rows each phase wrote (the device ring's change mask) and
+        whether they were also written into ``mirror`` (optional second table, the batch's history slot: fused path only)."""
         if not (pe.is_cuda and pe.dtype == torch.float32 and pe.is_contiguous()):
             raise ValueError("update_pe needs a contiguous float32 GPU table (it is mutated in place)")
         if pe.dim() != 2 or pe.shape[1] != self.pe_dim or pe.shape[0] < self.neighbor_sampler.num_rows:
@@ -1392,19 +1395,19 @@ class LSTEP(nn.Module):
         now32 = current_time.detach().to(device=pe.device, dtype=torch.float32).reshape(()) if isinstance(current_time, torch.Tensor) \
             else float(np.float32(current_time))
         if self._fused_tail_ok() and os.environ.get("LSTEP_TORCH_UPDATE") != "1":
-            ids = self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted, fused=True)
+            ids = self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted, fused=True, mirror=mirror)
             if changed is not None:
-                changed(ids)
-            ids = self.update_pe_phase2(pe, bn, t, now32, num_neighbors, fused=True)
+                changed(ids, mirror is not None)
+            ids = self.update_pe_phase2(pe, bn, t, now32, num_neighbors, fused=True, mirror=mirror)
             if changed is not None:
-                changed(ids)
+                changed(ids, mirror is not None)
             return pe
         ids, z = self.update_pe_phase1(pe, bn, src, dst, t, now32, presorted=presorted)
         self.apply_residual_tanh(pe, ids, z)
         if changed is not None:
-            changed(ids)
+            changed(ids, False)
         ids, z = self.update_pe_phase2(pe, bn, t, now32, num_neighbors)
         self.apply_residual_tanh(pe, ids, z)
         if changed is not None:
-            changed(ids)
+            changed(ids, False)
         return pe

@@ -851,15 +851,27 @@ def test_history_runs_kernels_match_dense_kernels_and_float64(hip, rows, P, T, l
     coef = torch.randn(T, P, generator=g).to(DEV).requires_grad_(True)
     gout = torch.randn(U, P, generator=g).to(DEV)
     outs = []
-    # third variant: slots that only hold the rows their batch wrote (every other row poisoned with NaN) + the table of the oldest snapshot
-    sparse_buf = torch.from_numpy(np.where(changed[:, :, None], buf, np.float32("nan"))).to(DEV)
-    sparse_buf[:, 0] = torch.from_numpy(buf[:, 0]).to(DEV)          # row 0 is always marked
-    oldest = torch.from_numpy(buf[start].copy()).to(DEV)
-    for hist, mask, old in ((ring.buf, None, None), (ring.buf, ring.mask, None), (sparse_buf, ring.mask, oldest)):
+    for hist, mask, old in ((ring.buf, None, None), (ring.buf, ring.mask, None)):
         coef.grad = None
         out = _HistoryFilter.apply(coef, hist, ring.geom(), ids, mask, old)
         out.backward(gout)
         outs.append((out.detach().cpu().numpy(), coef.grad.cpu().numpy().copy()))
+    if length >= 2:
+        # slots that only hold the rows their batch wrote (every other row poisoned with NaN), window = snapshots 1 .. length-1, and an
+        # `oldest` table that is still one slide behind (= snapshot 0): rows written by snapshot 1's batch must come from its slot
+        sparse_buf = torch.from_numpy(np.where(changed[:, :, None], buf, np.float32("nan"))).to(DEV)
+        sparse_buf[:, 0] = torch.from_numpy(buf[:, 0]).to(DEV)          # row 0 is always marked
+        oldest = torch.from_numpy(buf[start].copy()).to(DEV)
+        ring.start, ring.len = (start + 1) % ring.S, length - 1
+        coef.grad = None
+        out = _HistoryFilter.apply(coef, sparse_buf, ring.geom(), ids, ring.mask, oldest)
+        out.backward(gout)
+        h1 = torch.from_numpy(buf[window[1:]]).double()[:, ids.cpu()]
+        r_out = torch.einsum("sp,sup->up", coef.detach().cpu().double()[:length - 1], h1).numpy()
+        r_g = torch.einsum("up,sup->sp", gout.cpu().double(), h1).numpy()
+        assert np.abs(out.detach().cpu().numpy() - r_out).max() <= 2e-6 * (np.abs(r_out).max() + 1e-9) + 1e-6
+        assert np.abs(coef.grad.cpu().numpy()[:length - 1] - r_g).max() <= 2e-6 * (np.abs(r_g).max() + 1e-9) + 1e-6
+        ring.start, ring.len = start, length
     hist = torch.from_numpy(buf[window]).double()[:, ids.cpu()]              # [t, U, P]
     ref_out = torch.einsum("sp,sup->up", coef.detach().cpu().double()[:length], hist).numpy()
     ref_g = torch.einsum("up,sup->sp", gout.cpu().double(), hist).numpy()
