@@ -178,7 +178,8 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fwd_kernel(HistView h, int t_len, int P, const uint32_t* __restrict__ mask,
                                                                                          int words, const int64_t* __restrict__ ids, int64_t num_ids,
                                                                                          const float* __restrict__ coef, const double* __restrict__ cpre,
-                                                                                         float* __restrict__ out) {
+                                                                                         float* __restrict__ out, float* __restrict__ table_out,
+                                                                                         int32_t* __restrict__ slot_of) {
     extern __shared__ double cpre_lds[];
     const int lane = lane_id();
     const int waves_per_block = (int)(blockDim.x >> 6);
@@ -237,7 +238,11 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fw
             }
             cur = st[kRunsInFlight];
         }
-        if (active) st4(out + u * (int64_t)P + col, acc);
+        if (active) {
+            st4(out + u * (int64_t)P + col, acc);
+            if (table_out) st4(table_out + node_now * h.node_stride + col, acc);     // the splice of train:230: pe[batch nodes] = filtered rows
+        }
+        if (slot_of && lane == 0) slot_of[node_now] = (int32_t)u;
     }
 }
 
@@ -461,13 +466,14 @@ extern "C" int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe
 extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                              int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                              const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out,
-                                             void* stream) {
+                                             float* table_out, int32_t* slot_of, void* stream) {
     if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: negative count");
     if (num_ids == 0) return LSTEP_OK;
     if (int rc = check_hist("lstep_history_filter_runs_fwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
     if (int rc = check_mask("lstep_history_filter_runs_fwd", mask, mask_words, time_slots)) return rc;
     if (!node_ids || !coef || !out || !workspace || (((uintptr_t)workspace) & 15) || (((uintptr_t)oldest) & 15))
         return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: NULL or misaligned pointer");
+    if (((uintptr_t)table_out) & 15) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: misaligned table_out");
     HistView h{hist, node_stride, time_stride, time_slots, time_rot, oldest};
     double* cpre = (double*)workspace;
     const size_t lds_bytes = (size_t)(t_len + 1) * pe_dim * sizeof(double);
@@ -478,7 +484,7 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
         int64_t blocks = (num_ids + 15) / 16;
         if (blocks > 256) blocks = 256;
         hipLaunchKernelGGL(history_filter_runs_fwd_kernel<true>, dim3((unsigned)blocks), dim3(1024), lds_bytes, (hipStream_t)stream, h, (int)t_len,
-                           (int)pe_dim, mask, (int)mask_words, node_ids, num_ids, coef, (const double*)nullptr, out);
+                           (int)pe_dim, mask, (int)mask_words, node_ids, num_ids, coef, (const double*)nullptr, out, table_out, slot_of);
         return check_launch("history_filter_runs_fwd_kernel<lds>");
     }
     hipLaunchKernelGGL(coef_prefix_kernel, dim3((unsigned)((pe_dim + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream,
@@ -486,7 +492,7 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
     int64_t blocks = (num_ids + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > kRunsFwdBlocks) blocks = kRunsFwdBlocks;
     hipLaunchKernelGGL(history_filter_runs_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim,
-                       mask, (int)mask_words, node_ids, num_ids, coef, (const double*)cpre, out);
+                       mask, (int)mask_words, node_ids, num_ids, coef, (const double*)cpre, out, table_out, slot_of);
     return check_launch("history_filter_runs_fwd_kernel");
 }
 

@@ -361,10 +361,17 @@ class LstepEngine:
         """FFT-filter the batch rows over the ring window and build the current PE in the spare slot (train:224-230)."""
         ring = self.ring
         ring.wait_window()
-        rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest)
-        cur = ring.base_for_next()
-        cur.index_copy_(0, batch_nodes, rows.detach())   # (these rows are marked as changed by update_pe's phase 1: same node set)
-        self.slot_of[batch_nodes] = torch.arange(batch_nodes.numel(), dtype=torch.int32, device=self.device)
+        if ring.mask is not None and ring.len > 0:
+            # the run kernel writes the filtered rows into the current table and numbers them in slot_of on its way out
+            cur = ring.base_for_next()
+            rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest,
+                                                splice=(cur, self.slot_of))
+        else:
+            rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest)
+            cur = ring.base_for_next()
+            cur.index_copy_(0, batch_nodes, rows.detach())
+            self.slot_of[batch_nodes] = torch.arange(batch_nodes.numel(), dtype=torch.int32, device=self.device)
+        # (the spliced rows are marked as changed by update_pe's phase 1: same node set)
         # the engine's gather rows are cat[src, dst, neg]: their first 2B rows are the entries batch_nodes_and_segments grouped
         return cur, SplicedRows(rows, self.slot_of, getattr(self, "_batch_groups", None))
 

@@ -734,10 +734,24 @@ class _GatherAggregate(torch.autograd.Function):
                                                          nat.ptr(g_self), mod.ld_edge, mod.ld_pe, ctx.ld_self,
                                                          nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
                                                          nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
+        g_w = None
+        if slot_dot is not None and mod.__dict__.get("aux_wgrad_stream", False) and mod.edge_agg.weight.grad is None:
+            # d(edge_agg.weight) = column sums of the slot dots: a parameter gradient, nothing in the backward chain waits for it, so the
+            # reduction (a slow shape for the library: 49 152 x 20 -> 20) goes to the auxiliary stream; join_aux_stream() orders its reader
+            # (.grad is still None, so autograd will adopt the tensor as it is, without touching it on this stream)
+            aux = _aux_stream(dev)
+            done = torch.cuda.Event()
+            done.record()
+            with torch.cuda.stream(aux):
+                aux.wait_event(done)
+                g_w = slot_dot.sum(dim=0)
+            slot_dot.record_stream(aux)
+            g_w.record_stream(torch.cuda.current_stream(dev))
         _flush_deferred(dev)     # the critical kernel is out: now launch the postponed auxiliary-stream work
         if use_slot:
             grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self, ctx.self_groups)
-        g_w = slot_dot.sum(dim=0) if slot_dot is not None else None
+        if g_w is None and slot_dot is not None:
+            g_w = slot_dot.sum(dim=0)
         g_table = None
         if grad_rows is not None and not use_slot:
             if g_pe is not None:  # padding slots all read row 0: one weighted column sum instead of a hot atomic row
@@ -814,7 +828,7 @@ class _HistoryFilter(torch.autograd.Function):
     the ``*_runs_*`` kernels read one row per run of equal snapshots instead of one per snapshot."""
 
     @staticmethod
-    def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None):
+    def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None, splice=None):
         lib = nat.load_library()
         node_stride, time_stride, slots, rot, t_len, P = geom
         U = ids.numel()
@@ -828,7 +842,8 @@ class _HistoryFilter(torch.autograd.Function):
                 ws = nat._workspace(ids.device, int(lib.lstep_history_filter_runs_workspace(t_len, P)))
                 nat.check(lib.lstep_history_filter_runs_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(mask),
                                                             int(mask.shape[1]), nat.ptr(oldest), nat.ptr(ids), U, nat.ptr(cc), nat.ptr(ws),
-                                                            nat.ptr(out), nat.current_stream()))
+                                                            nat.ptr(out), nat.ptr(splice[0]) if splice else None,
+                                                            nat.ptr(splice[1]) if splice else None, nat.current_stream()))
         ctx.geom, ctx.coef_shape = geom, tuple(coef.shape)
         # NOT save_for_backward: the device ring appends its next snapshot (a slot outside this window) in place
         # before backward runs; the window itself (rows and mask bits) is guaranteed untouched by HistoryRing (engine.py).
@@ -859,7 +874,7 @@ class _HistoryFilter(torch.autograd.Function):
                                                                 nat.ptr(g), nat.ptr(partial), nat.current_stream()))
                     diff = partial.sum(dim=0)
                     nat.check(lib.lstep_history_filter_runs_finish(nat.ptr(diff), t_len, P, nat.ptr(g_coef), nat.current_stream()))
-        return g_coef, None, None, None, None, None
+        return g_coef, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ backbone
@@ -1120,12 +1135,17 @@ class LSTEP(nn.Module):
         return self.filter_history(hist, geom, self._ids(node_ids), batch_idx)
 
     def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int, mask: torch.Tensor = None,
-                       oldest: torch.Tensor = None):
+                       oldest: torch.Tensor = None, splice=None):
         """Shared by the drop-in method above and the device ring of ``lstep_amd.engine`` (geom = strides/rotation; ``mask`` = the
         ring's change bits, ``oldest`` = its table of the window's oldest snapshot when the slots only hold changed rows, see
         ``HistoryRing``)."""
+        if splice is not None:     # (table, slot_of): the run kernel also writes table[ids[u]] = out[u] and slot_of[ids[u]] = u
+            table, slot_of = splice
+            if (mask is None or table.dtype != torch.float32 or not table.is_contiguous() or table.shape[1] != geom[0]
+                    or slot_of.dtype != torch.int32):
+                raise ValueError("filter_history: the fused splice needs the change-mask path, a contiguous fp32 table and an int32 slot map")
         coef = self.fft_coefficients(geom[4], batch_idx)
-        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask, oldest)
+        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask, oldest, splice)
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
