@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 20
+#define LSTEP_ABI_VERSION 21
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -243,6 +243,20 @@ int lstep_tail_bwd(const float* grad_out, const float* cat1, const float* cat2, 
  * gradient hits of lstep_gather_aggregate_bwd (out_hits), where ~95 % of the entries are -1.
  * workspace: lstep_sort_live_workspace(n, key_bits) bytes of device scratch. */
 int64_t lstep_sort_live_workspace(int64_t n, int32_t key_bits);
+/* The same without the host round trip.  The sort runs on a FIXED number of items, `capacity` (the caller's estimate from earlier batches):
+ * the live keys padded with `sentinel`, a value above every live key that still fits key_bits (it sorts last).  Outputs: sorted_keys /
+ * order [capacity]; live_index [n]: indices of the live entries, ascending; *count (device int32): their number.  Consumers read *count on
+ * the device (lstep_segment_rows_sum_live).  If *count > capacity, the live entries live_index[capacity .. *count) are NOT in the sorted
+ * output: add them with lstep_scatter_add_overflow (float atomics; exact, only the order of summation differs). */
+int64_t lstep_sort_live_bounded_workspace(int64_t n, int64_t capacity, int32_t key_bits);
+int lstep_sort_live_bounded(const int32_t* keys, int64_t n, int32_t key_bits, int32_t sentinel, int64_t capacity, void* workspace,
+                            int64_t workspace_bytes, int32_t* sorted_keys, int32_t* order, int32_t* live_index, int32_t* count, void* stream);
+/* lstep_segment_rows_sum (no time part, accumulate 0 / 1) over such a padded list: only the first min(*num_live, num_entries) entries count. */
+int lstep_segment_rows_sum_live(const float* table, int32_t width, int32_t ld_table, const int32_t* ent_seg, const int32_t* ent_row,
+                                int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate, void* stream);
+/* out[keys[e], :width] += table[e / div, :width] for e = live_index[i], i in [capacity, *count). */
+int lstep_scatter_add_overflow(float* out, int32_t width, int32_t ld_out, const int32_t* keys, const int32_t* live_index, const int32_t* count,
+                               int64_t capacity, int32_t div, const float* table, int32_t ld_table, void* stream);
 int lstep_sort_live(const int32_t* keys, int64_t n, int32_t key_bits, void* workspace, int64_t workspace_bytes, int32_t* sorted_keys,
                     int32_t* order, int64_t* num_live, void* stream);
 

@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 20
+ABI_VERSION = 21
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -86,6 +86,10 @@ SIGNATURES = {
     "lstep_history_advance_oldest": (C.c_int, [_P, _P, _I32, _I64, _P, _I32, _I32, _I64, _P]),
     "lstep_history_filter_runs_finish": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _I32, _P]),
+    "lstep_sort_live_bounded_workspace": (_I64, [_I64, _I64, _I32]),
+    "lstep_sort_live_bounded": (C.c_int, [_P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P]),
+    "lstep_segment_rows_sum_live": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _P, _I32, _I32, _P]),
+    "lstep_scatter_add_overflow": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
     "lstep_group_by_key_workspace": (_I64, [_I64, _I32]),
@@ -192,6 +196,24 @@ def sort_live(keys, key_bits: int):
             check(lib.lstep_sort_live(ptr(keys), n, int(key_bits), ptr(ws), ws.numel(), ptr(sorted_keys), ptr(order), C.byref(live),
                                       current_stream()))
     return sorted_keys, order, int(live.value)
+
+
+def sort_live_bounded(keys, key_bits: int, sentinel: int, capacity: int):
+    """``lstep_sort_live_bounded``: (sorted_keys [capacity], order [capacity], live_index [n], count (device int32 [1])); no host sync."""
+    import torch
+
+    lib = load_library()
+    n = keys.numel()
+    dev = keys.device
+    sorted_keys = torch.empty(capacity, dtype=torch.int32, device=dev)
+    order = torch.empty(capacity, dtype=torch.int32, device=dev)
+    live_index = torch.empty(n, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _workspace(dev, int(lib.lstep_sort_live_bounded_workspace(n, capacity, key_bits)))
+    with torch.cuda.device(dev):
+        check(lib.lstep_sort_live_bounded(ptr(keys), n, int(key_bits), int(sentinel), int(capacity), ptr(ws), ws.numel(), ptr(sorted_keys),
+                                          ptr(order), ptr(live_index), ptr(count), current_stream()))
+    return sorted_keys, order, live_index, count
 
 
 def small_mm(a, b, out=None, beta: float = 0.0):

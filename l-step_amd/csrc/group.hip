@@ -58,6 +58,18 @@ __global__ void take_kernel(const int32_t* __restrict__ src, const int32_t* __re
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = src[idx[i]];
 }
 
+// live prefix + sentinel padding up to `capacity`: keys_out / idx_out are the (fixed-size) input of the sort
+__global__ void take_pad_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int64_t capacity,
+                                int32_t sentinel, int32_t* __restrict__ keys_out, int32_t* __restrict__ idx_out) {
+    const int64_t n = *count;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = i < n;
+        const int32_t e = live ? idx[i] : 0;
+        keys_out[i] = live ? src[e] : sentinel;
+        idx_out[i] = e;
+    }
+}
+
 static size_t select_temp_bytes(int64_t n) {
     size_t a = 0;
     NonNegative pred{nullptr};
@@ -148,4 +160,40 @@ extern "C" int lstep_sort_live(const int32_t* keys, int64_t n, int32_t key_bits,
     if (sort_pairs(temp, temp_bytes, live_keys, sorted_keys, idx, order, host_count, key_bits, s) != hipSuccess)
         return set_error(LSTEP_EHIP, "lstep_sort_live: radix sort failed");
     return check_launch("lstep_sort_live");
+}
+
+// lstep_sort_live without the host round trip: the sort runs on a FIXED number of items (`capacity`, chosen by the caller from earlier
+// batches): the live keys, padded with `sentinel` (a value above every live key that still fits key_bits).  *count (device) = number of
+// live entries, live_index[0 .. *count) = their indices in ascending order.  If *count > capacity only the first `capacity` live entries are
+// in the sorted output: the caller handles live_index[capacity .. *count) separately (lstep_scatter_add_overflow).
+extern "C" int64_t lstep_sort_live_bounded_workspace(int64_t n, int64_t capacity, int32_t key_bits) {
+    if (n <= 0 || capacity <= 0) return 0;
+    const size_t a = select_temp_bytes(n), b = cub_temp_bytes(capacity, key_bits);
+    return (int64_t)(2 * align256((size_t)capacity * 4) + 256 + align256(a > b ? a : b));
+}
+
+extern "C" int lstep_sort_live_bounded(const int32_t* keys, int64_t n, int32_t key_bits, int32_t sentinel, int64_t capacity, void* workspace,
+                                       int64_t workspace_bytes, int32_t* sorted_keys, int32_t* order, int32_t* live_index, int32_t* count,
+                                       void* stream) {
+    if (n <= 0 || capacity <= 0 || key_bits <= 0 || key_bits > 31 || sentinel < 0 || (key_bits < 31 && sentinel >= (1 << key_bits)))
+        return set_error(LSTEP_EINVAL, "lstep_sort_live_bounded: bad arguments");
+    if (n >= ((int64_t)1 << 31) || capacity >= ((int64_t)1 << 31)) return set_error(LSTEP_EINVAL, "lstep_sort_live_bounded: more than 2^31 - 1 entries");
+    if (!keys || !workspace || !sorted_keys || !order || !live_index || !count) return set_error(LSTEP_EINVAL, "lstep_sort_live_bounded: NULL pointer");
+    if (workspace_bytes < lstep_sort_live_bounded_workspace(n, capacity, key_bits))
+        return set_error(LSTEP_EINVAL, "lstep_sort_live_bounded: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    int32_t* live_keys = (int32_t*)ws;
+    int32_t* live_idx = (int32_t*)(ws + align256((size_t)capacity * 4));
+    void* temp = ws + 2 * align256((size_t)capacity * 4) + 256;
+    size_t temp_bytes = select_temp_bytes(n);
+    NonNegative pred{keys};
+    if (hipcub::DeviceSelect::If(temp, temp_bytes, hipcub::CountingInputIterator<int32_t>(0), live_index, count, (int)n, pred, s) != hipSuccess)
+        return set_error(LSTEP_EHIP, "lstep_sort_live_bounded: select failed");
+    const unsigned grid = (unsigned)((capacity + 255) / 256 < 2048 ? (capacity + 255) / 256 : 2048);
+    hipLaunchKernelGGL(take_pad_kernel, dim3(grid), dim3(256), 0, s, keys, live_index, count, capacity, sentinel, live_keys, live_idx);
+    temp_bytes = cub_temp_bytes(capacity, key_bits);
+    if (sort_pairs(temp, temp_bytes, live_keys, sorted_keys, live_idx, order, capacity, key_bits, s) != hipSuccess)
+        return set_error(LSTEP_EHIP, "lstep_sort_live_bounded: radix sort failed");
+    return check_launch("lstep_sort_live_bounded");
 }

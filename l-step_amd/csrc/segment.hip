@@ -45,10 +45,15 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                                                                    const float* __restrict__ tw, const float* __restrict__ tb, int D,
                                                                    const int32_t* __restrict__ ent_seg, const int32_t* __restrict__ ent_row,
                                                                    const float* __restrict__ ent_dt, int64_t num_entries,
-                                                                   float* __restrict__ out, int ld_out, bool accumulate) {
+                                                                   float* __restrict__ out, int ld_out, bool accumulate,
+                                                                   const int32_t* __restrict__ num_live) {
     const int lane = lane_id();
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t e0 = chunk * kChunk;
+    if (num_live) {      // the entry list is padded: only its first min(*num_live, num_entries) entries count (lstep_sort_live_bounded)
+        const int64_t live = *num_live;
+        if (live < num_entries) num_entries = live;
+    }
     if (e0 >= num_entries) return;
     const int64_t e1 = (e0 + kChunk < num_entries) ? e0 + kChunk : num_entries;
     const int seg_prev = e0 > 0 ? ent_seg[e0 - 1] : -1;            // segment that may spill in from the previous chunk
@@ -206,8 +211,52 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
         hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3((unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
                            (hipStream_t)stream, ent_seg, num_entries, out, (int)ld_out, (int)(width + time_dim));
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, (const int32_t*)nullptr);
     return check_launch("segment_rows_sum_kernel");
+}
+
+// lstep_segment_rows_sum (no time part, accumulate 0 / 1) over a PADDED entry list: only the first min(*num_live, num_entries) entries count
+extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, int32_t ld_table, const int32_t* ent_seg, const int32_t* ent_row,
+                                           int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate,
+                                           void* stream) {
+    if (num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: negative count");
+    if (num_entries == 0) return LSTEP_OK;
+    if (ld_table == 0) ld_table = width;
+    if (ld_out == 0) ld_out = width;
+    if (width <= 0 || (width & 3) || width > 4 * kMaxRowVec || ld_table < width || (ld_table & 3) || ld_out < width || (ld_out & 3) ||
+        (accumulate != 0 && accumulate != 1))
+        return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: unsupported arguments");
+    if (!table || !ent_seg || !ent_row || !out || !num_live) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: NULL pointer");
+    const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
+    const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table,
+                       (const float*)nullptr, (const float*)nullptr, 0, ent_seg, ent_row, (const float*)nullptr, num_entries, out, (int)ld_out,
+                       accumulate == 1, num_live);
+    return check_launch("segment_rows_sum_kernel<live>");
+}
+
+// out[keys[e], :W] += table[e / div, :W] for the live entries e = live_index[i], i in [capacity, *count): the ones a bounded sort left out
+__global__ __launch_bounds__(kBlock) void scatter_add_overflow_kernel(float* __restrict__ out, int W, int ld_out, const int32_t* __restrict__ keys,
+                                                                       const int32_t* __restrict__ live_index, const int32_t* __restrict__ count,
+                                                                       int64_t capacity, int div, const float* __restrict__ table, int ld_table) {
+    const int lane = lane_id();
+    const int64_t n = *count;
+    const int64_t waves = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t i = capacity + (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block(); i < n; i += waves) {
+        const int e = live_index[i];
+        const float* src = table + (int64_t)(e / div) * ld_table;
+        float* dst = out + (int64_t)keys[e] * ld_out;
+        for (int c = lane; c < W; c += kWave) atomicAdd(dst + c, src[c]);
+    }
+}
+
+extern "C" int lstep_scatter_add_overflow(float* out, int32_t width, int32_t ld_out, const int32_t* keys, const int32_t* live_index,
+                                          const int32_t* count, int64_t capacity, int32_t div, const float* table, int32_t ld_table, void* stream) {
+    if (width <= 0 || ld_out < width || ld_table < width || capacity < 0 || div <= 0) return set_error(LSTEP_EINVAL, "lstep_scatter_add_overflow: bad sizes");
+    if (!out || !keys || !live_index || !count || !table) return set_error(LSTEP_EINVAL, "lstep_scatter_add_overflow: NULL pointer");
+    hipLaunchKernelGGL(scatter_add_overflow_kernel, dim3(256), dim3(kBlock), 0, (hipStream_t)stream, out, (int)width, (int)ld_out, keys, live_index,
+                       count, capacity, (int)div, table, (int)ld_table);
+    return check_launch("scatter_add_overflow_kernel");
 }
 
 extern "C" int64_t lstep_padding_rows_sum_blocks(int64_t n) {

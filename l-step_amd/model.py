@@ -600,15 +600,59 @@ class SplicedRows:
         self.self_groups = self_groups
 
 
-def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src_row_of, table: torch.Tensor, accumulate: bool):
+class _LiveCount:
+    """Number of live entries seen by the last few ``_segment_reduce_rows`` calls of one call site, read back asynchronously."""
+
+    def __init__(self):
+        self.last, self.pending = None, None      # last known count; (pinned tensor, event, device tensor) on its way
+
+    def poll(self):
+        if self.pending is not None and self.pending[1].query():
+            self.last = int(self.pending[0][0])
+            self.pending = None
+        return self.last
+
+    def send(self, count_dev):
+        if self.pending is None:
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(count_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending = (host, ev, count_dev)
+
+
+def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src_row_of, table: torch.Tensor, accumulate: bool, div: int = 0):
     """out[u] (+)= sum of table[src_row, :P] over the entries with seg_of_entry == u; entries with a negative segment are
-    dropped.  ``seg_of_entry`` int32 [n]; ``src_row_of(order)`` maps original entry indices to table rows.  ``out`` [U, P] must be
-    zero where nothing has been accumulated yet."""
+    dropped.  ``seg_of_entry`` int32 [n]; ``src_row_of(order)`` maps original entry indices to table rows (``div`` > 0: it is
+    ``order // div``).  ``out`` [U, P] must be zero where nothing has been accumulated yet.
+
+    The live entries (typically ~5 %) are compacted and sorted by segment.  Their number is only known on the device; with ``div`` given
+    the sort runs on a fixed capacity taken from earlier batches (twice the last count seen) and every consumer reads the count on the
+    device, so the backward pass has no host round trip here; live entries beyond the capacity (a sudden jump) are added with atomics."""
     lib = nat.load_library()
     dev, P = table.device, mod.pe_dim
-    if seg_of_entry.numel() == 0:
+    n = seg_of_entry.numel()
+    if n == 0:
         return
-    sorted_keys, order, n_hit = nat.sort_live(seg_of_entry.contiguous(), max(1, int(out.shape[0]).bit_length()))
+    keys = seg_of_entry.contiguous()
+    key_bits = max(1, int(out.shape[0]).bit_length())
+    track = mod.__dict__.setdefault("_live_counts", {}).setdefault((n, div), _LiveCount()) if div > 0 else None
+    last = track.poll() if track is not None else None
+    if last is not None and os.environ.get("LSTEP_SYNC_LIVE_SORT") != "1":
+        capacity = min(n, max(8192, (2 * last + 4095) // 4096 * 4096))
+        sorted_keys, order, live_index, count = nat.sort_live_bounded(keys, key_bits, int(out.shape[0]), capacity)
+        ent_row = torch.div(order, div, rounding_mode="floor") if div > 1 else order
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_segment_rows_sum_live(nat.ptr(table), P, int(table.stride(0)), nat.ptr(sorted_keys), nat.ptr(ent_row), capacity,
+                                                      nat.ptr(count), nat.ptr(out), P, 1 if accumulate else 0, nat.current_stream()))
+            if capacity < n:
+                nat.check(lib.lstep_scatter_add_overflow(nat.ptr(out), P, P, nat.ptr(keys), nat.ptr(live_index), nat.ptr(count), capacity,
+                                                         max(div, 1), nat.ptr(table), int(table.stride(0)), nat.current_stream()))
+        track.send(count)
+        return
+    sorted_keys, order, n_hit = nat.sort_live(keys, key_bits)
+    if track is not None:
+        track.last = n_hit
     if n_hit == 0:
         return
     # NOTE: every tensor whose address goes to the C ABI must stay referenced until the launch has been issued: a
@@ -632,7 +676,7 @@ def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, 
     P = mod.pe_dim
     total = torch.zeros((num_rows, P), dtype=torch.float32, device=hits.device)
     if g_pe is not None:
-        _segment_reduce_rows(mod, total, hits.reshape(-1), lambda o: (o // K).contiguous(), g_pe, accumulate=False)
+        _segment_reduce_rows(mod, total, hits.reshape(-1), lambda o: (o // K).contiguous(), g_pe, accumulate=False, div=K)
     if g_self is None:
         return total
     if self_groups is None:

@@ -1023,3 +1023,36 @@ def test_engine_gradients_do_not_depend_on_stream_overlap(hip, monkeypatch):
         for name in a:
             scale = float(a[name].abs().max())
             assert float((a[name] - b[name]).abs().max()) <= 1e-4 * scale + 1e-9, f"iteration {it}: gradient of {name} depends on the schedule"
+
+
+def test_live_entry_reduction_without_host_sync_incl_overflow(hip):
+    """``_segment_reduce_rows`` with a capacity taken from earlier calls (lstep_sort_live_bounded + lstep_segment_rows_sum_live +
+    lstep_scatter_add_overflow): the first call learns the live count with one host read, later calls sort a fixed number of items and
+    read the count on the device; a call whose live count exceeds the capacity adds the excess with atomics.  All against index_add."""
+    from lstep_amd.model import _segment_reduce_rows
+
+    class Mod:
+        pe_dim = 172
+
+    mod = Mod()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, K, U, P = 3000, 20, 700, 172
+    table = torch.randn(B, 176, generator=g).to(DEV)
+    for live_frac in (0.02, 0.03, 0.5, 0.01, 0.0):       # third call: 15x more live entries than the capacity expects -> overflow path
+        seg = torch.randint(0, U, (B * K,), generator=g, dtype=torch.int32)
+        dead = torch.rand(B * K, generator=g) >= live_frac
+        seg[dead] = -1
+        seg = seg.to(DEV)
+        out = torch.zeros(U, P, device=DEV)
+        _segment_reduce_rows(mod, out, seg, lambda o: (o // K).contiguous(), table, accumulate=False, div=K)
+        torch.cuda.synchronize()
+        ref = torch.zeros(U, P, dtype=torch.float64, device=DEV)
+        live = (seg >= 0).nonzero().reshape(-1)
+        ref.index_add_(0, seg[live].long(), table[live // K, :P].double())
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
+        # accumulate mode on top of existing content
+        _segment_reduce_rows(mod, out, seg, lambda o: (o // K).contiguous(), table, accumulate=True, div=K)
+        torch.cuda.synchronize()
+        assert float((out.double() - 2 * ref).abs().max()) <= 2e-5 * (float(ref.abs().max()) + 1.0)
+    tracker = mod.__dict__["_live_counts"][(B * K, K)]
+    assert tracker.last is not None
