@@ -55,11 +55,12 @@ class HistoryRing:
     snapshots (``lstep_history_filter_runs_*``).  Whoever writes rows of the snapshot being built must call ``mark``.
 
     Two ways of keeping the slots:
-    * **sparse** (the single-GPU engine's default): the current PE lives in ``table`` and is updated in place; ``commit`` copies only the
-      rows the batch wrote into the batch's slot (``lstep_copy_rows``, ~21 % of the table on the c4 workload) -- the run kernels never
-      read any other row of a slot -- and ``oldest`` holds the window's oldest snapshot, moved on by ``lstep_history_advance_oldest`` when
-      the window slides (``apply_advance``: after the pending backward pass, which still reads the old window).  ~0.6 GB of row traffic
-      per batch instead of the 2.8 GB of a whole-table clone.
+    * **sparse** (the single-GPU engine's default): the current PE lives in ``table`` and is updated in place; only the rows the batch
+      wrote (~21 % of the table on the c4 workload) reach the batch's slot -- ``update_pe``'s kernels write them there themselves
+      (``building()``, the ``mirror`` of ``lstep_update_rows``), ``commit`` copies what is left (``lstep_copy_rows``) -- because the run
+      kernels never read any other row of a slot; ``oldest`` holds the window's oldest snapshot, moved on by
+      ``lstep_history_advance_oldest`` when the window slides (``apply_advance``: behind the pending backward pass, which still reads the
+      old window).  ~0.5 GB of row traffic per batch instead of the 2.8 GB of a whole-table clone.
     * **clones** (``sparse=False``: the owner-sharded rings of ``lstep_amd.parallel``, ``LSTEP_CLONE_HISTORY=1``, and whenever there is
       no mask -- ``LSTEP_DENSE_HISTORY=1`` or more than 128 slots): every slot is a full snapshot; the snapshot being built lives in a
       spare slot, and a second spare slot lets the next clone be prefetched on a copy stream under the backward pass without touching
