@@ -180,12 +180,26 @@ def main():
     gc.freeze()
     sink = []
     model[0].gather_event_sink = sink
+    trace = os.environ.get("LSTEP_BENCH_TRACE") == "1"      # per-step host / GPU times on stderr (does not drain the GPU between steps)
+    marks = []
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+        if trace:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((time.perf_counter() - t0, ev))
     barrier()
     elapsed = time.perf_counter() - t0
+    if trace and rank == 0:
+        prev_h, prev_g = 0.0, None
+        rows = []
+        for h, ev in marks:
+            g = marks[0][1].elapsed_time(ev)
+            rows.append(f"{(h - prev_h) * 1e3:.2f}/{(g - prev_g) if prev_g is not None else float('nan'):.2f}")
+            prev_h, prev_g = h, g
+        print("[trace] per step host-enqueue ms / GPU ms since previous step end: " + " ".join(rows), file=sys.stderr)
     model[0].gather_event_sink = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

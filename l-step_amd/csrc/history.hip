@@ -382,7 +382,10 @@ __global__ __launch_bounds__(kBlock) void history_slot_bits_kernel(uint32_t* __r
     if (i >= num_rows) return;
     uint32_t* w = mask + i * words + (slot >> 5);
     const uint32_t bit = 1u << (slot & 31);
-    *w = (value || i == 0) ? (*w | bit) : (*w & ~bit);   // row 0 = the padding row: every update_pe rewrites it (LSTEP.py:317)
+    // atomics: a word holds the bits of 32 slots, and history_mark_kernel may be setting another slot's bit of the same word from
+    // another stream (a clone prefetched on the copy stream while the batch's writers mark theirs); row 0 = the padding row, which
+    // every update_pe rewrites (LSTEP.py:317)
+    if (value || i == 0) atomicOr(w, bit); else atomicAnd(w, ~bit);
 }
 
 static int check_hist(const char* who, const float* hist, int64_t node_stride, int64_t time_stride, int slots, int rot, int t_len, int P) {

@@ -18,6 +18,7 @@ Edge streams live on the device (``EdgeStream``); a batch is a slice, no host ro
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import threading
 from dataclasses import dataclass
@@ -258,19 +259,48 @@ class HistoryRing:
 
     def as_reference_tensor(self) -> torch.Tensor:
         """``[N+1, t, P]`` copy of the window, oldest first (tests / checkpoint parity with ``EarlyStopping.save_pe``)."""
+        if not self.sparse:
+            idx = [(self.start + i) % self.S for i in range(self.len)]
+            return self.buf[idx].permute(1, 0, 2).contiguous()
+        out = torch.empty((self.rows, self.len, self.P), dtype=torch.float32, device=self.buf.device)
+        for i, snap in enumerate(self.snapshots()):
+            out[:, i] = snap
+        return out
+
+    def snapshots(self):
+        """Yield the window's snapshots ``[rows, P]`` one at a time, oldest first (a 1 M-node window is 69 GB as one tensor).  Clone
+        rings yield views of their slots; a sparse ring rebuilds each snapshot from the one before it and the rows whose change bit
+        of that slot is set (the yielded tensor is reused for the next one: copy what must be kept)."""
         idx = [(self.start + i) % self.S for i in range(self.len)]
         if not self.sparse:
-            return self.buf[idx].permute(1, 0, 2).contiguous()
+            for ph in idx:
+                yield self.buf[ph]
+            return
         torch.cuda.synchronize(self.buf.device)
-        out = torch.empty((self.rows, self.len, self.P), dtype=torch.float32, device=self.buf.device)
+        cur = None
         for i, ph in enumerate(idx):
-            if i == 0:      # rows the first slot's batch wrote are in the slot (``oldest`` may not have taken them over yet)
-                hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool()
-                out[:, 0] = torch.where(hit.unsqueeze(1), self.buf[ph], self.oldest)
-            else:
-                hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool()
-                out[:, i] = torch.where(hit.unsqueeze(1), self.buf[ph], out[:, i - 1])
-        return out
+            hit = ((self.mask[:, ph // 32] >> (ph % 32)) & 1).bool().unsqueeze(1)
+            # (i == 0: rows the first slot's batch wrote are in the slot; ``oldest`` may not have taken them over yet)
+            cur = torch.where(hit, self.buf[ph], self.oldest if i == 0 else cur)
+            yield cur
+
+
+class BatchKey:
+    """Identity of a batch's endpoint tensors for the look-ahead grouping: the same memory (address, length, layout), not written
+    since (version counters are shared by all views of a buffer).  The key HOLDS the tensors it was made from: as long as it lives
+    the caching allocator cannot hand their block to another batch's tensors, so an equal address means the same buffer -- without the
+    references a freed look-ahead batch and a later batch of the same size (epoch boundary, train -> eval switch) could collide."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor):
+        self.src, self.dst = src, dst
+        self.sig = self._sig(src, dst)
+
+    @staticmethod
+    def _sig(src, dst):
+        return tuple((t.data_ptr(), t.numel(), t.stride(), t.dtype, t._version) for t in (src, dst))
+
+    def matches(self, src: torch.Tensor, dst: torch.Tensor) -> bool:
+        return self.sig == self._sig(src, dst) and self.sig == self._sig(self.src, self.dst)
 
 
 class _LookupRows(torch.autograd.Function):
@@ -350,12 +380,25 @@ class LstepEngine:
         self._update_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
         self.slot_of = torch.full((rows,), -1, dtype=torch.int32, device=dev)
         self.fused_loss = torch.device(dev).type == "cuda" and backbone.pe_dim % 4 == 0 and os.environ.get("LSTEP_TORCH_LOSS") != "1"
-        # the engine joins the auxiliary stream before every optimiser step, so the model may put its weight-gradient products there
-        backbone.aux_wgrad_stream = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
-        predictor.aux_wgrad_stream = backbone.aux_wgrad_stream
-        if self.ring is not None and self.ring.sparse and backbone.aux_wgrad_stream:
+        # the engine joins the auxiliary stream before every optimiser step, so INSIDE its training iteration (``aux_streams``) the model
+        # may put its weight-gradient products there; outside of it every backward() is self-contained on the caller's stream
+        self.use_aux = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
+        backbone.aux_wgrad_stream = predictor.aux_wgrad_stream = False
+        if self.ring is not None and self.ring.sparse and self.use_aux:
             from .model import _aux_stream
             self.ring.advance_stream = _aux_stream(dev)    # idle between the weight gradients and the next weight composition
+
+    @contextlib.contextmanager
+    def aux_streams(self):
+        """Scope in which the model may defer parameter-gradient work to the auxiliary stream (``LSTEP.join_aux_stream`` is called before
+        the optimiser step inside it).  The flag is off everywhere else: a ``backward()`` of the drop-in methods, of
+        ``compute_src_dst_node_temporal_embeddings`` or of user code leaves complete gradients on the caller's stream."""
+        bb, pr = self.backbone, self.predictor
+        bb.aux_wgrad_stream = pr.aux_wgrad_stream = self.use_aux
+        try:
+            yield
+        finally:
+            bb.aux_wgrad_stream = pr.aux_wgrad_stream = False
 
     # ---- shared pieces
     def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):
@@ -398,7 +441,7 @@ class LstepEngine:
         If ``prefetch_batch_nodes`` was called for exactly these tensors, its result is picked up: the only host wait is for the
         prefetched counts, which were copied out long ago."""
         pre = self.__dict__.pop("_prefetched_group", None)
-        if pre is not None and pre[0] == self._batch_key(src, dst):
+        if pre is not None and pre[0].matches(src, dst):
             order, seg, uniq, counts = pre[1]
             n_unique = counts.get()[0]
         else:
@@ -410,18 +453,16 @@ class LstepEngine:
         """Group the NEXT batch's endpoints now (the edge stream is known ahead).  Its kernels queue up behind the current forward pass
         and its counts travel to the host asynchronously, so the next ``train_iteration`` starts without draining the GPU: the host
         can enqueue the next forward while the current backward is still running."""
-        self._prefetched_group = (self._batch_key(src, dst), self._group_batch(src, dst, wait=False))
-
-    @staticmethod
-    def _batch_key(src, dst):
-        """Identity of a batch's endpoint tensors: same memory, same length, and not written since (version counters are shared by
-        all views of a buffer).  The prefetched grouping is only picked up for exactly these tensors."""
-        return (src.data_ptr(), dst.data_ptr(), src.numel(), dst.numel(), src._version, dst._version)
+        self._prefetched_group = (BatchKey(src, dst), self._group_batch(src, dst, wait=False))
 
     # ---- train:204-311
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
         """``lookahead = (src, dst)`` of the next batch (optional): see ``prefetch_batch_nodes``.  The grouping made from them is used by
         the next call only if it receives the same (unmodified) tensors; otherwise it is recomputed."""
+        with self.aux_streams():
+            return self._train_iteration(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
+
+    def _train_iteration(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
         bb, ring = self.backbone, self.ring
         out, loss = None, None
         bb.prepare_step()
@@ -497,14 +538,18 @@ class LstepEngine:
         # against 5.2 with the second thread -- the backward's launches would start 0.7 ms late)
         th = threading.Thread(target=worker, name="lstep-update-pe")
         th.start()
-        optimizer.zero_grad()
-        loss.backward()
-        bb.join_aux_stream()
-        th.join()
+        try:
+            optimizer.zero_grad()
+            loss.backward()
+            bb.join_aux_stream()
+        finally:
+            # whatever happened above, the worker must not be left mutating the table / mask / commit state behind our back, and the
+            # streams must meet again
+            th.join()
+            ring.apply_advance()  # (no-op unless the worker committed) the backward pass is enqueued: `oldest` may move on behind it
+            main.wait_stream(side)
         if err:
             raise err[0]
-        ring.apply_advance()  # the backward pass is enqueued: the window's oldest snapshot may move on behind it (copy stream)
-        main.wait_stream(side)
         optimizer.step()      # after update_pe has read its weights
         self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
         return out

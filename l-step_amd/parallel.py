@@ -234,7 +234,7 @@ class DistributedLstep:
 
     def _prefetched_owner_counts(self, src, dst):
         pre = self.__dict__.pop("_owner_prefetch", None)
-        if pre is None or pre[0] != self.eng._batch_key(src, dst):
+        if pre is None or not pre[0].matches(src, dst):
             return None
         pre[2].synchronize()
         return [int(c) for c in pre[1].tolist()]
@@ -329,6 +329,10 @@ class DistributedLstep:
 
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
+        with self.eng.aux_streams():
+            return self._train_iteration(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
+
+    def _train_iteration(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
         n_glob = src.numel()
         assert n_glob % self.W == 0, "global batch must divide by the world size"
         b = n_glob // self.W

@@ -1,0 +1,332 @@
+"""GPU parity tests AT THE SHAPES OF BASELINE.json's configurations (c1 Enron B=200 K=20, c2 Wikipedia B=600 K=20,
+c3 Reddit B=4096 K=32, c4 synthetic 1 M nodes / 20 M edges B=16384), each against the CPU oracle, with the reference's default
+history window T = 100 (utils/load_configs.py:32) filled AND slid, plus the reference's best-config window T = 200
+(utils/load_configs.py:89,93,95) that falls off the change-mask path.  c5 (4 M / 100 M, eight GPUs) cannot run on one GPU.
+
+No dataset ships with the reference: the graphs are synthetic with the real datasets' node / edge counts, non-zero
+node features (so the node channel is exercised) and N(0,1) edge features.
+
+What is compared where the oracle cannot afford the full batch (its node channel gathers a dense [rows, time_gap, 172] block):
+  * a random ROW SAMPLE of the batch's embeddings (the HIP side still runs the whole batch in one launch), and
+  * gradients of a loss that weights only those sample rows -- the HIP backward kernels run on the full batch shape (all other rows
+    receive zero gradient), the oracle differentiates the sample rows alone; the two parameter gradients must agree.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from lstep_amd import protocol, synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = dict(rtol=0, atol=5e-5)
+BAR = dict(rtol=0, atol=1e-4)     # north_star's bar; used where thousands of fp32 terms are summed in a different order
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lstep_amd import _native
+    from lstep_amd.engine import EdgeStream, LstepEngine
+    from lstep_amd.sampler import NeighborSampler
+    from lstep_amd.smoke import build_hip_model
+
+    _native.load_library()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.NeighborSampler, ns.build, ns.EdgeStream, ns.LstepEngine = NeighborSampler, build_hip_model, EdgeStream, LstepEngine
+    return ns
+
+
+def _oracle(g, node_raw, edge_raw, K, T, sd):
+    from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model
+    osamp = OracleNeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=g["num_nodes"])
+    return build_oracle_model(node_raw, edge_raw, osamp, K, T, sd), osamp
+
+
+def _oracle_state_step(om, st, batch_idx, src, dst, ts, eid, K, G, T):
+    """The STATE transition of one evaluation batch (evaluate_model_utils.py:57-63,118-135): FFT splice, update_pe, append.  The four
+    combining_pe_raw_feat calls of that loop only feed the metrics, so the pre-roll skips them on the CPU (2 s each at B = 600)."""
+    bn = protocol.unique_batch_nodes(src, dst)
+    st.history, cur = protocol.splice_current_pe(om[0], st.history, bn, batch_idx, T)
+    cur = om[0].update_pe(pe=cur, node_ids=bn, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst, node_interact_times=ts,
+                          current_time=ts.max(), num_neighbors=K, time_gap=G)
+    st.history = torch.cat([st.history, cur.unsqueeze(1)], dim=1)
+
+
+def _parity(got, ref32, ref64, atol, tag, max_excused=1e-5):
+    """|got - ref32| <= atol everywhere, EXCEPT where the fp32 oracle's own summation error explains the difference: an element may
+    exceed the bar only if it is no further from the float64 yardstick (``oracle.float64_yardstick``) than the fp32 oracle is, plus the
+    bar.  (The padding row of update_pe sums tens of thousands of fp32 terms; the reference's result there depends on its summation
+    order -- sequential on the CPU, atomics on a GPU.)  ``ref64`` may be a callable (built only when needed).  At most ``max_excused``
+    of the elements may take that exit."""
+    got, ref32 = np.asarray(got, dtype=np.float64), np.asarray(ref32, dtype=np.float64)
+    d = np.abs(got - ref32)
+    bad = d > atol
+    if not bad.any():
+        return
+    ref64 = np.asarray(ref64() if callable(ref64) else ref64, dtype=np.float64)
+    to64, slack = np.abs(got - ref64)[bad], np.abs(ref32 - ref64)[bad]
+    where = np.argwhere(bad)
+    ok = to64 <= slack + atol
+    msg = (f"{tag}: {int(bad.sum())} of {bad.size} elements differ from the fp32 oracle by more than {atol} (worst {d.max():.3e} at "
+           f"{where[np.argmax(d[bad])].tolist()}); vs float64: hip {to64.max():.3e}, fp32 oracle {slack.max():.3e}; rows {sorted(set(where[:, 0].tolist()))[:8]}")
+    assert ok.all(), "NOT explained by fp32 summation order -- " + msg
+    assert bad.sum() <= max(1, max_excused * bad.size), "too many -- " + msg
+    warnings.warn("explained by the fp32 oracle's own rounding -- " + msg)
+
+
+def _compare_grads(om, hm, atol, tag):
+    for (k, po), (_, ph) in zip(om.named_parameters(), hm.named_parameters()):
+        if po.grad is None:
+            assert ph.grad is None or float(ph.grad.abs().max()) == 0.0, k
+            continue
+        assert ph.grad is not None, k
+        ref = po.grad.numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(ph.grad.cpu().numpy(), ref, rtol=0, atol=atol * scale, err_msg=f"{tag} {k}")
+
+
+# ------------------------------------------------------------------------------------------------ c1, c2 (and T = 200)
+PROTOCOL_CASES = {
+    # name: (nodes, edges, batch, K, T, pre-roll batches, trained batches)
+    "c1-enron-B200-K20-T100": (184, 125_235, 200, 20, 100, 104, 3),
+    "c2-wikipedia-B600-K20-T100": (9_227, 157_474, 600, 20, 100, 103, 3),
+    "T200-clone-fallback": (300, 40_000, 64, 20, 200, 204, 2),
+}
+
+
+@pytest.mark.parametrize("name", list(PROTOCOL_CASES))
+def test_engine_protocol_full_slid_window_vs_oracle(hip, name):
+    """Engine vs oracle protocol at the configuration's own N, E, B, K, time_gap = 2000 and window T: the history is grown from one
+    snapshot by T + 3 evaluation batches (masked FFT while it is short, then full, then the ring rotates and its `oldest` table lags),
+    then consecutive TRAINING iterations are compared: PE snapshots, link probabilities, the three losses and every parameter gradient
+    (train_LSTEP_link_prediction.py:204-311)."""
+    from lstep_amd.optim import FusedAdam
+    N, E, B, K, T, preroll, trained = PROTOCOL_CASES[name]
+    G = 2000
+    seed = 1000 + N
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=seed)
+    node_raw, edge_raw = synth.make_features(N, E, seed=seed + 1)
+    pe0 = synth.make_initial_pe(N, seed=seed + 2)
+    sd = synth.make_state_dict(K, T, seed=seed + 3)
+    from oracle.lstep_oracle import float64_yardstick
+    om, _ = _oracle(g, node_raw, edge_raw, K, T, sd)
+    o64 = float64_yardstick(om)        # runs the same trajectory in float64: the yardstick of ``_parity``
+    hm = hip.build(node_raw, edge_raw, hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N, device=DEV), K, T, sd, DEV)
+    eng = hip.LstepEngine(hm[0], hm[1], K, G)
+    assert (eng.ring.mask is None) == (T > 126), "T = 200 must take the mask-less clone ring, T = 100 the change-mask ring"
+    stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+    first = E // 2
+    assert first + (preroll + trained + 1) * B <= E
+
+    st = protocol.ProtocolState(history=torch.from_numpy(pe0.copy()).unsqueeze(1))
+    st64 = protocol.ProtocolState(history=torch.from_numpy(pe0.copy()).double().unsqueeze(1))
+    eng.ring.load(torch.from_numpy(pe0.copy()).unsqueeze(1).to(DEV))
+    om.eval(), o64.eval(), hm.eval()
+    with torch.no_grad():
+        for j in range(preroll):
+            lo = first + j * B
+            sl = slice(lo, lo + B)
+            for m_, s_ in ((om, st), (o64, st64)):
+                _oracle_state_step(m_, s_, j + 1, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], K, G, T)
+            neg = synth.make_negatives(N, 2 * B, seed=j)
+            eng.eval_iteration(j + 1, *stream.batch(lo, lo + B), torch.from_numpy(neg[:B]).to(DEV), torch.from_numpy(neg[B:]).to(DEV))
+            if j in (2, T // 2, T - 1, preroll - 1):      # short masked window, half, exactly full, slid
+                _parity(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), st64.history[:, -1, :].numpy(), 5e-5, f"pre-roll batch {j}")
+    assert eng.ring.len == T and st.history.shape[1] >= T
+    assert eng.ring.start != 0, "the window must have slid"
+    _parity(eng.ring.as_reference_tensor().cpu().numpy(), st.history[:, -T:, :].numpy(), st64.history[:, -T:, :].numpy(), 5e-5, "window after the pre-roll")
+
+    om.train(), o64.train(), hm.train()
+    oo, oo64, ho = torch.optim.Adam(om.parameters(), lr=1e-4), torch.optim.Adam(o64.parameters(), lr=1e-4), FusedAdam(hm.parameters(), lr=1e-4)
+    for b in range(trained):
+        j = preroll + b
+        lo = first + j * B
+        sl = slice(lo, lo + B)
+        neg = synth.make_negatives(N, B, seed=5000 + b)
+        args = (j + 1, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], neg, K, G, T)
+        ro = protocol.train_iteration(om[0], om[1], oo, st, *args)
+        r64 = protocol.train_iteration(o64[0], o64[1], oo64, st64, *args)
+        nxt = stream.batch(lo + B, lo + 2 * B)[:2] if b % 2 == 0 else None       # with and without the look-ahead grouping
+        rh = eng.train_iteration(ho, j + 1, *stream.batch(lo, lo + B), torch.from_numpy(neg).to(DEV), lookahead=nxt)
+        _parity(rh["predicts"].cpu().numpy(), ro["predicts"], r64["predicts"], 5e-5, f"train batch {b}: link probabilities")
+        np.testing.assert_allclose([float(rh["lp_loss"]), float(rh["pe_loss"]), float(rh["loss"])], [ro["lp_loss"], ro["pe_loss"], ro["loss"]],
+                                   rtol=0, atol=2e-5)
+        _parity(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), st64.history[:, -1, :].numpy(), 5e-5, f"train batch {b}: snapshot")
+        _compare_grads(om, hm, 3e-5, f"train batch {b}")
+    _parity(eng.ring.as_reference_tensor().cpu().numpy(), st.history[:, -T:, :].numpy(), st64.history[:, -T:, :].numpy(), 5e-5, "final window")
+
+
+# ------------------------------------------------------------------------------------------------ c3
+@pytest.mark.parametrize("G", [2000, 1000])
+def test_c3_reddit_shape_rows_update_and_gradients_vs_oracle(hip, G):
+    """Reddit-shaped: N = 10 984, E = 672 447, B = 4096, K = 32, time_gap 2000 (default) and 1000 (best config, load_configs.py:83-95).
+    One launch over the 3 B = 12 288 rows [src | dst | neg]; a 256-row sample, its masked-loss gradients and the FULL update_pe table
+    against the oracle."""
+    from oracle.lstep_oracle import float64_yardstick
+    N, E, B, K, T = 10_984, 672_447, 4096, 32, 100
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=303)
+    node_raw, edge_raw = synth.make_features(N, E, seed=304)
+    pe_np = synth.make_initial_pe(N, seed=305)
+    pe_np[0] = 0.02       # the padding row is live (models/LSTEP.py:317,339)
+    sd = synth.make_state_dict(K, T, seed=306)
+    om, osamp = _oracle(g, node_raw, edge_raw, K, T, sd)
+    hs = hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N, device=DEV)
+    hm = hip.build(node_raw, edge_raw, hs, K, T, sd, DEV)
+    lo = E // 2
+    sl = slice(lo, lo + B)
+    src, dst, t, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+    neg = synth.make_negatives(N, B, seed=307)
+    ids3, t3 = np.concatenate([src, dst, neg]), np.concatenate([t, t, t])
+    pick = np.sort(np.random.RandomState(308).choice(3 * B, size=256, replace=False))
+
+    # S: sampled neighbourhoods of the sample rows, bit-exact, both widths
+    for width in (K, G):
+        a = hs.get_historical_neighbors(ids3[pick], t3[pick], width)
+        b = osamp.get_historical_neighbors(ids3[pick], t3[pick], width)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+
+    # O + its gradients through a dense PE table
+    pe_o = torch.from_numpy(pe_np.copy()).requires_grad_(True)
+    pe_h = torch.from_numpy(pe_np.copy()).to(DEV).requires_grad_(True)
+    wgt = torch.from_numpy(np.random.RandomState(309).standard_normal((256, synth.FEAT_DIM)).astype(np.float32))
+    ref = om[0].combining_pe_raw_feat(pe_o, ids3[pick], t3[pick], K, G)
+    got = hm[0].combining_pe_raw_feat(pe_h, ids3, t3, K, G)
+    assert tuple(got.shape) == (3 * B, synth.FEAT_DIM)
+    np.testing.assert_allclose(got.detach().cpu().numpy()[pick], ref.detach().numpy(), **TOL)
+    (ref * wgt).sum().backward()
+    full_w = torch.zeros(3 * B, synth.FEAT_DIM)
+    full_w[pick] = wgt
+    (got * full_w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(pe_h.grad.cpu().numpy(), pe_o.grad.numpy(), **TOL)
+    _compare_grads(om, hm, 2e-5, f"c3 G={G}")
+
+    # U1 + U2: the whole table
+    with torch.no_grad():
+        bn = protocol.unique_batch_nodes(src, dst)
+        assert len(bn) > B, "U > B: rows past B stay padding in phase 2 (zip quirk, models/LSTEP.py:306-308)"
+        ref_t = om[0].update_pe(torch.from_numpy(pe_np.copy()), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).numpy()
+        got_t = hm[0].update_pe(torch.from_numpy(pe_np.copy()).to(DEV), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).cpu().numpy()
+        f64 = lambda: float64_yardstick(om, tables=False)[0].update_pe(torch.from_numpy(pe_np.copy()).double(), bn, eid, src, dst, t, t.max(),  # noqa: E731
+                                                                        num_neighbors=K, time_gap=G).numpy()
+        _parity(got_t, ref_t, f64, 5e-5, f"c3 update_pe G={G}")
+    assert float(np.abs(got_t - pe_np).max(axis=1).astype(bool).mean()) > 0.5, "most of the table must have been touched"
+
+
+# ------------------------------------------------------------------------------------------------ c4: the bench workload itself
+def test_c4_bench_workload_vs_oracle(hip, monkeypatch):
+    """The workload bench.py times (workload.build_workload('synth-1M-20M'): 1 M nodes, 20 M edges, F = 172, B = 16384, K = 20,
+    time_gap = 2000, T = 100), history evolved by the engine's own pre-roll exactly as bench.py does it:
+
+      1. sampled neighbourhoods of a row sample of the batch [src | dst | neg] (49 152 rows), K = 20 and time_gap = 2000: bit-exact;
+      2. a 256-row sample of combining_pe_raw_feat run over all 49 152 rows in one launch, and the parameter / PE-table gradients of
+         a loss on those rows, vs the oracle;
+      3. update_pe's whole [N+1, 172] table vs the oracle's dense [N+1, 272] scatter version;
+      4. the FFT filter over the evolved, rotated ring (change-mask run kernel) for a sample of batch nodes vs the oracle's
+         torch.fft pipeline on the same nodes' histories;
+      5. the evolved history itself, snapshot by snapshot, vs the same pre-roll with LSTEP_DENSE_HISTORY=1 (no change mask, full clones)."""
+    from lstep_amd.engine import LstepEngine
+    from lstep_amd.workload import build_workload, evolve_history
+    from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model, float64_yardstick
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip("needs ~170 GB of HBM (two 70 GB history rings + the 13.8 GB edge table)")
+    monkeypatch.delenv("LSTEP_DENSE_HISTORY", raising=False)
+    wl = build_workload("synth-1M-20M", DEV, seed=0)
+    N, E, B, K, G, T = wl.num_nodes, wl.num_edges, wl.batch, wl.K, wl.G, wl.T
+    assert (N, E, B, K, G, T) == (1_000_000, 20_000_000, 16384, 20, 2000, 100)
+    eng, hm = wl.engine, wl.model
+    assert eng.ring.sparse and eng.ring.mask is not None
+
+    # the same starting window for the dense ring, then the same pre-roll on both
+    monkeypatch.setenv("LSTEP_DENSE_HISTORY", "1")
+    dense = LstepEngine(hm[0], hm[1], K, G)
+    monkeypatch.delenv("LSTEP_DENSE_HISTORY")
+    assert dense.ring.mask is None and not dense.ring.sparse
+    dense.ring.buf[:T].copy_(eng.ring.buf[:T])
+    dense.ring.start, dense.ring.len = 0, T
+    dense.ring.adopt_full_slots()
+    start = E // 2
+    hm.eval()
+    assert evolve_history(eng, wl.stream, start, B, N) == T
+    assert evolve_history(dense, wl.stream, start, B, N) == T
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i, snap in enumerate(eng.ring.snapshots()):                      # (5)
+        ref = dense.ring.buf[(dense.ring.start + i) % dense.ring.S]
+        worst = max(worst, float((snap - ref).abs().max()))
+    assert worst <= 5e-5, f"sparse change-mask ring vs dense clone ring: {worst}"
+
+    # host copies for the oracle
+    src_a, dst_a = wl.stream.src.cpu().numpy(), wl.stream.dst.cpu().numpy()
+    ts_a, eid_a = wl.stream.ts.cpu().numpy(), wl.stream.eid.cpu().numpy()
+    osamp = OracleNeighborSampler(src_a, dst_a, eid_a, ts_a, num_nodes=N)
+    sd = {k: v.detach().cpu().numpy() for k, v in hm.state_dict().items()}
+    om = build_oracle_model(hm[0].node_raw_features.cpu().numpy(), hm[0].edge_raw_features.cpu().numpy(), osamp, K, T, sd)
+
+    sl = slice(start, start + B)
+    src, dst, t, eid = src_a[sl], dst_a[sl], ts_a[sl], eid_a[sl]
+    neg = synth.make_negatives(N, B, seed=41)
+    ids3, t3 = np.concatenate([src, dst, neg]), np.concatenate([t, t, t])
+    rng = np.random.RandomState(42)
+    pick = np.sort(rng.choice(3 * B, size=256, replace=False))
+
+    for width in (K, G):                                                 # (1)
+        a = wl.sampler.get_historical_neighbors(ids3[pick], t3[pick], width)
+        b = osamp.get_historical_neighbors(ids3[pick], t3[pick], width)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+    assert int((a[0] != 0).sum(axis=1).max()) > K, "time_gap slots beyond K must be exercised"
+
+    # (4) FFT filter over the rotated ring for a sample of the batch nodes
+    bn = protocol.unique_batch_nodes(src, dst)
+    nodes = np.sort(rng.choice(bn, size=256, replace=False))
+    nodes_d = torch.from_numpy(nodes).to(DEV)
+    assert eng.ring.start != 0
+    with torch.no_grad():
+        eng.ring.wait_window()
+        got_f = hm[0].filter_history(eng.ring.buf, eng.ring.geom(), nodes_d, 1234, mask=eng.ring.mask, oldest=eng.ring.oldest).cpu().numpy()
+        hist = torch.stack([dense.ring.buf[(dense.ring.start + i) % dense.ring.S][nodes_d] for i in range(T)], dim=1).cpu()   # [256, T, P]
+        ref_f = om[0].fourier_transform_pe(np.arange(256), hist, 1234).numpy()
+    np.testing.assert_allclose(got_f, ref_f, **TOL)
+    del dense
+    torch.cuda.empty_cache()
+
+    pe_dev = eng.ring.last().clone()                                     # the evolved current PE table
+    pe_cpu = pe_dev.cpu()
+
+    # (2) embeddings of the whole batch in one launch; oracle on the sample rows; gradients of a loss on those rows
+    hm.train(), om.train()
+    pe_o = pe_cpu.clone().requires_grad_(True)
+    pe_h = pe_dev.clone().requires_grad_(True)
+    wgt = torch.from_numpy(rng.standard_normal((256, synth.FEAT_DIM)).astype(np.float32))
+    ref = om[0].combining_pe_raw_feat(pe_o, ids3[pick], t3[pick], K, G)
+    got = hm[0].combining_pe_raw_feat(pe_h, torch.from_numpy(ids3).to(DEV), torch.from_numpy(t3).to(DEV), K, G)
+    assert tuple(got.shape) == (3 * B, synth.FEAT_DIM)
+    np.testing.assert_allclose(got.detach().cpu().numpy()[pick], ref.detach().numpy(), **TOL)
+    (ref * wgt).sum().backward()
+    full_w = torch.zeros(3 * B, synth.FEAT_DIM)
+    full_w[pick] = wgt
+    (got * full_w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(pe_h.grad.cpu().numpy(), pe_o.grad.numpy(), **TOL)
+    _compare_grads(om, hm, 2e-5, "c4")
+    del pe_o, pe_h, got, ref
+
+    # (3) update_pe over the full batch: every row of the 1 M-row table
+    with torch.no_grad():
+        ref_t = om[0].update_pe(pe_cpu.clone(), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).numpy()
+        got_t = hm[0].update_pe(pe_dev.clone(), torch.from_numpy(bn).to(DEV), torch.from_numpy(eid).to(DEV), torch.from_numpy(src).to(DEV),
+                                torch.from_numpy(dst).to(DEV), torch.from_numpy(t).to(DEV), float(t.max()), num_neighbors=K, time_gap=G).cpu().numpy()
+    f64 = lambda: float64_yardstick(om, tables=False)[0].update_pe(pe_cpu.double(), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).numpy()  # noqa: E731
+    _parity(got_t, ref_t, f64, 5e-5, "c4 update_pe")
+    changed = float((np.abs(got_t - pe_cpu.numpy()).max(axis=1) > 0).mean())
+    assert 0.1 < changed < 0.6, f"update_pe should touch roughly a quarter of the table at this shape, got {changed:.2f}"

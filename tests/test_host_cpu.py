@@ -183,3 +183,29 @@ def test_graft_entry_build_runs():
     import importlib
     entry = importlib.import_module("__graft_entry__")
     entry.build()
+
+
+def test_lookahead_batch_key_survives_allocator_reuse():
+    """The look-ahead grouping is only picked up for the SAME endpoint buffers, unmodified.  The key keeps the tensors alive, so a later
+    batch can never sit at a freed look-ahead batch's address (the collision the old (data_ptr, numel, version) key allowed)."""
+    import gc
+
+    import torch
+
+    from lstep_amd.engine import BatchKey
+    base_s, base_d = torch.arange(100), torch.arange(100, 200)
+    src, dst = base_s[10:30], base_d[10:30]
+    key = BatchKey(src, dst)
+    assert key.matches(base_s[10:30], base_d[10:30])            # another view of the same memory (what EdgeStream.batch returns)
+    assert not key.matches(base_s[11:31], base_d[10:30])
+    assert not key.matches(base_s[10:29], base_d[10:29])
+    base_s[12] = 7                                              # written since: version counters are shared by all views
+    assert not key.matches(base_s[10:30], base_d[10:30])
+    # freed look-ahead tensors: the key's references keep the block, a new batch of the same size gets other memory
+    a, b = torch.arange(64) + 1, torch.arange(64) + 2
+    key = BatchKey(a, b)
+    ptrs = (a.data_ptr(), b.data_ptr())
+    del a, b
+    gc.collect()
+    c, d = torch.arange(64) + 3, torch.arange(64) + 4
+    assert (c.data_ptr(), d.data_ptr()) != ptrs and not key.matches(c, d)
