@@ -39,6 +39,18 @@ def gather_algorithmic_bytes(count: torch.Tensor, K: int, G: int, row_bytes: int
     return float((row_bytes * (2 * k + v + 3) + 24 * k + 8 * v).sum().item())
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(seconds_budget: float = 25.0):
     """Oracle train iterations on a bounded sample: same degree structure (E/N = 20), K, time_gap, T; smaller N and batch."""
     from lstep_amd import protocol, synth
@@ -80,9 +92,33 @@ def cpu_baseline(seconds_budget: float = 25.0):
         if len(times) >= 8:
             break
     per_iter = float(np.mean(times))
-    return {"value": B / per_iter, "unit": "edges/s", "cores": cores, "kind": "port",
+    return {"value": B / per_iter, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "host_cores_visible": avail,
             "sample": f"oracle (reference op sequence) train iteration, synthetic {N} nodes / {E} edges (same E/N as the GPU workload), "
                       f"batch {B}, K={K}, time_gap={G}, T={T} history full; {len(times)} timed iterations after 1 warm-up, {per_iter * 1e3:.0f} ms each"}
+
+
+def default_workload(gpus: int) -> str:
+    """BASELINE.json: configs[3] (1 M nodes / 20 M edges, B = 16384) is the single-GPU workload and the 4-GPU one; configs[4]
+    (4 M / 100 M) the 8-GPU one.  Weak scaling: every rank contributes B = 16384 edges to the global batch."""
+    return "synth-4M-100M" if gpus >= 8 else "synth-1M-20M"
+
+
+def launch_ranks(gpus: int, argv) -> int:
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()       # (does not initialise the GPU runtime)
+    if have < gpus and os.environ.get("LSTEP_SINGLE_DEVICE") != "1":
+        print(f"bench.py: --gpus {gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -90,10 +126,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="synth-1M-20M")
+    ap.add_argument("--workload", default=None, help="default by --gpus: 1, 2, 4 -> synth-1M-20M (BASELINE.json configs[3]), 8 -> synth-4M-100M "
+                                                     "(configs[4]); the per-GPU batch is fixed (weak scaling), the global batch is gpus x batch")
     ap.add_argument("--time-gap", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prime", type=int, default=12, help="training iterations run as part of the set-up pre-roll, before the warm-up steps")
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="eval = evaluate_model_utils.py:38-142 iteration (4x combine, no backward)")
     ap.add_argument("--zipf", type=float, default=None, help="power-law endpoint popularity exponent (hub-skew variant)")
     ap.add_argument("--history", choices=["evolved", "random"], default="evolved",
@@ -102,12 +140,19 @@ def main():
                          "random = T independent random tables (every row differs between snapshots: the worst case for the filter)")
     args = ap.parse_args()
 
+    if args.workload is None:
+        args.workload = default_workload(args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU under torch.distributed.run, BEFORE anything
+        # in this process touches the GPU (a process that has initialised HIP must not be re-exec'ed or forked), and hand its exit
+        # code on.  Rank 0 of the child job prints the JSON line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {args.gpus}` (it starts its own ranks) "
+                         f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if os.environ.get("LSTEP_SINGLE_DEVICE") == "1":   # rehearsal of the N > 1 plumbing on a one-GPU box (with LSTEP_DIST_BACKEND=gloo)
         local_rank = 0
@@ -148,9 +193,11 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)
     prerolled = 0
+    prime = args.prime if args.mode == "train" else 0
+    prime = max(0, min(prime, start // (B * world) - 1))
     if args.history == "evolved":
         from lstep_amd.workload import evolve_history
-        prerolled = evolve_history(runner, wl.stream, start, B * world, wl.num_nodes)
+        prerolled = evolve_history(runner, wl.stream, start - prime * B * world, B * world, wl.num_nodes)
 
     def step(i):
         lo = start + i * B * world
@@ -170,6 +217,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Setup, not measurement: `prime` TRAINING iterations on the batches right before the first warm-up batch finish the pre-roll.  The
+    # first training iterations of a process are 1.5-2x slower than the steady state (HIP-graph capture of the weight composition, the
+    # first synchronous gradient sort of every call site, and above all the caching allocator, which needs about ten iterations of the
+    # three-stream schedule before it stops calling hipMalloc); with the driver's `--warmup 5` they sat inside the timed region
+    # (round-1 record: 4.35 ms/step over 20 steps whose last twelve ran at 3.6).
+    for i in range(-prime, 0):
+        step(i)
     for i in range(args.warmup):
         step(i)
     # Host hygiene before the timed region: move everything allocated so far (torch, the workload, the captured graphs: a few million
@@ -210,7 +264,7 @@ def main():
         # HBM traffic per launch of the gather kernel: not measurable from inside the process; taken from the committed PMC
         # passes of this same command (profiles/*pmc_traffic.json, made by tools/pmc_summary.py), default workload only
         traffic, traffic_src = None, None
-        if args.workload == "synth-1M-20M" and args.batch is None and args.time_gap == 2000:
+        if args.workload == "synth-1M-20M" and args.batch is None and args.time_gap == 2000 and world == 1:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
             if cands:
@@ -235,9 +289,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl.describe() + (f", zipf {args.zipf} endpoints" if args.zipf else ""), "global_batch": B * world,
-                       "history": (f"evolved: {prerolled} pre-roll batches through the engine's own eval iteration" if args.history == "evolved"
-                                   else "random: T independent snapshots"),
-                       "parallelism": f"owner-sharded history + row-sharded batch x{world} (RCCL)" if use_dist else "single GPU"},
+                       "per_gpu_batch": B, "workload_name": args.workload,
+                       "history": (f"evolved: {prerolled} pre-roll batches through the engine's own eval iteration + {prime} through its training iteration"
+                                   if args.history == "evolved" else f"random: T independent snapshots (+ {prime} training iterations of set-up)"),
+                       "parallelism": (f"x{world}: PE history, FFT filter and update_pe sharded by node owner (id % {world}); gather / dense tail / loss "
+                                       f"on each rank's {B}-edge slice of the global batch; RCCL all-gather of updated PE rows") if use_dist
+                                      else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "lstep::gather_aggregate_fwd_kernel<true, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),

@@ -36,70 +36,86 @@ from .model import SplicedRows
 
 
 # ---------------------------------------------------------------------------------------------- collectives
+# ONE code path for RCCL and gloo: equal padded blocks in the flat [W * rows, ...] layout both backends accept for
+# all_gather_into_tensor / reduce_scatter_tensor, so the world-size-2 gloo tests execute exactly the branches RCCL executes on
+# the GPUs.  The only backend difference left: gloo has no device collectives, so CUDA tensors are staged through the host
+# (tests with several ranks on one GPU).  LSTEP_FORCE_COLLECTIVES=1 keeps the collectives even at world size 1 (the -m gpu test
+# that runs the RCCL calls on a one-GPU box).
 def _staged(t: torch.Tensor, group) -> bool:
-    """gloo has no CUDA all_gather: stage through the host (tests on one GPU); RCCL works on device memory."""
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def all_gather_var(t: torch.Tensor, group=None, counts=None):
-    """All-gather of row blocks with different row counts.  Returns (concatenated rows in rank order, counts list).
-    ``counts`` (rows per rank) may be passed when every rank can derive it locally: that saves the size exchange and its
-    host sync.  RCCL path: one ``all_gather_into_tensor`` of equal padded blocks; gloo: list all_gather (CPU staging)."""
-    w = dist.get_world_size(group)
-    dev = t.device
-    staged = _staged(t, group)
-    if counts is None:
-        n = torch.tensor([t.shape[0]], dtype=torch.int64, device="cpu" if staged else dev)
-        ns = [torch.zeros_like(n) for _ in range(w)]
-        dist.all_gather(ns, n, group=group)
-        counts = [int(x.item()) for x in ns]
-    mx = max(counts)
-    if w == 1:
-        return t, counts
-    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+def _skip_single(w: int) -> bool:
+    return w == 1 and os.environ.get("LSTEP_FORCE_COLLECTIVES") != "1"
+
+
+def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    if t.shape[0] == rows and t.is_contiguous():
+        return t
+    pad = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
-    if dist.get_backend(group) == "gloo":
-        if staged:
-            pad = pad.cpu()
-        outs = [torch.empty_like(pad) for _ in range(w)]
-        dist.all_gather(outs, pad, group=group)
-        return torch.cat([o[:c] for o, c in zip(outs, counts)], dim=0).to(dev), counts
-    out = torch.empty((w, mx) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    return pad
+
+
+def _unpad_blocks(flat: torch.Tensor, counts, mx: int) -> torch.Tensor:
+    """[W * mx, ...] of equal padded blocks -> the counts[r] valid rows of every block, concatenated in rank order."""
     if all(c == mx for c in counts):
-        return out.reshape((w * mx,) + tuple(t.shape[1:])), counts
-    return torch.cat([out[i, :c] for i, c in enumerate(counts)], dim=0), counts
+        return flat
+    return torch.cat([flat[i * mx:i * mx + c] for i, c in enumerate(counts)], dim=0)
+
+
+def exchange_counts(n: int, device, group=None):
+    """Row count of every rank (one small all-gather + a host read: avoid it where the counts can be derived locally)."""
+    w = dist.get_world_size(group)
+    if _skip_single(w):
+        return [int(n)]
+    staged = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+    mine = torch.tensor([int(n)], dtype=torch.int64, device="cpu" if staged else device)
+    ns = torch.empty((w,), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(ns, mine, group=group)
+    return [int(x) for x in ns.tolist()]
 
 
 class PendingGather:
-    """An all-gather of row blocks that is in flight on RCCL's stream (``async_op=True``) while the caller keeps
-    enqueueing compute; ``wait()`` makes the current stream wait for it and returns the concatenated rows."""
+    """All-gather of row blocks with different row counts, left in flight (``async_op=True``: on RCCL's stream, or in gloo's worker
+    thread) while the caller keeps enqueueing compute; ``wait()`` makes the current stream wait for it and returns the rows of all
+    ranks concatenated in rank order.  ``counts`` (rows per rank) may be passed when every rank can derive it locally: that saves the
+    size exchange and its host sync."""
 
-    def __init__(self, t: torch.Tensor, group=None):
-        self.group, self.work, self.done = group, None, None
+    def __init__(self, t: torch.Tensor, group=None, counts=None):
+        self.done, self.work = None, None
         w = dist.get_world_size(group)
-        if dist.get_backend(group) == "gloo":
-            self.done = all_gather_var(t, group)[0]          # no asynchronous CUDA collectives on gloo: finish now
+        self.counts = counts if counts is not None else exchange_counts(t.shape[0], t.device, group)
+        if _skip_single(w):
+            self.done = t
             return
-        dev = t.device
-        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
-        ns = torch.empty((w,), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(ns, n, group=group)
-        self.counts = ns.tolist()
-        mx = max(self.counts)
-        self.pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        self.pad[: t.shape[0]] = t
-        self.out = torch.empty((w, mx) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        self.work = dist.all_gather_into_tensor(self.out, self.pad, group=group, async_op=True)
+        self.dev, self.mx = t.device, max(self.counts)
+        self.staged = _staged(t, group)
+        pad = _pad_rows(t, self.mx)
+        if self.staged:
+            pad = pad.cpu()
+        self.pad = pad                                   # (kept alive until the collective has finished)
+        self.out = torch.empty((w * self.mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=pad.device)
+        self.work = dist.all_gather_into_tensor(self.out, pad, group=group, async_op=True)
 
     def wait(self) -> torch.Tensor:
         if self.done is None:
             self.work.wait()
-            self.done = torch.cat([self.out[i, :c] for i, c in enumerate(self.counts)], dim=0)
+            out = _unpad_blocks(self.out, self.counts, self.mx)
+            self.done = out.to(self.dev) if self.staged else out
+            self.pad = self.out = self.work = None
         return self.done
 
 
+def all_gather_var(t: torch.Tensor, group=None, counts=None):
+    """Blocking form of ``PendingGather``.  Returns (concatenated rows in rank order, counts list)."""
+    g = PendingGather(t, group, counts)
+    return g.wait(), g.counts
+
+
 def all_reduce_sum(t: torch.Tensor, group=None):
+    if _skip_single(dist.get_world_size(group)):
+        return t
     if _staged(t, group):
         c = t.cpu()
         dist.all_reduce(c, group=group)
@@ -110,23 +126,28 @@ def all_reduce_sum(t: torch.Tensor, group=None):
 
 
 def reduce_scatter_var(t: torch.Tensor, counts, group=None):
-    """Sum ``t`` (rows ordered rank-major, ``counts[r]`` rows for rank r) over all ranks and return THIS rank's block.
-    RCCL: one reduce_scatter of equal padded blocks (each rank receives only what it owns: half the traffic of an
-    all-reduce); gloo (CPU tests / staged CUDA tensors): all_reduce + slice."""
+    """Sum ``t`` (rows ordered rank-major, ``counts[r]`` rows for rank r) over all ranks and return THIS rank's block: one
+    reduce_scatter of equal padded blocks (each rank receives only what it owns: half the traffic of an all-reduce)."""
     w, r = dist.get_world_size(group), dist.get_rank(group)
-    offs = [0]
-    for c in counts:
-        offs.append(offs[-1] + c)
-    if dist.get_backend(group) == "gloo":
-        all_reduce_sum(t, group)
-        return t[offs[r]:offs[r + 1]]
+    assert len(counts) == w and sum(counts) == t.shape[0]
+    if _skip_single(w):
+        return t
     mx = max(counts)
-    padded = torch.zeros((w, mx) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    for i, c in enumerate(counts):
-        padded[i, :c] = t[offs[i]:offs[i + 1]]
-    out = torch.empty((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if all(c == mx for c in counts):
+        padded = t.contiguous()
+    else:
+        padded = torch.zeros((w * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        off = 0
+        for i, c in enumerate(counts):
+            padded[i * mx:i * mx + c] = t[off:off + c]
+            off += c
+    staged = _staged(t, group)
+    if staged:
+        padded = padded.cpu()
+    out = torch.empty((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=padded.device)
     dist.reduce_scatter_tensor(out, padded, group=group)
-    return out[:counts[r]]
+    out = out[:counts[r]]
+    return out.to(t.device) if staged else out
 
 
 def all_reduce_gradients(params, group=None):
@@ -291,7 +312,7 @@ class DistributedLstep:
         if fused:
             ids = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted, fused=True,
                                            owned_idx=owned_idx)
-            if self.W > 1:
+            if not _skip_single(self.W):
                 self._write_rows(all_gather_var(self._rows_with_ids(ids), self.group, counts=owner_counts)[0])
         else:
             ids, z = self.bb.update_pe_phase1(self.table, bn, src, dst, ts, now32, shard=shard, presorted=presorted)
@@ -308,7 +329,7 @@ class DistributedLstep:
         if fused:
             ids = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard, fused=True)
             ring.mark(ids, self.W, self.rank)
-            return ("rows", PendingGather(self._rows_with_ids(ids), self.group) if self.W > 1 else None)
+            return ("rows", PendingGather(self._rows_with_ids(ids), self.group) if not _skip_single(self.W) else None)
         ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
         ring.mark(ids, self.W, self.rank)
         return ("z", PendingGather(pack_ids(z, ids, self.bb.pe_dim), self.group))

@@ -301,6 +301,69 @@ def gen_traces():
     print("traces.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------- row P pinned by the reference's own loop
+EVAL_LOOP = dict(first=1200, edges=6 * 16 + 5, batch=16, stored=2)      # a ragged tail batch of 5 edges (drop_last=False)
+
+
+def gen_eval_loop():
+    """The reference's OWN evaluation loop (``evaluate_model_utils.evaluate_model_link_prediction``, an importable function -- unlike the
+    training loop, which is a script body) on a tiny ``Data`` with its own index ``DataLoader`` and seeded ``NegativeEdgeSampler``s.
+    Nothing of ``lstep_amd.protocol`` is involved: the fixture pins ``protocol.eval_iteration``, the oracle and the engine to
+    reference-executed loop code.  Recorded through hooks: the negatives the sampler drew (they are inputs of the hot path), the
+    link predictor's logits, the table every ``update_pe`` returned; returned by the function: the per-batch losses."""
+    from evaluate_model_utils import evaluate_model_link_prediction
+    from utils.DataLoader import get_idx_data_loader
+    from utils.utils import NegativeEdgeSampler
+    g = synth.make_temporal_graph(**TRACE_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=31)
+    sampler = ref_sampler(g)
+    lo, n, bsz = EVAL_LOOP["first"], EVAL_LOOP["edges"], EVAL_LOOP["batch"]
+    sl = slice(lo, lo + n)
+    data = Data(g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], np.zeros(n))
+    rng = np.random.RandomState(61)
+    hist0 = (0.1 * rng.standard_normal((g["num_nodes"] + 1, EVAL_LOOP["stored"], synth.PE_DIM))).astype(np.float32)
+    out = {"history0": hist0}
+    for strategy in ("random", "historical"):
+        model = ref_model(node_raw, edge_raw, sampler, TRACE_K, TRACE_T)
+        neg = NegativeEdgeSampler(src_node_ids=g["src"], dst_node_ids=g["dst"], interact_times=g["ts"], negative_sample_strategy=strategy, seed=2)
+        drawn, logits, tables = [], [], []
+        sample = neg.sample
+
+        def recording_sample(*a, _sample=sample, **k):
+            res = _sample(*a, **k)
+            drawn.append(res)
+            return res
+
+        neg.sample = recording_sample
+        update = model[0].update_pe
+
+        def recording_update(*a, _update=update, **k):
+            res = _update(*a, **k)
+            tables.append(res.detach().numpy().copy())
+            return res
+
+        model[0].update_pe = recording_update
+        hook = model[1].register_forward_hook(lambda mod, args, res: logits.append(res.detach().numpy().copy()))
+        loader = get_idx_data_loader(indices_list=list(range(n)), batch_size=bsz, shuffle=False)
+        losses, metrics = evaluate_model_link_prediction(model_name="LSTEP", model=model, final_trained_positional_encoding=torch.from_numpy(hist0.copy()),
+                                                         neighbor_sampler=sampler, evaluate_idx_data_loader=loader, evaluate_neg_edge_sampler=neg,
+                                                         evaluate_data=data, loss_func=torch.nn.BCELoss(), num_fft_batches=TRACE_T,
+                                                         num_neighbors=TRACE_K, time_gap=TRACE_G)
+        hook.remove()
+        nb = len(losses)
+        assert nb == (n + bsz - 1) // bsz == len(drawn) == len(tables) and len(logits) == 2 * nb
+        out[f"{strategy}/losses"] = np.asarray(losses, dtype=np.float64)
+        out[f"{strategy}/average_precision"] = np.asarray([m["average_precision"] for m in metrics])
+        for b in range(nb):
+            out[f"{strategy}/b{b}/neg_src"] = np.asarray(drawn[b][0], dtype=np.int64)
+            out[f"{strategy}/b{b}/neg_dst"] = np.asarray(drawn[b][1], dtype=np.int64)
+            out[f"{strategy}/b{b}/pos_logits"] = logits[2 * b].reshape(-1)
+            out[f"{strategy}/b{b}/neg_logits"] = logits[2 * b + 1].reshape(-1)
+            out[f"{strategy}/b{b}/snapshot"] = tables[b]
+    np.savez_compressed(os.path.join(HERE, "eval_loop.npz"), **out)
+    print("eval_loop.npz", len(out), "arrays")
+
+
 # ----------------------------------------------------------------------------------------------- RNG-defined sampling
 def gen_random_sampling():
     from utils.utils import get_neighbor_sampler as ref_get
@@ -357,7 +420,7 @@ def gen_loader():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling"]
+    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop"]
     if "sampler" in which:
         gen_sampler()
     if "time" in which:
@@ -370,3 +433,5 @@ if __name__ == "__main__":
         gen_loader()
     if "random_sampling" in which:
         gen_random_sampling()
+    if "eval_loop" in which:
+        gen_eval_loop()

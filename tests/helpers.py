@@ -22,6 +22,7 @@ METHOD_K, METHOD_T = 5, 6
 TRACE_GRAPH = dict(num_nodes=64, num_edges=2000, seed=30)
 TRACE_K, TRACE_T, TRACE_B, TRACE_G = 5, 4, 16, 2000
 TRACE_START, TRACE_BATCHES, GRAD_ROW_STRIDE = 640, 7, 4
+EVAL_LOOP = dict(first=1200, edges=6 * 16 + 5, batch=16, stored=2)
 
 
 def method_inputs():
@@ -69,3 +70,21 @@ def param_digest(model):
 
 def state_dict_tensors(K, T, seed=3, device="cpu"):
     return {k: torch.from_numpy(v).to(device) for k, v in synth.make_state_dict(K, T, seed=seed).items()}
+
+
+def eval_loop_batches(g, z, strategy):
+    """The batches the reference's own evaluate_model_link_prediction iterated over (tests/golden/eval_loop.npz): its index DataLoader's
+    chronological slices incl. the ragged tail, and the negatives its NegativeEdgeSampler drew for each."""
+    lo, n, bsz = EVAL_LOOP["first"], EVAL_LOOP["edges"], EVAL_LOOP["batch"]
+    out = []
+    for b, s0 in enumerate(range(lo, lo + n, bsz)):
+        sl = slice(s0, min(s0 + bsz, lo + n))
+        out.append((g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], z[f"{strategy}/b{b}/neg_src"], z[f"{strategy}/b{b}/neg_dst"]))
+    return out
+
+
+def eval_loop_expected(z, strategy, b):
+    """(probabilities [pos | neg], snapshot, loss) the reference's loop produced for batch b."""
+    logits = np.concatenate([z[f"{strategy}/b{b}/pos_logits"], z[f"{strategy}/b{b}/neg_logits"]])
+    prob = np.clip(1.0 / (1.0 + np.exp(-logits.astype(np.float64))), 0.0, 1.0)
+    return prob, z[f"{strategy}/b{b}/snapshot"], float(z[f"{strategy}/losses"][b])

@@ -7,8 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (GRAD_ROW_STRIDE, METHOD_K, METHOD_T, SAMPLER_GRAPHS, TRACE_B, TRACE_BATCHES, TRACE_G, TRACE_K, TRACE_START,
-                     TRACE_T, eval_batches, method_inputs, param_digest, trace_batches, trace_inputs)
+from helpers import (EVAL_LOOP, GRAD_ROW_STRIDE, METHOD_K, METHOD_T, SAMPLER_GRAPHS, TRACE_B, TRACE_BATCHES, TRACE_G, TRACE_K, TRACE_START,
+                     TRACE_T, eval_batches, eval_loop_batches, eval_loop_expected, method_inputs, param_digest, trace_batches, trace_inputs)
 from lstep_amd import protocol, synth
 
 pytestmark = pytest.mark.gpu
@@ -262,6 +262,40 @@ def test_train_eval_traces_golden(hip, golden, mode):
             np.testing.assert_allclose(loss, z[f"eval/b{b}/loss"][0], rtol=0, atol=2e-5)
             np.testing.assert_allclose(predicts, z[f"eval/b{b}/predicts"], **TOL)
             np.testing.assert_allclose(snap, z[f"eval/b{b}/snapshot"], **TOL)
+
+
+@pytest.mark.parametrize("strategy", ["random", "historical"])
+@pytest.mark.parametrize("mode", ["dropin", "engine"])
+def test_eval_protocol_matches_the_references_own_loop(hip, golden, mode, strategy):
+    """tests/golden/eval_loop.npz was produced by the reference's own ``evaluate_model_link_prediction`` (not by this repository's
+    restatement of the loop): per-batch losses, link probabilities and the table each update_pe returned, incl. a ragged 5-edge tail
+    batch and negatives from its own NegativeEdgeSampler.  Both the reference-shaped drop-in protocol and the device engine must
+    reproduce them."""
+    z = golden("eval_loop")
+    g, node_raw, edge_raw, _ = trace_inputs()
+    model = hip.build(node_raw, edge_raw, hip_sampler(hip, g), TRACE_K, TRACE_T, synth.make_state_dict(TRACE_K, TRACE_T), DEV)
+    model.eval()
+    hist0 = torch.from_numpy(z["history0"].copy()).to(DEV)
+    if mode == "dropin":
+        st = protocol.ProtocolState(history=hist0)
+    else:
+        eng = hip.LstepEngine(model[0], model[1], TRACE_K, TRACE_G)
+        eng.ring.load(hist0)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    with torch.no_grad():
+        for b, (src, dst, t, eid, neg_src, neg_dst) in enumerate(eval_loop_batches(g, z, strategy)):
+            if strategy == "random":        # that strategy's negative sources ARE the batch sources (evaluate_model_utils.py:52-53)
+                neg_src = src
+            if mode == "dropin":
+                res = protocol.eval_iteration(model[0], model[1], st, b, src, dst, t, eid, neg_src, neg_dst, TRACE_K, TRACE_G, TRACE_T)
+                got_p, got_s, got_l = res["predicts"], st.history[:, -1, :].cpu().numpy(), res["loss"]
+            else:
+                res = eng.eval_iteration(b, dev(src), dev(dst), dev(t), dev(eid), dev(neg_src), dev(neg_dst))
+                got_p, got_s, got_l = res["predicts"].cpu().numpy(), eng.ring.last().cpu().numpy(), float(res["loss"])
+            prob, snap, loss = eval_loop_expected(z, strategy, b)
+            np.testing.assert_allclose(got_p, prob, err_msg=f"batch {b}", **TOL)
+            np.testing.assert_allclose(got_s, snap, err_msg=f"batch {b}", **TOL)
+            np.testing.assert_allclose(got_l, loss, rtol=0, atol=2e-5)
 
 
 # ------------------------------------------------------------------------------------------------ oracle at larger sizes

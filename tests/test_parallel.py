@@ -23,15 +23,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":       # = RCCL on ROCm
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
 def _cpu_worker(rank, world, port, q):
     try:
         _init(rank, world, port)
-        from lstep_amd.parallel import all_gather_var, all_reduce_gradients, all_reduce_sum, owned_rows, reduce_scatter_var
+        from lstep_amd.parallel import PendingGather, all_gather_var, all_reduce_gradients, all_reduce_sum, owned_rows, reduce_scatter_var
         # uneven row blocks, incl. an empty one
         t = torch.arange(rank * 3 * 4, dtype=torch.float32).reshape(rank * 3, 4) + 100 * rank
         cat, counts = all_gather_var(t)
@@ -41,6 +45,20 @@ def _cpu_worker(rank, world, port, q):
         assert cat.tolist() == [5, 5, 7] and counts == [1, 2]
         blk = reduce_scatter_var(torch.arange(10, dtype=torch.float32).reshape(5, 2) * (rank + 1), [2, 3])
         assert torch.equal(blk, (torch.arange(10, dtype=torch.float32).reshape(5, 2) * 3)[:2] if rank == 0 else (torch.arange(10, dtype=torch.float32).reshape(5, 2) * 3)[2:])
+        # equal counts (no un-padding), rows with trailing dimensions, counts known locally (no size exchange), and the asynchronous form
+        t3 = torch.arange(2 * 3 * 2, dtype=torch.float32).reshape(2, 3, 2) + 1000 * rank
+        cat, counts = all_gather_var(t3, counts=[2, 2])
+        assert counts == [2, 2] and cat.shape == (4, 3, 2) and torch.equal(cat[2:], torch.arange(12, dtype=torch.float32).reshape(2, 3, 2) + 1000)
+        pend = PendingGather(torch.full((rank + 2, 5), float(rank)))
+        got = pend.wait()
+        assert pend.counts == [2, 3] and got.shape == (5, 5) and got[:2].eq(0).all() and got[2:].eq(1).all() and pend.wait() is got
+        # padded reduce-scatter against all_reduce + slice, uneven incl. an empty block, with trailing dimensions
+        for cnt in ([2, 3], [5, 0], [0, 5], [4, 4]):
+            full = torch.randn(sum(cnt), 3, 2, generator=torch.Generator().manual_seed(7 + rank))
+            want = all_reduce_sum(full.clone())
+            off = [0, cnt[0], sum(cnt)]
+            blk = reduce_scatter_var(full, cnt)
+            assert blk.shape[0] == cnt[rank] and torch.allclose(blk, want[off[rank]:off[rank + 1]], atol=1e-6)
         v = torch.full((3,), float(rank + 1))
         assert all_reduce_sum(v).tolist() == [3.0, 3.0, 3.0]
         lin = torch.nn.Linear(3, 2)
@@ -76,10 +94,10 @@ def test_collective_helpers_gloo_world2():
     _run(_cpu_worker, 2)
 
 
-def _gpu_worker(rank, world, port, q):
+def _gpu_worker(rank, world, port, q, backend="gloo"):
     try:
-        _init(rank, world, port)
         torch.cuda.set_device(0)
+        _init(rank, world, port, backend)
         dev = "cuda:0"
         from lstep_amd.engine import EdgeStream, LstepEngine
         from lstep_amd.parallel import DistributedLstep, all_gather_var
@@ -92,7 +110,7 @@ def _gpu_worker(rank, world, port, q):
         model.train()
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
         dl = DistributedLstep(LstepEngine(model[0], model[1], TRACE_K, TRACE_G, make_ring=False), opt)
-        assert dl.ring.rows == (33 if rank == 0 else 32)
+        assert dl.ring.rows == (65 - rank + world - 1) // world
         stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], dev)
         init = torch.from_numpy(pe0.copy()).to(dev)
         tol = dict(rtol=0, atol=5e-5)
@@ -134,6 +152,16 @@ def test_distributed_engine_reproduces_golden_trace_2_ranks_one_gpu():
 
 
 @pytest.mark.gpu
+def test_distributed_engine_on_rccl_world_size_1_reproduces_golden_trace(monkeypatch):
+    """The RCCL calls themselves (``backend="nccl"``: all_gather_into_tensor of padded blocks, the asynchronous gather left in flight on
+    RCCL's stream, reduce_scatter_tensor, the flat gradient all-reduce) on the one GPU of the test box: world size 1 with
+    LSTEP_FORCE_COLLECTIVES=1, so no collective is short-circuited.  Same golden trace as the 2-rank gloo run above."""
+    assert torch.cuda.is_available()
+    monkeypatch.setenv("LSTEP_FORCE_COLLECTIVES", "1")      # (inherited by the spawned rank)
+    _run(_gpu_worker, 1, "nccl")
+
+
+@pytest.mark.gpu
 def test_bench_multi_rank_plumbing_gloo_two_ranks_one_gpu():
     """`bench.py --gpus 2` under torch.distributed.run (the driver's launch line), rehearsed on one GPU with gloo: the JSON
     line must come out with n_gpus = 2 and a global batch of 2 x B."""
@@ -150,3 +178,29 @@ def test_bench_multi_rank_plumbing_gloo_two_ranks_one_gpu():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["value"] > 0
     assert line["roofline"]["rows_per_launch"] == 3 * 256
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no WORLD_SIZE in the environment): bench.py must start the two ranks itself, before touching the
+    GPU, and rank 0's JSON line must come out of the parent's stdout.  Rehearsed on one GPU with gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LSTEP_SINGLE_DEVICE="1", LSTEP_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "tiny",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["config"]["per_gpu_batch"] == 256 and line["value"] > 0
+
+
+def test_bench_default_workload_by_gpu_count():
+    import importlib.util
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    spec = importlib.util.spec_from_file_location("lstep_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert [mod.default_workload(n) for n in (1, 2, 4, 8)] == ["synth-1M-20M"] * 3 + ["synth-4M-100M"]
