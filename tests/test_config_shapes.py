@@ -23,7 +23,6 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 TOL = dict(rtol=0, atol=5e-5)
-BAR = dict(rtol=0, atol=1e-4)     # north_star's bar; used where thousands of fp32 terms are summed in a different order
 
 
 @pytest.fixture(scope="module")
@@ -50,36 +49,72 @@ def _oracle(g, node_raw, edge_raw, K, T, sd):
     return build_oracle_model(node_raw, edge_raw, osamp, K, T, sd), osamp
 
 
-def _oracle_state_step(om, st, batch_idx, src, dst, ts, eid, K, G, T):
+class _RollingOracleHistory:
+    """The oracle's PE history ``[N+1, t, P]`` for a long pre-roll without the reference's per-batch ``torch.cat`` of the whole tensor
+    (0.6 GB per batch at N = 9 227, T = 100): snapshots are appended as columns of one buffer and the window is a view of it.  Same
+    content as ``protocol.ProtocolState.history`` after the same batches (``as_state`` hands it over)."""
+
+    def __init__(self, first: torch.Tensor, T: int, total: int):
+        self.T = T
+        self.buf = torch.empty((first.shape[0], total + 1, first.shape[1]), dtype=first.dtype)
+        self.buf[:, 0] = first
+        self.n = 1
+
+    def window(self):
+        return self.buf[:, max(0, self.n - self.T):self.n]
+
+    def append(self, snap):
+        self.buf[:, self.n] = snap
+        self.n += 1
+
+    def as_state(self):
+        return protocol.ProtocolState(history=self.window().clone())
+
+
+def _oracle_state_step(om, hist, batch_idx, src, dst, ts, eid, K, G, o64=None):
     """The STATE transition of one evaluation batch (evaluate_model_utils.py:57-63,118-135): FFT splice, update_pe, append.  The four
-    combining_pe_raw_feat calls of that loop only feed the metrics, so the pre-roll skips them on the CPU (2 s each at B = 600)."""
+    combining_pe_raw_feat calls of that loop only feed the metrics, so the pre-roll skips them on the CPU (2 s each at B = 600).
+    ``o64``: also returns the padding row of a float64 ``update_pe`` applied to the same spliced table (the yardstick of ``_parity``)."""
     bn = protocol.unique_batch_nodes(src, dst)
-    st.history, cur = protocol.splice_current_pe(om[0], st.history, bn, batch_idx, T)
+    window = hist.window()
+    cur = window[:, -1, :].clone()
+    cur[torch.from_numpy(bn)] = om[0].fourier_transform_pe(bn, window, batch_idx)
+    row0_64 = None
+    if o64 is not None:
+        row0_64 = o64[0].update_pe(pe=cur.double(), node_ids=bn, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
+                                   node_interact_times=ts, current_time=ts.max(), num_neighbors=K, time_gap=G)[0].numpy().copy()
     cur = om[0].update_pe(pe=cur, node_ids=bn, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst, node_interact_times=ts,
                           current_time=ts.max(), num_neighbors=K, time_gap=G)
-    st.history = torch.cat([st.history, cur.unsqueeze(1)], dim=1)
+    hist.append(cur)
+    return row0_64
 
 
-def _parity(got, ref32, ref64, atol, tag, max_excused=1e-5):
-    """|got - ref32| <= atol everywhere, EXCEPT where the fp32 oracle's own summation error explains the difference: an element may
-    exceed the bar only if it is no further from the float64 yardstick (``oracle.float64_yardstick``) than the fp32 oracle is, plus the
-    bar.  (The padding row of update_pe sums tens of thousands of fp32 terms; the reference's result there depends on its summation
-    order -- sequential on the CPU, atomics on a GPU.)  ``ref64`` may be a callable (built only when needed).  At most ``max_excused``
-    of the elements may take that exit."""
+def _parity(got, ref32, atol, tag, row0_64=None):
+    """|got - ref32| <= atol for every row of a PE table / window EXCEPT, where needed, the padding row 0.
+
+    Row 0 is ill-conditioned in fp32: update_pe zeroes it and then sets it to tanh(MLP(sum of cat[pe[source], 0] over every padded
+    neighbour slot of the batch)) (models/LSTEP.py:317-339) -- tens of thousands of fp32 terms whose sum, not their size, reaches the
+    hundreds, pushed through a 272-wide MLP.  The reference's own value there depends on its summation order (sequential index_add_
+    on the CPU, atomics on a GPU): against a float64 evaluation of the same update (``oracle.float64_yardstick``) the fp32 oracle is off
+    by up to 2e-2 at the Reddit shape, the HIP path (block-wise partial sums) by 4e-4.  So for row 0 the bar is the fp32 oracle's OWN
+    distance from the float64 value: |hip - f64| <= 2 * max|fp32 oracle - f64| + atol per snapshot (``row0_64`` = float64 row 0, same
+    leading shape as got[0]).  Every other row must meet ``atol`` against the fp32 oracle as it stands."""
     got, ref32 = np.asarray(got, dtype=np.float64), np.asarray(ref32, dtype=np.float64)
     d = np.abs(got - ref32)
-    bad = d > atol
-    if not bad.any():
+    if not (d > atol).any():
         return
-    ref64 = np.asarray(ref64() if callable(ref64) else ref64, dtype=np.float64)
-    to64, slack = np.abs(got - ref64)[bad], np.abs(ref32 - ref64)[bad]
-    where = np.argwhere(bad)
-    ok = to64 <= slack + atol
-    msg = (f"{tag}: {int(bad.sum())} of {bad.size} elements differ from the fp32 oracle by more than {atol} (worst {d.max():.3e} at "
-           f"{where[np.argmax(d[bad])].tolist()}); vs float64: hip {to64.max():.3e}, fp32 oracle {slack.max():.3e}; rows {sorted(set(where[:, 0].tolist()))[:8]}")
-    assert ok.all(), "NOT explained by fp32 summation order -- " + msg
-    assert bad.sum() <= max(1, max_excused * bad.size), "too many -- " + msg
-    warnings.warn("explained by the fp32 oracle's own rounding -- " + msg)
+    rows = np.unique(np.argwhere(d > atol)[:, 0])
+    assert rows.tolist() == [0] and row0_64 is not None, \
+        f"{tag}: rows {rows[:8].tolist()} differ from the fp32 oracle by up to {d.max():.3e} (bar {atol}); only the padding row 0 has a float64 yardstick"
+    f64 = np.asarray(row0_64, dtype=np.float64).reshape(-1, got.shape[-1])
+    hip_err = np.abs(got[0].reshape(f64.shape) - f64).max(axis=1)
+    ref_err = np.abs(ref32[0].reshape(f64.shape) - f64).max(axis=1)
+    worst = int(np.argmax(hip_err - 2 * ref_err))
+    assert (hip_err <= 2 * ref_err + atol).all(), \
+        (f"{tag}: padding row further from float64 than the fp32 oracle's own rounding allows: |hip - f64| = {hip_err[worst]:.3e}, "
+         f"|fp32 oracle - f64| = {ref_err[worst]:.3e} (snapshot {worst})")
+    warnings.warn(f"{tag}: padding row 0 differs from the fp32 oracle by {d[0].max():.3e}; against float64 the HIP path is within "
+                  f"{hip_err.max():.3e}, the fp32 oracle within {ref_err.max():.3e}")
 
 
 def _compare_grads(om, hm, atol, tag):
@@ -118,7 +153,7 @@ def test_engine_protocol_full_slid_window_vs_oracle(hip, name):
     sd = synth.make_state_dict(K, T, seed=seed + 3)
     from oracle.lstep_oracle import float64_yardstick
     om, _ = _oracle(g, node_raw, edge_raw, K, T, sd)
-    o64 = float64_yardstick(om)        # runs the same trajectory in float64: the yardstick of ``_parity``
+    o64 = float64_yardstick(om)        # the float64 yardstick of ``_parity``
     hm = hip.build(node_raw, edge_raw, hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N, device=DEV), K, T, sd, DEV)
     eng = hip.LstepEngine(hm[0], hm[1], K, G)
     assert (eng.ring.mask is None) == (T > 126), "T = 200 must take the mask-less clone ring, T = 100 the change-mask ring"
@@ -126,24 +161,26 @@ def test_engine_protocol_full_slid_window_vs_oracle(hip, name):
     first = E // 2
     assert first + (preroll + trained + 1) * B <= E
 
-    st = protocol.ProtocolState(history=torch.from_numpy(pe0.copy()).unsqueeze(1))
-    st64 = protocol.ProtocolState(history=torch.from_numpy(pe0.copy()).double().unsqueeze(1))
+    hist = _RollingOracleHistory(torch.from_numpy(pe0.copy()), T, preroll)
+    yard0 = [np.zeros(synth.PE_DIM)]                     # float64 padding row of every snapshot (the first one is the given table)
     eng.ring.load(torch.from_numpy(pe0.copy()).unsqueeze(1).to(DEV))
     om.eval(), o64.eval(), hm.eval()
     with torch.no_grad():
         for j in range(preroll):
             lo = first + j * B
             sl = slice(lo, lo + B)
-            for m_, s_ in ((om, st), (o64, st64)):
-                _oracle_state_step(m_, s_, j + 1, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], K, G, T)
+            yard0.append(_oracle_state_step(om, hist, j + 1, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], K, G, o64))
             neg = synth.make_negatives(N, 2 * B, seed=j)
             eng.eval_iteration(j + 1, *stream.batch(lo, lo + B), torch.from_numpy(neg[:B]).to(DEV), torch.from_numpy(neg[B:]).to(DEV))
             if j in (2, T // 2, T - 1, preroll - 1):      # short masked window, half, exactly full, slid
-                _parity(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), st64.history[:, -1, :].numpy(), 5e-5, f"pre-roll batch {j}")
-    assert eng.ring.len == T and st.history.shape[1] >= T
+                _parity(eng.ring.last().cpu().numpy(), hist.window()[:, -1, :].numpy(), 5e-5, f"pre-roll batch {j}", yard0[-1])
+    st = hist.as_state()
+    assert eng.ring.len == T == st.history.shape[1]
     assert eng.ring.start != 0, "the window must have slid"
-    _parity(eng.ring.as_reference_tensor().cpu().numpy(), st.history[:, -T:, :].numpy(), st64.history[:, -T:, :].numpy(), 5e-5, "window after the pre-roll")
+    _parity(eng.ring.as_reference_tensor().cpu().numpy(), st.history.numpy(), 5e-5, "window after the pre-roll", np.stack(yard0[-T:]))
 
+    # training iterations: the float64 yardstick runs the same protocol from the fp32 oracle's state (same weights: the pre-roll trains nothing)
+    st64 = protocol.ProtocolState(history=st.history.double())
     om.train(), o64.train(), hm.train()
     oo, oo64, ho = torch.optim.Adam(om.parameters(), lr=1e-4), torch.optim.Adam(o64.parameters(), lr=1e-4), FusedAdam(hm.parameters(), lr=1e-4)
     for b in range(trained):
@@ -153,15 +190,14 @@ def test_engine_protocol_full_slid_window_vs_oracle(hip, name):
         neg = synth.make_negatives(N, B, seed=5000 + b)
         args = (j + 1, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], neg, K, G, T)
         ro = protocol.train_iteration(om[0], om[1], oo, st, *args)
-        r64 = protocol.train_iteration(o64[0], o64[1], oo64, st64, *args)
+        protocol.train_iteration(o64[0], o64[1], oo64, st64, *args)
         nxt = stream.batch(lo + B, lo + 2 * B)[:2] if b % 2 == 0 else None       # with and without the look-ahead grouping
         rh = eng.train_iteration(ho, j + 1, *stream.batch(lo, lo + B), torch.from_numpy(neg).to(DEV), lookahead=nxt)
-        _parity(rh["predicts"].cpu().numpy(), ro["predicts"], r64["predicts"], 5e-5, f"train batch {b}: link probabilities")
+        np.testing.assert_allclose(rh["predicts"].cpu().numpy(), ro["predicts"], err_msg=f"train batch {b}", **TOL)
         np.testing.assert_allclose([float(rh["lp_loss"]), float(rh["pe_loss"]), float(rh["loss"])], [ro["lp_loss"], ro["pe_loss"], ro["loss"]],
                                    rtol=0, atol=2e-5)
-        _parity(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), st64.history[:, -1, :].numpy(), 5e-5, f"train batch {b}: snapshot")
+        _parity(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), 5e-5, f"train batch {b}: snapshot", st64.history[0, -1, :].numpy())
         _compare_grads(om, hm, 3e-5, f"train batch {b}")
-    _parity(eng.ring.as_reference_tensor().cpu().numpy(), st.history[:, -T:, :].numpy(), st64.history[:, -T:, :].numpy(), 5e-5, "final window")
 
 
 # ------------------------------------------------------------------------------------------------ c3
@@ -215,9 +251,9 @@ def test_c3_reddit_shape_rows_update_and_gradients_vs_oracle(hip, G):
         assert len(bn) > B, "U > B: rows past B stay padding in phase 2 (zip quirk, models/LSTEP.py:306-308)"
         ref_t = om[0].update_pe(torch.from_numpy(pe_np.copy()), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).numpy()
         got_t = hm[0].update_pe(torch.from_numpy(pe_np.copy()).to(DEV), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).cpu().numpy()
-        f64 = lambda: float64_yardstick(om, tables=False)[0].update_pe(torch.from_numpy(pe_np.copy()).double(), bn, eid, src, dst, t, t.max(),  # noqa: E731
-                                                                        num_neighbors=K, time_gap=G).numpy()
-        _parity(got_t, ref_t, f64, 5e-5, f"c3 update_pe G={G}")
+        f64 = float64_yardstick(om, tables=False)[0].update_pe(torch.from_numpy(pe_np.copy()).double(), bn, eid, src, dst, t, t.max(),
+                                                               num_neighbors=K, time_gap=G)[0].numpy()
+        _parity(got_t, ref_t, 5e-5, f"c3 update_pe G={G}", f64)
     assert float(np.abs(got_t - pe_np).max(axis=1).astype(bool).mean()) > 0.5, "most of the table must have been touched"
 
 
@@ -326,7 +362,7 @@ def test_c4_bench_workload_vs_oracle(hip, monkeypatch):
         ref_t = om[0].update_pe(pe_cpu.clone(), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).numpy()
         got_t = hm[0].update_pe(pe_dev.clone(), torch.from_numpy(bn).to(DEV), torch.from_numpy(eid).to(DEV), torch.from_numpy(src).to(DEV),
                                 torch.from_numpy(dst).to(DEV), torch.from_numpy(t).to(DEV), float(t.max()), num_neighbors=K, time_gap=G).cpu().numpy()
-    f64 = lambda: float64_yardstick(om, tables=False)[0].update_pe(pe_cpu.double(), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G).numpy()  # noqa: E731
-    _parity(got_t, ref_t, f64, 5e-5, "c4 update_pe")
+        f64 = float64_yardstick(om, tables=False)[0].update_pe(pe_cpu.double(), bn, eid, src, dst, t, t.max(), num_neighbors=K, time_gap=G)[0].numpy()
+    _parity(got_t, ref_t, 5e-5, "c4 update_pe", f64)
     changed = float((np.abs(got_t - pe_cpu.numpy()).max(axis=1) > 0).mean())
     assert 0.1 < changed < 0.6, f"update_pe should touch roughly a quarter of the table at this shape, got {changed:.2f}"
