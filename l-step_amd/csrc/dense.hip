@@ -9,6 +9,8 @@
 // global memory straight into the MFMA operand registers -- both are row-major with the reduction index r as the row, which is
 // exactly the A[i][k] / B[k][j] lane layout of the 16x16x4 form (lane l: k = l >> 4, i or j = l & 15), so there is no LDS stage
 // and no transpose anywhere.  A second small kernel adds the per-workgroup partials (deterministic, no atomics).
+#include <stdlib.h>
+
 #include "lstep_common.h"
 
 namespace lstep {
@@ -125,18 +127,193 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const WgradPar
     }
 }
 
-// out = sum over the S partial blocks; 64 float4 columns x 4 partial groups per workgroup
+// ---- The same product with 16-byte operand loads wherever a wave's slice holds whole 64-column groups.
+// The 16x16x4 form wants, per lane (c = l & 15, kk = l >> 4), ONE element A[i = c][k = kk] = dY[r + kk][column of tile row c].  Nothing says
+// the 16 tile rows must be 16 CONSECUTIVE columns: lane c loads the float4 dY[r + kk][n0 + 4c .. 4c + 3], and component v of all lanes is
+// the A operand of the tile whose row i is column n0 + 4i + v -- a 64-column group is four interleaved tiles fed by one
+// global_load_dwordx4 (16 lanes = 256 contiguous bytes of a row) instead of four global_load_dword (4 x 64 bytes).  The same for X.
+// What that buys is depth: a wave tracks at most 63 vector-memory instructions in flight (vmcnt), and the dword pipeline above spends 16
+// of them per 4-row step.  Here a step costs 5-8 load instructions, so two blocks of 4 steps fit (see the loop below).
+// Slices that are not a multiple of 64 columns keep dword loads for their last 1-3 tiles (NR / KR), so no tile slot is wasted.
+template <int NG, int NR, int KG, int KR, int DEPTH>
+__global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const WgradParams p) {
+    constexpr int NT = 4 * NG + NR, KTW = 4 * KG + KR;
+    struct Operands { f32x4 a4[NG > 0 ? NG : 1]; float a1[NR > 0 ? NR : 1]; f32x4 b4[KG > 0 ? KG : 1]; float b1[KR > 0 ? KR : 1]; };
+
+    const int lane = lane_id(), wave = wave_in_block();
+    const int kk = lane >> 4, c = lane & 15;
+    const int n0 = blockIdx.z * (NT * 16);
+    const int k0 = (blockIdx.y * kWavesPerBlock + wave) * (KTW * 16);
+    if (k0 >= p.k) return;  // no barriers in this kernel
+    const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_wg;
+    int64_t r_end = r_begin + p.rows_per_wg;
+    if (r_end > p.m) r_end = p.m;
+
+    // columns, clamped into the matrix (n and k are multiples of 4 here): lanes / tiles past the edge read valid memory and produce
+    // values that are never stored
+    int colA4[NG > 0 ? NG : 1], colA1[NR > 0 ? NR : 1], colB4[KG > 0 ? KG : 1], colB1[KR > 0 ? KR : 1];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) colA4[g] = min(n0 + 64 * g + 4 * c, p.n - 4);
+#pragma unroll
+    for (int t = 0; t < NR; ++t) colA1[t] = min(n0 + 64 * NG + 16 * t + c, p.n - 1);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) colB4[g] = min(k0 + 64 * g + 4 * c, p.k - 4);
+#pragma unroll
+    for (int t = 0; t < KR; ++t) colB1[t] = min(k0 + 64 * KG + 16 * t + c, p.k - 1);
+
+    auto issue = [&](Operands& o, int64_t r) {
+        int64_t row = r + kk;
+        if (row > r_end - 1) row = r_end - 1;
+        const float* ra = p.dy + row * p.ldy;
+        const float* rb = p.x + row * p.ldx;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) o.a4[g] = *reinterpret_cast<const f32x4*>(ra + colA4[g]);
+#pragma unroll
+        for (int t = 0; t < NR; ++t) o.a1[t] = ra[colA1[t]];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) o.b4[g] = *reinterpret_cast<const f32x4*>(rb + colB4[g]);
+#pragma unroll
+        for (int t = 0; t < KR; ++t) o.b1[t] = rb[colB1[t]];
+    };
+
+    f32x4 acc[NT][KTW];
+    f32x4 bsum4[NG > 0 ? NG : 1];
+    float bsum1[NR > 0 ? NR : 1];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int b = 0; b < KTW; ++b) {
+            acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(acc[a][b]));   // one distinct accumulator tile each
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bsum4[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NR; ++t) bsum1[t] = 0.f;
+
+    // all products of one A element: tile row `a` against this wave's KTW tiles
+    auto row_of_tiles = [&](int a, float va, const Operands& o) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[a][4 * g + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(va, o.b4[g][v], acc[a][4 * g + v], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < KR; ++t) acc[a][4 * KG + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(va, o.b1[t], acc[a][4 * KG + t], 0, 0, 0);
+    };
+
+    // Two blocks of DEPTH steps, ping-pong: while block i is multiplied, the loads of block i + 1 are in flight, issued a whole block
+    // (DEPTH * NT * KTW MFMAs = 7 000-10 000 cycles) before their first use.  (A ring that issues step s + DEPTH - 1 next to the MFMAs of
+    // step s looks deeper but is not: at the loop header hipcc's wait-count pass forgets which loads of the previous trip are still in
+    // flight and waits for all of them -- `s_waitcnt vmcnt(<loads of this trip so far>)` -- so the pipeline drains once per trip; the
+    // dword kernel above has that shape.  Here "everything issued before this trip" is exactly what the first MFMA of a trip needs.)
+    const int64_t steps = (r_end - r_begin + 3) >> 2;
+    Operands buf[2][DEPTH];
+    auto issue_block = [&](Operands (&blk)[DEPTH], int64_t s) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(blk[d], r_begin + 4 * (s + d));
+    };
+    auto multiply_block = [&](const Operands (&blk)[DEPTH], int64_t s) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const bool live = r_begin + 4 * (s + d) + kk < r_end;   // dead rows: zero dY operand, the products vanish
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                f32x4 va = blk[d].a4[g];
+                if (!live) va = f32x4{0.f, 0.f, 0.f, 0.f};
+                bsum4[g] += va;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) row_of_tiles(4 * g + v, va[v], blk[d]);
+            }
+#pragma unroll
+            for (int t = 0; t < NR; ++t) {
+                const float va = live ? blk[d].a1[t] : 0.f;
+                bsum1[t] += va;
+                row_of_tiles(4 * NG + t, va, blk[d]);
+            }
+        }
+    };
+    issue_block(buf[0], 0);
+    for (int64_t s = 0; s < steps; s += 2 * DEPTH) {   // (rows past the slice are clamped loads and zero operands)
+        issue_block(buf[1], s + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply_block(buf[0], s);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_block(buf[0], s + 2 * DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply_block(buf[1], s + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // C/D layout of the 16x16 forms: lane l, register q -> tile row 4 * (l >> 4) + q, tile column l & 15.  Tile rows / columns of a
+    // 64-column group are the columns base + 4 * index + v: the four tiles v = 0..3 of a k-group hold four consecutive columns per
+    // lane, stored as one float4.
+    float* out = p.part + (int64_t)blockIdx.x * p.part_stride;
+    auto store_row = [&](int a, int q, int n) {
+        if (n >= p.n) return;
+        float* dst = out + (int64_t)n * p.k;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            const int k = k0 + 64 * g + 4 * c;
+            if (k < p.k) *reinterpret_cast<f32x4*>(dst + k) = f32x4{acc[a][4 * g][q], acc[a][4 * g + 1][q], acc[a][4 * g + 2][q], acc[a][4 * g + 3][q]};
+        }
+#pragma unroll
+        for (int t = 0; t < KR; ++t) {
+            const int k = k0 + 64 * KG + 16 * t + c;
+            if (k < p.k) dst[k] = acc[a][4 * KG + t][q];
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store_row(4 * g + v, q, n0 + 64 * g + 4 * (4 * kk + q) + v);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_row(4 * NG + t, q, n0 + 64 * NG + 16 * t + 4 * kk + q);
+    }
+    if (blockIdx.y == 0 && wave == 0) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 t = bsum4[g];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                t[v] += __shfl_xor(t[v], 16, kWave);
+                t[v] += __shfl_xor(t[v], 32, kWave);
+            }
+            const int n = n0 + 64 * g + 4 * c;
+            if (kk == 0 && n < p.n) *reinterpret_cast<f32x4*>(out + p.bias_off + n) = t;
+        }
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+            float u = bsum1[t];
+            u += __shfl_xor(u, 16, kWave);
+            u += __shfl_xor(u, 32, kWave);
+            const int n = n0 + 64 * NG + 16 * t + c;
+            if (kk == 0 && n < p.n) out[p.bias_off + n] = u;
+        }
+    }
+}
+
+// out = sum over the S partial blocks: 16 float4 columns x 16 partial groups per workgroup (every thread has S / 16 independent
+// 16-byte loads in flight; the first version gave each thread S / 4 and launched a quarter of the workgroups, 33 us per call for 48 MB
+// that sit in the Infinity Cache), groups added in a fixed order: deterministic
 __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t part_stride, int32_t num_part, int32_t n,
                                                               int32_t k, int32_t bias_off, float* __restrict__ dw, int32_t ld_dw,
                                                               float* __restrict__ db) {
     __shared__ float4 sh[kBlock];
-    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int64_t e = ((int64_t)blockIdx.x * 64 + col) * 4;
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t e = ((int64_t)blockIdx.x * 16 + col) * 4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < part_stride) {
         const float* src = part + e;
 #pragma unroll 8
-        for (int s = grp; s < num_part; s += 4) {
+        for (int s = grp; s < num_part; s += 16) {
             const float4 v = ld4_stream(src + (int64_t)s * part_stride);
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
         }
@@ -145,8 +322,8 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __res
     __syncthreads();
     if (grp != 0 || e >= part_stride) return;
 #pragma unroll
-    for (int g = 1; g < 4; ++g) {
-        const float4 v = sh[g * 64 + col];
+    for (int g = 1; g < 16; ++g) {
+        const float4 v = sh[g * 16 + col];
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     }
     const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
@@ -214,11 +391,20 @@ extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, 
     p.m = m; p.rows_per_wg = pl.rows_per_wg; p.part_stride = pl.part_stride;
     p.ldy = ldy; p.ldx = ldx; p.n = n; p.k = k; p.bias_off = pl.bias_off;
     const dim3 grid((unsigned)pl.splits, (unsigned)pl.gy, (unsigned)pl.gz), block(kBlock);
-    if (pl.nt == 11 && pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_kernel<11, 5, 4>), grid, block, 0, s, p);
+    // 16-byte operand loads need 16-byte aligned rows and whole float4s inside the matrices; anything else takes the dword kernel
+    static const bool no_wide = getenv("LSTEP_WGRAD_DWORD") != nullptr;      // A/B switch (tools/wgrad_bench.py)
+    const bool wide = !no_wide && n % 4 == 0 && k % 4 == 0 && n >= 4 && k >= 4 && ldy % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dy & 15) == 0 &&
+                      ((uintptr_t)x & 15) == 0;
+    if (wide) {
+        if (pl.nt == 11 && pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_v2_kernel<2, 3, 1, 1, 4>), grid, block, 0, s, p);
+        else if (pl.nt == 11) hipLaunchKernelGGL((wgrad_partial_v2_kernel<2, 3, 0, 3, 4>), grid, block, 0, s, p);
+        else if (pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_v2_kernel<2, 1, 1, 1, 4>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((wgrad_partial_v2_kernel<2, 1, 0, 3, 4>), grid, block, 0, s, p);
+    } else if (pl.nt == 11 && pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_kernel<11, 5, 4>), grid, block, 0, s, p);
     else if (pl.nt == 11) hipLaunchKernelGGL((wgrad_partial_kernel<11, 3, 4>), grid, block, 0, s, p);
     else if (pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_kernel<9, 5, 4>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((wgrad_partial_kernel<9, 3, 4>), grid, block, 0, s, p);
-    const unsigned rgrid = (unsigned)((pl.part_stride / 4 + 63) / 64);
+    const unsigned rgrid = (unsigned)((pl.part_stride / 4 + 15) / 16);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), block, 0, s, (const float*)workspace, pl.part_stride, (int32_t)pl.splits, n, k,
                        pl.bias_off, dw, ld_dw, db);
     return check_launch("lstep_linear_wgrad");
@@ -226,7 +412,7 @@ extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, 
 
 // ---- small dense products between weight-sized matrices (<= a few hundred rows / columns): the weight composition of the dense
 // tail and its backward (model._TailWeights).  The library runs these 8 - 25 MFLOP products as ONE workgroup (53 - 60 us each); here
-// every 16 x 16 output tile is its own wave on the fp32 matrix cores.  General element strides, so transposes are free.
+// every 16 x 16 output tile is its own workgroup on the fp32 matrix cores.  General element strides, so transposes are free.
 namespace lstep {
 
 struct SmallGemmParams {
@@ -237,38 +423,54 @@ struct SmallGemmParams {
     float alpha, beta;
 };
 
+// One WORKGROUP per 16 x 16 output tile: its four waves split the contraction (whole 4-wide MFMA steps), each issues all its operand
+// loads at once and runs two independent accumulator chains (the 16x16x4 form has a 40-cycle dependent latency), the four partial
+// tiles meet in LDS and are added in a fixed order.  (One WAVE per tile ran the 43-68 steps of these products as one dependent chain
+// behind 6-9 rounds of exposed load latency: ~30 us per product, 0.27 ms per training iteration on the auxiliary stream.)
 __global__ __launch_bounds__(kBlock) void small_gemm_kernel(const SmallGemmParams p) {
-    const int lane = lane_id();
+    __shared__ float red[kWavesPerBlock][4][kWave];
+    const int lane = lane_id(), wave = wave_in_block();
     const int tiles_n = (p.n + 15) / 16;
-    const int tile = blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (tile >= tiles_n * ((p.m + 15) / 16)) return;
+    const int tile = blockIdx.x;
     const int i0 = (tile / tiles_n) * 16, j0 = (tile % tiles_n) * 16;
     const int r = lane & 15, q = lane >> 4;
     const int ai = min(i0 + r, p.m - 1), bj = min(j0 + r, p.n - 1);   // clamped: out-of-range rows / columns are computed and dropped
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int kSteps = 8;     // 8 k-steps (32 k values) of operands in flight: the loop is latency-bound otherwise
+    const int steps_total = (p.k + 3) / 4;
+    const int per = (steps_total + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int s_begin = wave * per;
+    const int s_end = min(s_begin + per, steps_total);
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kSteps = 24;    // one round covers contractions up to 4 * 4 * 24 = 384
     const float* pa = p.a + ai * p.sa_i;
     const float* pb = p.b + bj * p.sb_j;
-    for (int k0 = 0; k0 < p.k; k0 += 4 * kSteps) {
+    for (int s0 = s_begin; s0 < s_end; s0 += kSteps) {
         float av[kSteps], bv[kSteps];
 #pragma unroll
         for (int u = 0; u < kSteps; ++u) {
-            const int kk = k0 + 4 * u + q;
-            const bool ok = kk < p.k;
-            const int kc = ok ? kk : p.k - 1;
+            const int kk = 4 * (s0 + u) + q;
+            const bool ok = s0 + u < s_end && kk < p.k;
+            const int kc = ok ? kk : 0;
             av[u] = pa[kc * p.sa_k];
             bv[u] = pb[kc * p.sb_k];
             if (!ok) av[u] = 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < kSteps; u += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
+        }
     }
 #pragma unroll
+    for (int v = 0; v < 4; ++v) red[wave][v][lane] = acc0[v] + acc1[v];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
     for (int v = 0; v < 4; ++v) {
+        const float sum = ((red[0][v][lane] + red[1][v][lane]) + red[2][v][lane]) + red[3][v][lane];
         const int i = i0 + 4 * q + v, j = j0 + r;
         if (i < p.m && j < p.n) {
             float* dst = p.c + i * p.sc_i + j * p.sc_j;
-            *dst = p.beta == 0.f ? p.alpha * acc[v] : p.alpha * acc[v] + p.beta * *dst;
+            *dst = p.beta == 0.f ? p.alpha * sum : p.alpha * sum + p.beta * *dst;
         }
     }
 }
@@ -283,6 +485,6 @@ extern "C" int lstep_small_gemm(const float* a, int64_t sa_i, int64_t sa_k, cons
     if (k == 0) return set_error(LSTEP_EINVAL, "lstep_small_gemm: empty contraction");
     SmallGemmParams p{a, b, c, m, n, k, sa_i, sa_k, sb_k, sb_j, sc_i, sc_j, alpha, beta};
     const int tiles = ((m + 15) / 16) * ((n + 15) / 16);
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, (hipStream_t)stream, p);
     return check_launch("lstep_small_gemm");
 }

@@ -89,7 +89,7 @@ def _oracle_state_step(om, hist, batch_idx, src, dst, ts, eid, K, G, o64=None):
     return row0_64
 
 
-def _parity(got, ref32, atol, tag, row0_64=None):
+def _parity(got, ref32, atol, tag, row0_64=None, scale=None):
     """|got - ref32| <= atol for every row of a PE table / window EXCEPT, where needed, the padding row 0.
 
     Row 0 is ill-conditioned in fp32: update_pe zeroes it and then sets it to tanh(MLP(sum of cat[pe[source], 0] over every padded
@@ -97,8 +97,10 @@ def _parity(got, ref32, atol, tag, row0_64=None):
     hundreds, pushed through a 272-wide MLP.  The reference's own value there depends on its summation order (sequential index_add_
     on the CPU, atomics on a GPU): against a float64 evaluation of the same update (``oracle.float64_yardstick``) the fp32 oracle is off
     by up to 2e-2 at the Reddit shape, the HIP path (block-wise partial sums) by 4e-4.  So for row 0 the bar is the fp32 oracle's OWN
-    distance from the float64 value: |hip - f64| <= 2 * max|fp32 oracle - f64| + atol per snapshot (``row0_64`` = float64 row 0, same
-    leading shape as got[0]).  Every other row must meet ``atol`` against the fp32 oracle as it stands."""
+    distance from the float64 value: |hip - f64| <= 2 * max|fp32 oracle - f64| + atol, the maximum taken over the snapshots compared
+    (``row0_64`` = float64 row 0, same leading shape as got[0]) and over every earlier comparison of the same test (``scale``, a dict
+    carried by the caller: which of two fp32 evaluations lands closer on ONE snapshot is luck, the size of the error is not).
+    Every other row must meet ``atol`` against the fp32 oracle as it stands."""
     got, ref32 = np.asarray(got, dtype=np.float64), np.asarray(ref32, dtype=np.float64)
     d = np.abs(got - ref32)
     if not (d > atol).any():
@@ -109,10 +111,13 @@ def _parity(got, ref32, atol, tag, row0_64=None):
     f64 = np.asarray(row0_64, dtype=np.float64).reshape(-1, got.shape[-1])
     hip_err = np.abs(got[0].reshape(f64.shape) - f64).max(axis=1)
     ref_err = np.abs(ref32[0].reshape(f64.shape) - f64).max(axis=1)
-    worst = int(np.argmax(hip_err - 2 * ref_err))
-    assert (hip_err <= 2 * ref_err + atol).all(), \
-        (f"{tag}: padding row further from float64 than the fp32 oracle's own rounding allows: |hip - f64| = {hip_err[worst]:.3e}, "
-         f"|fp32 oracle - f64| = {ref_err[worst]:.3e} (snapshot {worst})")
+    bound = float(ref_err.max())
+    if scale is not None:
+        bound = scale["ref_err"] = max(bound, scale.get("ref_err", 0.0))
+    worst = int(np.argmax(hip_err))
+    assert hip_err[worst] <= 2 * bound + atol, \
+        (f"{tag}: padding row further from float64 than the fp32 oracle's own rounding allows: |hip - f64| = {hip_err[worst]:.3e} "
+         f"(snapshot {worst}), max |fp32 oracle - f64| = {bound:.3e}")
     warnings.warn(f"{tag}: padding row 0 differs from the fp32 oracle by {d[0].max():.3e}; against float64 the HIP path is within "
                   f"{hip_err.max():.3e}, the fp32 oracle within {ref_err.max():.3e}")
 
@@ -163,6 +168,7 @@ def test_engine_protocol_full_slid_window_vs_oracle(hip, name):
 
     hist = _RollingOracleHistory(torch.from_numpy(pe0.copy()), T, preroll)
     yard0 = [np.zeros(synth.PE_DIM)]                     # float64 padding row of every snapshot (the first one is the given table)
+    scale = {}                                           # largest fp32-oracle error of the padding row seen so far (``_parity``)
     eng.ring.load(torch.from_numpy(pe0.copy()).unsqueeze(1).to(DEV))
     om.eval(), o64.eval(), hm.eval()
     with torch.no_grad():
@@ -173,11 +179,11 @@ def test_engine_protocol_full_slid_window_vs_oracle(hip, name):
             neg = synth.make_negatives(N, 2 * B, seed=j)
             eng.eval_iteration(j + 1, *stream.batch(lo, lo + B), torch.from_numpy(neg[:B]).to(DEV), torch.from_numpy(neg[B:]).to(DEV))
             if j in (2, T // 2, T - 1, preroll - 1):      # short masked window, half, exactly full, slid
-                _parity(eng.ring.last().cpu().numpy(), hist.window()[:, -1, :].numpy(), 5e-5, f"pre-roll batch {j}", yard0[-1])
+                _parity(eng.ring.last().cpu().numpy(), hist.window()[:, -1, :].numpy(), 5e-5, f"pre-roll batch {j}", yard0[-1], scale)
     st = hist.as_state()
     assert eng.ring.len == T == st.history.shape[1]
     assert eng.ring.start != 0, "the window must have slid"
-    _parity(eng.ring.as_reference_tensor().cpu().numpy(), st.history.numpy(), 5e-5, "window after the pre-roll", np.stack(yard0[-T:]))
+    _parity(eng.ring.as_reference_tensor().cpu().numpy(), st.history.numpy(), 5e-5, "window after the pre-roll", np.stack(yard0[-T:]), scale)
 
     # training iterations: the float64 yardstick runs the same protocol from the fp32 oracle's state (same weights: the pre-roll trains nothing)
     st64 = protocol.ProtocolState(history=st.history.double())
@@ -196,7 +202,7 @@ def test_engine_protocol_full_slid_window_vs_oracle(hip, name):
         np.testing.assert_allclose(rh["predicts"].cpu().numpy(), ro["predicts"], err_msg=f"train batch {b}", **TOL)
         np.testing.assert_allclose([float(rh["lp_loss"]), float(rh["pe_loss"]), float(rh["loss"])], [ro["lp_loss"], ro["pe_loss"], ro["loss"]],
                                    rtol=0, atol=2e-5)
-        _parity(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), 5e-5, f"train batch {b}: snapshot", st64.history[0, -1, :].numpy())
+        _parity(eng.ring.last().cpu().numpy(), st.history[:, -1, :].numpy(), 5e-5, f"train batch {b}: snapshot", st64.history[0, -1, :].numpy(), scale)
         _compare_grads(om, hm, 3e-5, f"train batch {b}")
 
 
