@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 21
+#define LSTEP_ABI_VERSION 22
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -148,7 +148,9 @@ int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe_dim);
 int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                   int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                   const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out,
-                                  float* table_out, int32_t* slot_of, void* stream);
+                                  float* table_out, int32_t* slot_of, const int32_t* num_live, void* stream);
+/* num_live (optional, device): node_ids is a capacity-sized list and only its first min(*num_live, num_ids) entries are batch nodes
+ * (the batch-node count of train_LSTEP_link_prediction.py:221-222 stays on the device: no host round trip before the FFT splice). */
 /* (table_out, slot_of: optional.  table_out [num_rows, node_stride] also receives out[u] at row node_ids[u] -- the splice
  * positional_encoding[:, -1][batch nodes] = filtered rows of train_LSTEP_link_prediction.py:230 -- and slot_of[node_ids[u]] = u.) */
 /* out_partial [lstep_history_filter_bwd_chunks(num_ids), t_len, P] holds per-chunk DIFFERENCE sums; the caller adds them over dim 0 and
@@ -179,7 +181,9 @@ int lstep_history_filter_runs_finish(const float* partial_sum, int32_t t_len, in
  *   torch_scatter targets;  gather backward: table = grad of the PE aggregate, D = 0, segment = spliced PE row. */
 int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
                            int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
-                           int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, void* stream);
+                           int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, const int32_t* num_live, void* stream);
+/* num_live (optional, device): only the first min(*num_live, num_entries) entries count (a capacity-sized entry list whose length
+ * lstep_group_by_key left on the device). */
 
 /* In-place row write pe[ids[i], :] = rows[i, :] (models/LSTEP.py:303,339). ids must be unique. */
 int lstep_scatter_rows(float* table, int32_t width, const int64_t* ids, int64_t num_ids, const float* rows,
@@ -296,7 +300,22 @@ int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float
  * w1 [176, 272], w2 / ws [176, 176], biases [176].  mirror (optional): a second [rows, pe_dim] table that receives the new rows as well
  * -- the batch's history slot, so that appending the snapshot (train_link_prediction.py:301) costs no separate copy. */
 int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
-                      const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim, void* stream);
+                      const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim, const int32_t* num_live,
+                      void* stream);
+/* num_live (optional, device): only the first min(*num_live, n) rows are updated; n is then the capacity the launch covers. */
+
+/* Device-resident counts for the engine's update_pe (no host synchronisation anywhere in models/LSTEP.py:268-340):
+ *   lstep_widen_ids             out[i] = i < *count ? ids32[i] : 0 -- lstep_group_by_key's distinct keys as an int64 id list of fixed
+ *                               capacity whose dead tail is the padding node 0 (no history, no neighbours).
+ *   lstep_update_entries_p2_dev lstep_update_entries_p2 with n_real / nseg read from lstep_group_by_key's device summary and the
+ *                               row-0 decision (models/LSTEP.py:324: 0 is among the unique neighbour ids iff a slot of a live row is
+ *                               padding) taken on the device: segment 0 is always reserved for row 0, touched = [0, uniq..., 0 ...],
+ *                               counts_out = {nseg, row-0 flag}. */
+int lstep_widen_ids(const int32_t* ids32, int64_t capacity, const int32_t* count, int64_t* out, void* stream);
+int lstep_update_entries_p2_dev(const int32_t* order, const int32_t* seg, const int32_t* summary, const int32_t* live_rows, int64_t capacity,
+                                int64_t touched_capacity, const int64_t* bn, const float* nt, const float* now32, int32_t num_neighbors,
+                                const int32_t* uniq, int32_t* ent_row, float* ent_dt, int32_t* ent_seg, int64_t* touched, int32_t* counts_out,
+                                void* stream);
 
 /* out[slot[i], :width] += rows[i, :width] for every i with slot[i] >= 0 (float atomics).  The stragglers of the spliced-row gradient:
  * negative-sample rows whose own node happens to be a batch node (a few hundred per batch; everything else goes through the sorted,

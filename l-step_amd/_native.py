@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 21
+ABI_VERSION = 22
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -63,7 +63,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 _LIB = None
 
-# name -> (restype, argtypes); must list every symbol of include/lstep_hip.h (tests/test_abi.py checks this)
+# name -> (restype, argtypes); must list every symbol of include/lstep_hip.h (tests/test_host_cpu.py::test_abi_exports_every_declared_symbol)
 _P, _I32, _I64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
 SIGNATURES = {
     "lstep_abi_version": (C.c_int, []),
@@ -80,12 +80,12 @@ SIGNATURES = {
     "lstep_history_slot_bits": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P]),
     "lstep_history_mark": (C.c_int, [_P, _I32, _I64, _I32, _P, _I64, _I32, _I32, _P]),
     "lstep_history_filter_runs_workspace": (_I64, [_I32, _I32]),
-    "lstep_history_filter_runs_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
+    "lstep_history_filter_runs_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_history_filter_runs_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, _P]),
     "lstep_copy_rows": (C.c_int, [_P, _P, _I32, _I64, _P, _I64, _I64, _P]),
     "lstep_history_advance_oldest": (C.c_int, [_P, _P, _I32, _I64, _P, _I32, _I32, _I64, _P]),
     "lstep_history_filter_runs_finish": (C.c_int, [_P, _I32, _I32, _P, _P]),
-    "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _I32, _P]),
+    "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _I32, _P, _P]),
     "lstep_sort_live_bounded_workspace": (_I64, [_I64, _I64, _I32]),
     "lstep_sort_live_bounded": (C.c_int, [_P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_segment_rows_sum_live": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _P, _I32, _I32, _P]),
@@ -102,7 +102,9 @@ SIGNATURES = {
     "lstep_update_entries_p1": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "lstep_update_keys_p2": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "lstep_update_entries_p2": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _I64, _P, _P, _P, _P, _P]),
-    "lstep_update_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "lstep_update_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P]),
+    "lstep_widen_ids": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "lstep_update_entries_p2_dev": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_fwd": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_bwd": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_link_loss_workspace": (_I64, [_I64]),
@@ -291,7 +293,8 @@ class PendingCounts:
 
 def group_by_key(keys, key_bits: int, limit: int, wait: bool = True):
     """``lstep_group_by_key`` on an int32 device tensor.  Returns (sorted_keys, order, seg, uniq, (n_unique, n_below, n_unique_below));
-    the three counts cost one host sync (``wait=False``: a ``PendingCounts`` instead, read later with ``.get()``).
+    the three counts cost one host sync (``wait=False``: a ``PendingCounts`` instead, read later with ``.get()``; ``wait=None``: the
+    device tensor ``summary`` int32 [3] itself, for consumers that read counts on the device).
     The scratch buffer is cached per device and grown on demand."""
     import torch
 
@@ -308,4 +311,6 @@ def group_by_key(keys, key_bits: int, limit: int, wait: bool = True):
     with torch.cuda.device(dev):
         check(lib.lstep_group_by_key(ptr(keys), n, int(key_bits), int(limit), ptr(ws), ws.numel(), ptr(sorted_keys), ptr(order), ptr(seg),
                                      ptr(uniq), ptr(summary), current_stream()))
+    if wait is None:       # counts stay on the device: the int32 [3] tensor itself
+        return sorted_keys, order, seg, uniq, summary
     return sorted_keys, order, seg, uniq, (summary.tolist() if wait else PendingCounts(summary))

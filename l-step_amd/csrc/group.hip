@@ -33,6 +33,14 @@ __global__ void unique_kernel(const int32_t* __restrict__ sk, const int32_t* __r
     }
 }
 
+// out[i] = i < *count ? (int64) ids32[i] : 0 -- a capacity-sized id list whose dead tail is the padding node 0 (no history, no
+// neighbours: every consumer that only READS per-id state treats it as a no-op)
+__global__ void widen_ids_kernel(const int32_t* __restrict__ ids32, int64_t capacity, const int32_t* __restrict__ count, int64_t* __restrict__ out) {
+    const int64_t n = *count;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = i < n ? (int64_t)ids32[i] : 0;
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Stable LSD radix sort of (key, value) pairs on the low `bits` key bits.  The library's default switches to a merge sort below
@@ -121,6 +129,15 @@ extern "C" int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bi
         return set_error(LSTEP_EHIP, "lstep_group_by_key: scan failed");
     hipLaunchKernelGGL(unique_kernel, dim3(grid), dim3(256), 0, s, sorted_keys, seg, n, limit, uniq, summary);
     return check_launch("lstep_group_by_key");
+}
+
+extern "C" int lstep_widen_ids(const int32_t* ids32, int64_t capacity, const int32_t* count, int64_t* out, void* stream) {
+    if (capacity < 0) return set_error(LSTEP_EINVAL, "lstep_widen_ids: negative capacity");
+    if (capacity == 0) return LSTEP_OK;
+    if (!ids32 || !count || !out) return set_error(LSTEP_EINVAL, "lstep_widen_ids: NULL pointer");
+    const unsigned grid = (unsigned)((capacity + 255) / 256 < 1024 ? (capacity + 255) / 256 : 1024);
+    hipLaunchKernelGGL(widen_ids_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids32, capacity, count, out);
+    return check_launch("widen_ids_kernel");
 }
 
 // ---- "sort the live entries": keys < 0 are dropped BEFORE the sort.  The gradient hits of the gather backward are ~95 % dead

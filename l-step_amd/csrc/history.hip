@@ -179,8 +179,12 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fw
                                                                                          int words, const int64_t* __restrict__ ids, int64_t num_ids,
                                                                                          const float* __restrict__ coef, const double* __restrict__ cpre,
                                                                                          float* __restrict__ out, float* __restrict__ table_out,
-                                                                                         int32_t* __restrict__ slot_of) {
+                                                                                         int32_t* __restrict__ slot_of, const int32_t* __restrict__ num_live) {
     extern __shared__ double cpre_lds[];
+    if (num_live) {      // ids is a capacity-sized list: only its first min(*num_live, num_ids) entries are nodes of this batch
+        const int64_t live = *num_live;
+        if (live < num_ids) num_ids = live;
+    }
     const int lane = lane_id();
     const int waves_per_block = (int)(blockDim.x >> 6);
     if (IN_LDS) {
@@ -469,7 +473,7 @@ extern "C" int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe
 extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                              int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                              const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out,
-                                             float* table_out, int32_t* slot_of, void* stream) {
+                                             float* table_out, int32_t* slot_of, const int32_t* num_live, void* stream) {
     if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: negative count");
     if (num_ids == 0) return LSTEP_OK;
     if (int rc = check_hist("lstep_history_filter_runs_fwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
@@ -487,7 +491,7 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
         int64_t blocks = (num_ids + 15) / 16;
         if (blocks > 256) blocks = 256;
         hipLaunchKernelGGL(history_filter_runs_fwd_kernel<true>, dim3((unsigned)blocks), dim3(1024), lds_bytes, (hipStream_t)stream, h, (int)t_len,
-                           (int)pe_dim, mask, (int)mask_words, node_ids, num_ids, coef, (const double*)nullptr, out, table_out, slot_of);
+                           (int)pe_dim, mask, (int)mask_words, node_ids, num_ids, coef, (const double*)nullptr, out, table_out, slot_of, num_live);
         return check_launch("history_filter_runs_fwd_kernel<lds>");
     }
     hipLaunchKernelGGL(coef_prefix_kernel, dim3((unsigned)((pe_dim + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream,
@@ -495,7 +499,7 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
     int64_t blocks = (num_ids + kWavesPerBlock - 1) / kWavesPerBlock;
     if (blocks > kRunsFwdBlocks) blocks = kRunsFwdBlocks;
     hipLaunchKernelGGL(history_filter_runs_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim,
-                       mask, (int)mask_words, node_ids, num_ids, coef, (const double*)cpre, out, table_out, slot_of);
+                       mask, (int)mask_words, node_ids, num_ids, coef, (const double*)cpre, out, table_out, slot_of, num_live);
     return check_launch("history_filter_runs_fwd_kernel");
 }
 

@@ -108,10 +108,15 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
 // Pre-pass for an UNINITIALISED output: only the rows of segments that straddle a chunk boundary are accumulated with atomics and need
 // zeros; every other row that owns entries is written whole by one wave.  One thread per chunk boundary.
 __global__ __launch_bounds__(kBlock) void segment_zero_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t num_entries,
-                                                                         float* __restrict__ out, int ld_out, int width) {
+                                                                         float* __restrict__ out, int ld_out, int width,
+                                                                         const int32_t* __restrict__ num_live) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block() + 1;   // boundary between chunk c - 1 and chunk c: one wave each
     const int64_t e = c * kChunk;
+    if (num_live) {
+        const int64_t live = *num_live;
+        if (live < num_entries) num_entries = live;
+    }
     if (e >= num_entries) return;
     const int sg = ent_seg[e];
     if (ent_seg[e - 1] != sg) return;
@@ -195,7 +200,8 @@ using namespace lstep;
 
 extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
                                       int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
-                                      int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, void* stream) {
+                                      int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, const int32_t* num_live,
+                                      void* stream) {
     if (num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: negative count");
     if (num_entries == 0) return LSTEP_OK;
     if (ld_table == 0) ld_table = width;
@@ -209,9 +215,9 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     if (accumulate == 2 && chunks > 1)   // uninitialised output: zero just the rows the atomics will add to
         hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3((unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                           (hipStream_t)stream, ent_seg, num_entries, out, (int)ld_out, (int)(width + time_dim));
+                           (hipStream_t)stream, ent_seg, num_entries, out, (int)ld_out, (int)(width + time_dim), num_live);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, (const int32_t*)nullptr);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live);
     return check_launch("segment_rows_sum_kernel");
 }
 

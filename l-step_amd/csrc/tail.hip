@@ -294,16 +294,21 @@ struct UpdateParams {
     const float *ws, *bs;  // [176, 176], [176] self_update_pe, or NULL (phase 2: the term is dead code in the reference)
     float* table;          // [N + 1, pe_dim]
     float* mirror;         // optional second table of the same shape that receives the new rows too (the batch's history slot)
+    const int32_t* live;   // optional device count: only the first min(*live, n) rows are updated (n is then the capacity the grid covers)
     int64_t n;
     int32_t ld_agg, pe_dim;
 };
 
 template <int S>
-__global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(const UpdateParams p) {
+__global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) {
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
     const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t r0 = task * (16 * S);
+    if (p.live) {
+        const int64_t live = *p.live;
+        if (live < p.n) p.n = live;
+    }
     if (r0 >= p.n) return;   // no barriers in this kernel
     bool live[S];
     const float *agg_l[S], *own_l[S];
@@ -440,12 +445,13 @@ extern "C" int lstep_tail_bwd(const float* grad_out, const float* cat1, const fl
 }
 
 extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
-                                 const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim, void* stream) {
+                                 const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim,
+                                 const int32_t* num_live, void* stream) {
     if (n < 0 || ld_agg < kCe || (ld_agg & 3) || pe_dim <= 0 || pe_dim > kPp || (pe_dim & 3)) return set_error(LSTEP_EINVAL, "lstep_update_rows: bad sizes");
     if (n == 0) return LSTEP_OK;
     if (!agg || !ids || !w1 || !b1 || !w2 || !b2 || !table || (ws && !bs)) return set_error(LSTEP_EINVAL, "lstep_update_rows: NULL pointer");
     if (((uintptr_t)mirror) & 15) return set_error(LSTEP_EINVAL, "lstep_update_rows: misaligned mirror table");
-    UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, mirror, n, ld_agg, pe_dim};
+    UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, mirror, num_live, n, ld_agg, pe_dim};
     const int S = tail_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);

@@ -52,6 +52,35 @@ __global__ void update_entries_p2_kernel(const int32_t* __restrict__ order, cons
     }
 }
 
+// The same with every count on the device (no host round trip between the grouping and the message sums):
+//   summary = lstep_group_by_key's {., n_real, nseg} of the capacity-sized key list, live_rows = number of batch nodes (the key list has
+//   capacity_rows * k slots; slots of rows >= *live_rows are padding by construction).  Segment 0 is ALWAYS reserved for row 0:
+//   ent_seg = seg + 1, touched = [0, uniq[0 .. nseg), 0 ...] up to touched_capacity, counts_out = {nseg, row-0 flag}: row 0 takes part
+//   iff some slot of a LIVE row is padding (models/LSTEP.py:324: 0 is in unique(neighbour ids)), i.e. live_rows * k > n_real.
+__global__ void update_entries_p2_dev_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ seg, const int32_t* __restrict__ summary,
+                                             const int32_t* __restrict__ live_rows, int64_t capacity, int64_t touched_capacity,
+                                             const int64_t* __restrict__ bn, const float* __restrict__ nt, const float* __restrict__ now32, int32_t k,
+                                             const int32_t* __restrict__ uniq, int32_t* __restrict__ ent_row, float* __restrict__ ent_dt,
+                                             int32_t* __restrict__ ent_seg, int64_t* __restrict__ touched, int32_t* __restrict__ counts_out) {
+    const float now = now32[0];
+    const int64_t n_real = summary[1], nseg = summary[2];
+    const int64_t total = capacity > touched_capacity ? capacity : touched_capacity;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < n_real) {
+            const int64_t o = order[e];
+            ent_row[e] = (int32_t)bn[o / k];
+            ent_dt[e] = now - nt[o];
+            ent_seg[e] = seg[e] + 1;
+        }
+        if (e + 1 < touched_capacity) touched[e + 1] = e < nseg ? (int64_t)uniq[e] : 0;
+        if (e == 0) {
+            touched[0] = 0;
+            counts_out[0] = (int32_t)nseg;
+            counts_out[1] = ((int64_t)live_rows[0] * k > n_real) ? 1 : 0;
+        }
+    }
+}
+
 static unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 }  // namespace lstep
@@ -87,4 +116,17 @@ extern "C" int lstep_update_entries_p2(const int32_t* order, const int32_t* seg,
     hipLaunchKernelGGL(update_entries_p2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, order, seg, n_real, bn, nt, now32,
                        num_neighbors, shift, uniq, nseg, ent_row, ent_dt, ent_seg, touched);
     return check_launch("update_entries_p2_kernel");
+}
+
+extern "C" int lstep_update_entries_p2_dev(const int32_t* order, const int32_t* seg, const int32_t* summary, const int32_t* live_rows,
+                                           int64_t capacity, int64_t touched_capacity, const int64_t* bn, const float* nt, const float* now32,
+                                           int32_t num_neighbors, const int32_t* uniq, int32_t* ent_row, float* ent_dt, int32_t* ent_seg,
+                                           int64_t* touched, int32_t* counts_out, void* stream) {
+    if (capacity <= 0 || touched_capacity <= 0 || num_neighbors <= 0) return set_error(LSTEP_EINVAL, "lstep_update_entries_p2_dev: bad sizes");
+    if (!order || !seg || !summary || !live_rows || !bn || !nt || !now32 || !uniq || !ent_row || !ent_dt || !ent_seg || !touched || !counts_out)
+        return set_error(LSTEP_EINVAL, "lstep_update_entries_p2_dev: NULL pointer");
+    const int64_t total = capacity > touched_capacity ? capacity : touched_capacity;
+    hipLaunchKernelGGL(update_entries_p2_dev_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, order, seg, summary, live_rows,
+                       capacity, touched_capacity, bn, nt, now32, num_neighbors, uniq, ent_row, ent_dt, ent_seg, touched, counts_out);
+    return check_launch("update_entries_p2_dev_kernel");
 }

@@ -380,6 +380,10 @@ class LstepEngine:
         self._update_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
         self.slot_of = torch.full((rows,), -1, dtype=torch.int32, device=dev)
         self.fused_loss = torch.device(dev).type == "cuda" and backbone.pe_dim % 4 == 0 and os.environ.get("LSTEP_TORCH_LOSS") != "1"
+        # every data-dependent size (batch nodes, grouped neighbour slots, touched rows) stays on the device: no host synchronisation and
+        # no second host thread anywhere in an iteration.  Needs the change-mask ring and the fused kernels; LSTEP_HOST_COUNTS=1 (A/B
+        # switch) restores the host-sized path, which also serves every other configuration.
+        self._want_device_counts = os.environ.get("LSTEP_HOST_COUNTS") != "1"
         # the engine joins the auxiliary stream before every optimiser step, so INSIDE its training iteration (``aux_streams``) the model
         # may put its weight-gradient products there; outside of it every backward() is self-contained on the caller's stream
         self.use_aux = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
@@ -401,16 +405,18 @@ class LstepEngine:
             bb.aux_wgrad_stream = pr.aux_wgrad_stream = False
 
     # ---- shared pieces
-    def _splice(self, batch_nodes: torch.Tensor, batch_idx: int):
-        """FFT-filter the batch rows over the ring window and build the current PE in the spare slot (train:224-230)."""
+    def _splice(self, batch_nodes: torch.Tensor, batch_idx: int, live: torch.Tensor = None):
+        """FFT-filter the batch rows over the ring window and build the current PE in the spare slot (train:224-230).
+        ``live``: ``batch_nodes`` is the capacity-sized list of ``batch_nodes_device`` and ``live`` its device-resident length."""
         ring = self.ring
         ring.wait_window()
         if ring.mask is not None and ring.len > 0:
             # the run kernel writes the filtered rows into the current table and numbers them in slot_of on its way out
             cur = ring.base_for_next()
             rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest,
-                                                splice=(cur, self.slot_of))
+                                                splice=(cur, self.slot_of), live=live)
         else:
+            assert live is None, "device-resident counts need a ring with a change mask that already holds a snapshot"
             rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest)
             cur = ring.base_for_next()
             cur.index_copy_(0, batch_nodes, rows.detach())
@@ -429,11 +435,32 @@ class LstepEngine:
             lab = self._label_cache = torch.cat([torch.ones(n, device=self.device), torch.zeros(n, device=self.device)])
         return lab
 
-    def _group_batch(self, src, dst, wait: bool):
+    @property
+    def device_counts(self) -> bool:
+        bb = self.backbone
+        return (self._want_device_counts and self.ring is not None and self.ring.sparse and bb._fused_tail_ok()
+                and getattr(bb.neighbor_sampler, "sample_neighbor_strategy", "recent") == "recent"
+                and not any(os.environ.get(v) == "1" for v in ("LSTEP_TORCH_UPDATE", "LSTEP_TORCH_ENTRIES")))
+
+    def _group_batch(self, src, dst, wait):
         rows = self.backbone.node_raw_features.shape[0]
         keys = torch.cat([src, dst]).to(torch.int32)
         _, order, seg, uniq, counts = nat.group_by_key(keys, max(1, int(rows).bit_length()), rows, wait=wait)
         return order, seg, uniq, counts
+
+    def batch_nodes_device(self, src, dst):
+        """``batch_nodes_and_segments`` without any host round trip: (bn int64 [2 B] = the sorted unique endpoints followed by a dead tail
+        of node 0, n_live int32 [1] = their number on the device, (order, seg) = the int32 grouping of cat[src, dst] by batch node)."""
+        pre = self.__dict__.pop("_prefetched_group", None)
+        if pre is not None and pre[0].matches(src, dst) and isinstance(pre[1][3], torch.Tensor):
+            order, seg, uniq, summary = pre[1]
+        else:
+            order, seg, uniq, summary = self._group_batch(src, dst, wait=None)
+        bn = torch.empty(uniq.numel(), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(nat.load_library().lstep_widen_ids(nat.ptr(uniq), uniq.numel(), nat.ptr(summary), nat.ptr(bn), nat.current_stream()))
+        self._batch_groups = (seg, order)
+        return bn, summary[0:1], (order, seg)
 
     def batch_nodes_and_segments(self, src, dst):
         """One native group-by-key of cat[src, dst] (``lstep_group_by_key``) gives the sorted unique batch nodes
@@ -441,7 +468,7 @@ class LstepEngine:
         If ``prefetch_batch_nodes`` was called for exactly these tensors, its result is picked up: the only host wait is for the
         prefetched counts, which were copied out long ago."""
         pre = self.__dict__.pop("_prefetched_group", None)
-        if pre is not None and pre[0].matches(src, dst):
+        if pre is not None and pre[0].matches(src, dst) and not isinstance(pre[1][3], torch.Tensor):
             order, seg, uniq, counts = pre[1]
             n_unique = counts.get()[0]
         else:
@@ -453,7 +480,7 @@ class LstepEngine:
         """Group the NEXT batch's endpoints now (the edge stream is known ahead).  Its kernels queue up behind the current forward pass
         and its counts travel to the host asynchronously, so the next ``train_iteration`` starts without draining the GPU: the host
         can enqueue the next forward while the current backward is still running."""
-        self._prefetched_group = (BatchKey(src, dst), self._group_batch(src, dst, wait=False))
+        self._prefetched_group = (BatchKey(src, dst), self._group_batch(src, dst, wait=None if self.device_counts else False))
 
     # ---- train:204-311
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
@@ -466,14 +493,19 @@ class LstepEngine:
         bb, ring = self.backbone, self.ring
         out, loss = None, None
         bb.prepare_step()
-        batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)
+        on_device = self.device_counts and (batch_idx == 0 or ring.len > 0)
+        if on_device:
+            batch_nodes, n_live, presorted = self.batch_nodes_device(src, dst)
+        else:
+            n_live = None
+            batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)
         if batch_idx == 0:
             cur = ring.spare()
             cur.copy_(initial_pe)
             ring.begin_slot(all_changed=True)
             spliced = None
         else:
-            cur, spliced = self._splice(batch_nodes, batch_idx)
+            cur, spliced = self._splice(batch_nodes, batch_idx, live=n_live)
             n = src.numel()
             ids3 = torch.cat([src, dst, neg_dst])
             emb_p = bb.combining_pe_raw_feat(cur, ids3, torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced, padded=True)
@@ -500,9 +532,12 @@ class LstepEngine:
             self.prefetch_batch_nodes(*lookahead)
 
         def update_and_append():
-            bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                         node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G,
-                         presorted=presorted, changed=ring.written, mirror=ring.building())
+            if on_device:
+                bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building())
+            else:
+                bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
+                             node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G,
+                             presorted=presorted, changed=ring.written, mirror=ring.building())
             if batch_idx == 0 and initial_pe is not None:
                 initial_pe.copy_(cur)  # the reference mutates initial_positional_encoding in place at batch 0 (train:281,286)
             ring.commit()
@@ -525,6 +560,19 @@ class LstepEngine:
         main = torch.cuda.current_stream(self.device)
         side = self._update_stream
         side.wait_stream(main)
+        if on_device:
+            # nothing in update_pe waits for the GPU any more: its ~25 launches go out from THIS thread onto the side stream (0.1 ms of
+            # host time), then the backward pass onto the main stream -- no second thread contending for the interpreter lock
+            with torch.cuda.stream(side):
+                update_and_append()
+            optimizer.zero_grad()
+            loss.backward()
+            bb.join_aux_stream()
+            ring.apply_advance()  # the backward pass is enqueued: the window's oldest snapshot may move on behind it
+            main.wait_stream(side)
+            optimizer.step()      # after update_pe has read its weights
+            self.slot_of.index_fill_(0, batch_nodes, -1)   # (the dead tail is node 0, whose entry is -1 anyway)
+            return out
         err = []
 
         def worker():
@@ -557,9 +605,14 @@ class LstepEngine:
     # ---- evaluate_model_utils.py:38-142 (call under torch.no_grad())
     def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
         bb, ring = self.backbone, self.ring
-        batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)    # sorted unique, like the reference's torch.unique
+        on_device = self.device_counts and ring.len > 0
+        if on_device:
+            batch_nodes, n_live, presorted = self.batch_nodes_device(src, dst)
+        else:
+            n_live = None
+            batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)    # sorted unique, like the reference's torch.unique
         self._batch_groups = None
-        cur, _ = self._splice(batch_nodes, batch_idx)
+        cur, _ = self._splice(batch_nodes, batch_idx, live=n_live)
         self.slot_of.index_fill_(0, batch_nodes, -1)
         n = src.numel()
         emb_p = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_src, neg_dst]), torch.cat([ts, ts, ts, ts]), self.K, self.G, padded=True)
@@ -571,9 +624,12 @@ class LstepEngine:
         labels = self._labels(n)
         if lookahead is not None:
             self.prefetch_batch_nodes(*lookahead)
-        bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
-                     node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted,
-                     changed=ring.written, mirror=ring.building())
+        if on_device:
+            bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building())
+        else:
+            bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
+                         node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted,
+                         changed=ring.written, mirror=ring.building())
         ring.commit()
         ring.apply_advance()
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

@@ -661,7 +661,7 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
     ent_row = src_row_of(order[:n_hit])
     with torch.cuda.device(dev):
         nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, int(table.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
-                                             n_hit, nat.ptr(out), P, 1 if accumulate else 0, nat.current_stream()))
+                                             n_hit, nat.ptr(out), P, 1 if accumulate else 0, None, nat.current_stream()))
 
 
 def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, self_groups=None):
@@ -686,7 +686,7 @@ def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, 
     n_known = ent_row.numel()
     with torch.cuda.device(hits.device):
         nat.check(lib.lstep_segment_rows_sum(nat.ptr(g_self), P, int(g_self.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
-                                             n_known, nat.ptr(total), P, 1, nat.current_stream()))
+                                             n_known, nat.ptr(total), P, 1, None, nat.current_stream()))
         rest = self_slot[n_known:].to(torch.int32).contiguous()
         if rest.numel():
             g_rest = g_self[n_known:]
@@ -872,10 +872,13 @@ class _HistoryFilter(torch.autograd.Function):
     the ``*_runs_*`` kernels read one row per run of equal snapshots instead of one per snapshot."""
 
     @staticmethod
-    def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None, splice=None):
+    def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None, splice=None, live=None):
         lib = nat.load_library()
         node_stride, time_stride, slots, rot, t_len, P = geom
         U = ids.numel()
+        if live is not None and mask is None:
+            raise ValueError("a device-resident row count needs the change-mask kernels")
+        # (with ``live``, ids is a capacity-sized list: rows past the live count are never written and never read)
         out = torch.empty((U, P), dtype=torch.float32, device=ids.device)
         cc = coef.detach().contiguous()
         with torch.cuda.device(ids.device):
@@ -887,7 +890,7 @@ class _HistoryFilter(torch.autograd.Function):
                 nat.check(lib.lstep_history_filter_runs_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(mask),
                                                             int(mask.shape[1]), nat.ptr(oldest), nat.ptr(ids), U, nat.ptr(cc), nat.ptr(ws),
                                                             nat.ptr(out), nat.ptr(splice[0]) if splice else None,
-                                                            nat.ptr(splice[1]) if splice else None, nat.current_stream()))
+                                                            nat.ptr(splice[1]) if splice else None, nat.ptr(live), nat.current_stream()))
         ctx.geom, ctx.coef_shape = geom, tuple(coef.shape)
         # NOT save_for_backward: the device ring appends its next snapshot (a slot outside this window) in place
         # before backward runs; the window itself (rows and mask bits) is guaranteed untouched by HistoryRing (engine.py).
@@ -918,7 +921,7 @@ class _HistoryFilter(torch.autograd.Function):
                                                                 nat.ptr(g), nat.ptr(partial), nat.current_stream()))
                     diff = partial.sum(dim=0)
                     nat.check(lib.lstep_history_filter_runs_finish(nat.ptr(diff), t_len, P, nat.ptr(g_coef), nat.current_stream()))
-        return g_coef, None, None, None, None, None, None
+        return g_coef, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ backbone
@@ -1179,7 +1182,7 @@ class LSTEP(nn.Module):
         return self.filter_history(hist, geom, self._ids(node_ids), batch_idx)
 
     def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int, mask: torch.Tensor = None,
-                       oldest: torch.Tensor = None, splice=None):
+                       oldest: torch.Tensor = None, splice=None, live: torch.Tensor = None):
         """Shared by the drop-in method above and the device ring of ``lstep_amd.engine`` (geom = strides/rotation; ``mask`` = the
         ring's change bits, ``oldest`` = its table of the window's oldest snapshot when the slots only hold changed rows, see
         ``HistoryRing``)."""
@@ -1189,11 +1192,11 @@ class LSTEP(nn.Module):
                     or slot_of.dtype != torch.int32):
                 raise ValueError("filter_history: the fused splice needs the change-mask path, a contiguous fp32 table and an int32 slot map")
         coef = self.fft_coefficients(geom[4], batch_idx)
-        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask, oldest, splice)
+        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask, oldest, splice, live)
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
-    def _segment_sum(self, pe, nseg, ent_seg, ent_row, ent_dt, exact: bool = False):
+    def _segment_sum(self, pe, nseg, ent_seg, ent_row, ent_dt, exact: bool = False, live: torch.Tensor = None):
         """out[s] = sum over the entries of segment s of cat[pe[ent_row], time_feat(ent_dt)]  (lstep_segment_rows_sum).
         Library-GEMM consumers: rows are bucketed (``_bucket_rows``) and everything past the data is zero.  ``exact`` (the fused
         ``lstep_update_rows`` consumer, which reads exactly ``nseg`` rows): no bucket rows and NO memset -- every segment owns entries, so
@@ -1208,7 +1211,7 @@ class LSTEP(nn.Module):
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_segment_rows_sum(nat.ptr(pe), P, P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
                                                  nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), ent_row.numel(), nat.ptr(out), self.ld_pe,
-                                                 2 if exact else 0, nat.current_stream()))
+                                                 2 if exact else 0, nat.ptr(live), nat.current_stream()))
         return out
 
     MLP_ROW_BLOCK = 65536   # hipBLASLt's fp32 rate for these skinny GEMMs swings 50-115 TFLOP/s with M; 65536-row blocks sit at ~100 (tools/gemm_m.py)
@@ -1242,7 +1245,7 @@ class LSTEP(nn.Module):
         return self._padded_cached("update_mlp", (m1.weight, m1.bias, m2.weight, m2.bias), lambda: (
             _pad2(m1.weight.detach(), Pp, Cp).t(), _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).t(), _pad1(m2.bias.detach(), Pp)))
 
-    def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None):
+    def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None, live: torch.Tensor = None):
         """``lstep_update_rows``: pe[ids] += tanh(pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(pe[ids])]) in place, one launch."""
         lib = nat.load_library()
         Pp = self.ld_self
@@ -1257,7 +1260,7 @@ class LSTEP(nn.Module):
         ids = ids.contiguous()
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_update_rows(nat.ptr(agg), int(agg.stride(0)), nat.ptr(ids), ids.numel(), nat.ptr(w1), nat.ptr(b1), nat.ptr(w2),
-                                            nat.ptr(b2), nat.ptr(ws), nat.ptr(bs), nat.ptr(pe), nat.ptr(mirror), self.pe_dim,
+                                            nat.ptr(b2), nat.ptr(ws), nat.ptr(bs), nat.ptr(pe), nat.ptr(mirror), self.pe_dim, nat.ptr(live),
                                             nat.current_stream()))
 
     @classmethod
@@ -1441,6 +1444,68 @@ class LSTEP(nn.Module):
             agg2[0, :P] = part.sum(dim=0)
         self._update_rows(pe, touched, agg2, with_self=False, mirror=mirror)
         return touched
+
+    @torch.no_grad()
+    def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None):
+        """``update_pe`` for the engine, with every data-dependent size left on the device: no host synchronisation, no second host
+        thread, a fixed launch sequence.
+
+        ``bn`` int64 [2 B] is the capacity-sized batch-node list of ``lstep_widen_ids`` (sorted unique endpoints, dead tail = node 0),
+        ``n_live`` int32 [1] their number on the device, ``presorted = (order, seg)`` the int32 grouping of cat[src, dst] by batch node.
+        Dead rows are the padding node 0: it has no history, so the sampler returns all-padding neighbourhoods for them, their keys drop
+        out of the grouping, their change-mask marks hit row 0 (always marked) and their contribution to row 0's padding sum is
+        K * pe[0] = 0 (pe[0] is zeroed first, models/LSTEP.py:317).  What does depend on the exact count reads it on the device:
+        ``lstep_update_rows`` (which rows to write), ``lstep_segment_rows_sum`` (how many grouped slots are real) and the decision
+        whether row 0 takes part in phase 2 at all (``lstep_update_entries_p2_dev``)."""
+        lib = nat.load_library()
+        dev, P, K = pe.device, self.pe_dim, int(num_neighbors)
+        cap = bn.numel()
+        rows = pe.shape[0]
+        now32 = t.max().to(torch.float32).reshape(1)          # torch.Tensor([current_time]) of models/LSTEP.py:277: float32-rounded
+        order32, seg32 = presorted
+        n2 = order32.numel()
+        # ---- phase 1 (LSTEP.py:277-303)
+        ent_row = torch.empty(n2, dtype=torch.int32, device=dev)
+        ent_dt = torch.empty(n2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_update_entries_p1(nat.ptr(order32), n2, nat.ptr(src), nat.ptr(dst), nat.ptr(t), nat.ptr(now32), src.numel(),
+                                                  nat.ptr(ent_row), nat.ptr(ent_dt), nat.current_stream()))
+        agg = self._segment_sum(pe, cap, seg32, ent_row, ent_dt, exact=True)
+        self._update_rows(pe, bn, agg, with_self=True, mirror=mirror, live=n_live)
+        if changed is not None:
+            changed(bn, mirror is not None)       # (the dead tail marks row 0, which every update_pe rewrites anyway)
+        # ---- phase 2 (LSTEP.py:305-339): row i of bn is zipped with the i-th EDGE time, rows >= min(U, B) stay padding
+        nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, K)
+        n = nbr.numel()
+        pe[0].zero_()
+        keys32 = torch.empty(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_update_keys_p2(nat.ptr(nbr), n, rows, 1, 0, nat.ptr(keys32), nat.current_stream()))
+        _, order, seg, uniq, summary = nat.group_by_key(keys32, max(1, int(rows + 1).bit_length()), rows, wait=None)
+        tcap = min(n, rows) + 1                                # row 0's reserved segment + at most one per slot / per table row
+        ent_row = torch.empty(n, dtype=torch.int32, device=dev)
+        ent_dt = torch.empty(n, dtype=torch.float32, device=dev)
+        ent_seg = torch.empty(n, dtype=torch.int32, device=dev)
+        touched = torch.empty(tcap, dtype=torch.int64, device=dev)
+        counts = torch.empty(2, dtype=torch.int32, device=dev)    # {touched rows besides row 0, does row 0 take part}
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_update_entries_p2_dev(nat.ptr(order), nat.ptr(seg), nat.ptr(summary), nat.ptr(n_live), n, tcap, nat.ptr(bn),
+                                                      nat.ptr(nt), nat.ptr(now32), K, nat.ptr(uniq), nat.ptr(ent_row), nat.ptr(ent_dt),
+                                                      nat.ptr(ent_seg), nat.ptr(touched), nat.ptr(counts), nat.current_stream()))
+        agg2 = self._segment_sum(pe, tcap, ent_seg, ent_row, ent_dt, exact=True, live=summary[1:2])
+        # row 0 collects cat[pe[source], 0] from every padded slot: segment 0 has no entries of its own, its aggregate is the sum over
+        # the rows of (their number of padded slots) * pe[source row]
+        agg2[0].zero_()
+        part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), P), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, nat.ptr(bn), cap, nat.ptr(pe), P, int(pe.stride(0)), nat.ptr(part),
+                                                 nat.current_stream()))
+        agg2[0, :P] = part.sum(dim=0)
+        self._update_rows(pe, touched[1:], agg2[1:], with_self=False, mirror=mirror, live=counts[0:1])
+        self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=counts[1:2])
+        if changed is not None:
+            changed(touched, mirror is not None)
+        return pe
 
     @torch.no_grad()
     def update_pe(self, pe, node_ids, edge_ids, batch_src_node_ids, batch_dst_node_ids, node_interact_times, current_time,

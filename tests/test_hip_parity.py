@@ -1090,3 +1090,61 @@ def test_live_entry_reduction_without_host_sync_incl_overflow(hip):
         assert float((out.double() - 2 * ref).abs().max()) <= 2e-5 * (float(ref.abs().max()) + 1.0)
     tracker = mod.__dict__["_live_counts"][(B * K, K)]
     assert tracker.last is not None
+
+
+@pytest.mark.parametrize("case", ["mature-no-padding", "young-padding", "U-greater-than-B"])
+def test_engine_device_resident_counts_equal_host_counts(hip, monkeypatch, case):
+    """The engine keeps every data-dependent size of an iteration on the device (batch nodes, real neighbour slots, touched rows, whether
+    row 0 takes part in phase 2): no host synchronisation, no second host thread.  Same results as the host-sized path
+    (LSTEP_HOST_COUNTS=1), which the golden traces pin.  Cases: a mature graph where every batch node has K earlier interactions and
+    U <= B, so NO slot is padding and row 0 must stay exactly zero (models/LSTEP.py:317,324); a young graph full of padding; U > B, where
+    the rows past B are padding by the reference's zip truncation (models/LSTEP.py:306-308)."""
+    from lstep_amd.optim import FusedAdam
+    N, E, K, T, B, start = {"mature-no-padding": (24, 6000, 4, 5, 64, 5000), "young-padding": (300, 3000, 20, 5, 64, 100),
+                            "U-greater-than-B": (400, 8000, 8, 5, 48, 4000)}[case]
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=61)
+    node_raw, edge_raw = synth.make_features(N, E, seed=62)
+    sd = synth.make_state_dict(K, T, seed=63)
+    res = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("LSTEP_HOST_COUNTS", "1")
+        else:
+            monkeypatch.delenv("LSTEP_HOST_COUNTS", raising=False)
+        model = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, sd, DEV)
+        model.train()
+        eng = hip.LstepEngine(model[0], model[1], K, 2000)
+        assert eng.device_counts == (not host)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+        init = torch.from_numpy(synth.make_initial_pe(N, seed=64)).to(DEV)
+        tables, losses, row0 = [], [], []
+        for b in range(7):
+            lo = start + b * B
+            neg = torch.from_numpy(synth.make_negatives(N, B, seed=b)).to(DEV)
+            nxt = stream.batch(lo + B, lo + 2 * B)[:2] if b % 2 == 0 else None
+            out = eng.train_iteration(opt, b, *stream.batch(lo, lo + B), neg, initial_pe=init, lookahead=nxt)
+            tables.append(eng.ring.last().clone())
+            row0.append(float(eng.ring.last()[0].abs().max()))
+            if out is not None:
+                losses.append([float(out["loss"]), float(out["lp_loss"]), float(out["pe_loss"])])
+        model.eval()
+        with torch.no_grad():
+            for b in range(7, 10):
+                lo = start + b * B
+                neg = torch.from_numpy(synth.make_negatives(N, 2 * B, seed=b)).to(DEV)
+                out = eng.eval_iteration(b, *stream.batch(lo, lo + B), neg[:B], neg[B:])
+                tables.append(eng.ring.last().clone())
+                losses.append([float(out["loss"]), 0.0, 0.0])
+        res.append((torch.stack(tables).cpu().numpy(), np.array(losses), row0, eng.ring.as_reference_tensor().cpu().numpy()))
+    (ta, la, ra, ha), (tb, lb, rb, hb) = res
+    np.testing.assert_allclose(ta, tb, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ha, hb, rtol=0, atol=2e-6)
+    if case == "mature-no-padding":
+        assert max(ra[1:]) == 0.0 and max(rb[1:]) == 0.0, "no padded slot in the batch: row 0 must stay zero after update_pe"
+    else:
+        assert min(ra) > 0.0
+    if case == "U-greater-than-B":
+        src, dst = g["src"][start:start + B], g["dst"][start:start + B]
+        assert len(np.unique(np.concatenate([src, dst]))) > B
