@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 22
+#define LSTEP_ABI_VERSION 23
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -43,6 +43,19 @@ typedef struct lstep_csr {
     int64_t num_rows;      /* max node id + 1 */
     int64_t nnz;           /* 2 * number of edges */
 } lstep_csr_t;
+
+/* A slot of the device-resident PE history ring whose index lives ON THE DEVICE: slot = (*start + add) % slots.  Entry points that take a
+ * `const lstep_ring_ref_t* ring` use it INSTEAD of their host-side slot / rotation argument when it is non-NULL, and then interpret their
+ * slot-pointer argument (the slot's rows) as the base of the whole ring: rows of the slot = base + slot * slot_stride floats.  With it
+ * the launch sequence of a training iteration no longer depends on how far the ring has rotated, so the iteration can be captured
+ * once as a HIP graph and replayed; lstep_ring_tick advances *start by one at the end of an iteration. */
+typedef struct {
+    const int32_t* start;   /* device: physical slot of the window's oldest snapshot */
+    int32_t add;            /* 0 = oldest snapshot, window length = the slot being built, ... */
+    int32_t slots;          /* physical slots of the ring */
+    int64_t slot_stride;    /* floats between two slots */
+} lstep_ring_ref_t;
+int lstep_ring_tick(int32_t* start, int32_t slots, void* stream);
 
 /* Branch selection for lstep_gather_aggregate_fwd/bwd */
 #define LSTEP_BRANCH_EDGE_NODE 1u /* A + N: models/LSTEP.py:147-158,177-211 */
@@ -135,9 +148,10 @@ int lstep_history_filter_bwd(const float* hist, int64_t node_stride, int64_t tim
  *   lstep_history_mark       set the bit of `slot` for the listed node ids; world > 1: only ids with id % world == rank, at row id / world
  *                            (owner-sharded rings); ids outside [0, num_rows) are ignored.
  * A bit that is set for an unchanged row costs one extra row read, a bit that is missing for a changed row gives wrong results. */
-int lstep_history_slot_bits(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, int32_t value, void* stream);
+int lstep_history_slot_bits(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, int32_t value, const lstep_ring_ref_t* ring,
+                            void* stream);
 int lstep_history_mark(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, const int64_t* ids, int64_t num_ids,
-                       int32_t world, int32_t rank, void* stream);
+                       int32_t world, int32_t rank, const lstep_ring_ref_t* ring, void* stream);
 /* workspace: lstep_history_filter_runs_workspace(t_len, pe_dim) bytes, 16-byte aligned (float64 prefix sums of coef) */
 int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe_dim);
 /* oldest (optional, [num_rows, node_stride]): the window's oldest snapshot.  With it the slots need not be full clones: a slot only has to hold
@@ -148,7 +162,7 @@ int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe_dim);
 int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                   int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                   const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out,
-                                  float* table_out, int32_t* slot_of, const int32_t* num_live, void* stream);
+                                  float* table_out, int32_t* slot_of, const int32_t* num_live, const lstep_ring_ref_t* ring, void* stream);
 /* num_live (optional, device): node_ids is a capacity-sized list and only its first min(*num_live, num_ids) entries are batch nodes
  * (the batch-node count of train_LSTEP_link_prediction.py:221-222 stays on the device: no host round trip before the FFT splice). */
 /* (table_out, slot_of: optional.  table_out [num_rows, node_stride] also receives out[u] at row node_ids[u] -- the splice
@@ -157,14 +171,16 @@ int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_
  * passes the [t_len, P] result to lstep_history_filter_runs_finish, which turns it into d(coef) (running sums in float64). */
 int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                   int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
-                                  const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial, void* stream);
+                                  const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial,
+                                  const lstep_ring_ref_t* ring, void* stream);
 /* dst[r, :width] = src[r, :width] for r in ids (row stride ld floats; rows outside [0, num_rows) ignored): the rows a batch wrote, copied
  * from the current PE table into the batch's history slot (train_link_prediction.py:301 appends the whole table). */
-int lstep_copy_rows(float* dst, const float* src, int32_t width, int64_t ld, const int64_t* ids, int64_t num_ids, int64_t num_rows, void* stream);
+int lstep_copy_rows(float* dst, const float* src, int32_t width, int64_t ld, const int64_t* ids, int64_t num_ids, int64_t num_rows,
+                    const lstep_ring_ref_t* ring, void* stream);
 /* oldest[r] = slot_rows[r] for every row r whose bit of `slot` is set in the change mask: the window's oldest snapshot moves to that slot
  * (the trim of train_link_prediction.py:224-225). */
 int lstep_history_advance_oldest(float* oldest, const float* slot_rows, int32_t width, int64_t ld, const uint32_t* mask, int32_t mask_words,
-                                 int32_t slot, int64_t num_rows, void* stream);
+                                 int32_t slot, int64_t num_rows, const lstep_ring_ref_t* ring, void* stream);
 int lstep_history_filter_runs_finish(const float* partial_sum, int32_t t_len, int32_t pe_dim, float* dcoef, void* stream);
 
 /* Segmented row sums.  Entry e = 0..num_entries-1 belongs to output row ent_seg[e]; entries of one segment must be
@@ -301,7 +317,7 @@ int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float
  * -- the batch's history slot, so that appending the snapshot (train_link_prediction.py:301) costs no separate copy. */
 int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim, const int32_t* num_live,
-                      void* stream);
+                      const lstep_ring_ref_t* ring, void* stream);
 /* num_live (optional, device): only the first min(*num_live, n) rows are updated; n is then the capacity the launch covers. */
 
 /* Device-resident counts for the engine's update_pe (no host synchronisation anywhere in models/LSTEP.py:268-340):

@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 22
+ABI_VERSION = 23
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -31,6 +31,11 @@ class CsrStruct(C.Structure):
     """``lstep_csr_t``"""
     _fields_ = [("indptr", C.c_void_p), ("nbr", C.c_void_p), ("eid", C.c_void_p), ("ts", C.c_void_p),
                 ("num_rows", C.c_int64), ("nnz", C.c_int64)]
+
+
+class RingRef(C.Structure):
+    """``lstep_ring_ref_t``: a slot of the history ring whose index lives on the device, slot = (*start + add) % slots."""
+    _fields_ = [("start", C.c_void_p), ("add", C.c_int32), ("slots", C.c_int32), ("slot_stride", C.c_int64)]
 
 
 def _stale() -> bool:
@@ -77,13 +82,15 @@ SIGNATURES = {
     "lstep_history_filter_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
     "lstep_history_filter_bwd_chunks": (_I64, [_I64]),
     "lstep_history_filter_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
-    "lstep_history_slot_bits": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P]),
-    "lstep_history_mark": (C.c_int, [_P, _I32, _I64, _I32, _P, _I64, _I32, _I32, _P]),
+    "lstep_history_slot_bits": (C.c_int, [_P, _I32, _I64, _I32, _I32, C.POINTER(RingRef), _P]),
+    "lstep_history_mark": (C.c_int, [_P, _I32, _I64, _I32, _P, _I64, _I32, _I32, C.POINTER(RingRef), _P]),
+    "lstep_ring_tick": (C.c_int, [_P, _I32, _P]),
     "lstep_history_filter_runs_workspace": (_I64, [_I32, _I32]),
-    "lstep_history_filter_runs_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
-    "lstep_history_filter_runs_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, _P]),
-    "lstep_copy_rows": (C.c_int, [_P, _P, _I32, _I64, _P, _I64, _I64, _P]),
-    "lstep_history_advance_oldest": (C.c_int, [_P, _P, _I32, _I64, _P, _I32, _I32, _I64, _P]),
+    "lstep_history_filter_runs_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _P,
+                                               C.POINTER(RingRef), _P]),
+    "lstep_history_filter_runs_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, C.POINTER(RingRef), _P]),
+    "lstep_copy_rows": (C.c_int, [_P, _P, _I32, _I64, _P, _I64, _I64, C.POINTER(RingRef), _P]),
+    "lstep_history_advance_oldest": (C.c_int, [_P, _P, _I32, _I64, _P, _I32, _I32, _I64, C.POINTER(RingRef), _P]),
     "lstep_history_filter_runs_finish": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _I32, _P, _P]),
     "lstep_sort_live_bounded_workspace": (_I64, [_I64, _I64, _I32]),
@@ -102,7 +109,7 @@ SIGNATURES = {
     "lstep_update_entries_p1": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "lstep_update_keys_p2": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "lstep_update_entries_p2": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _I64, _P, _P, _P, _P, _P]),
-    "lstep_update_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P]),
+    "lstep_update_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, C.POINTER(RingRef), _P]),
     "lstep_widen_ids": (C.c_int, [_P, _I64, _P, _P, _P]),
     "lstep_update_entries_p2_dev": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_fwd": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),

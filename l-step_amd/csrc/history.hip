@@ -13,6 +13,11 @@ struct HistView {
     int64_t node_stride, time_stride;
     int slots, rot;
     const float* oldest;   // optional [rows, node_stride] table holding the window's oldest snapshot (rings whose slots only store changed rows)
+    const int32_t* rot_dev = nullptr;   // lstep_ring_ref_t: the rotation lives on the device (rot = (*rot_dev + rot_add) % slots)
+    int rot_add = 0;
+    __device__ __forceinline__ void resolve() {
+        if (rot_dev) rot = (*rot_dev + rot_add) % slots;
+    }
     __device__ __forceinline__ const float* row(int64_t node, int s) const {
         int ph = s + rot;
         if (ph >= slots) ph -= slots;
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fw
                                                                                          float* __restrict__ out, float* __restrict__ table_out,
                                                                                          int32_t* __restrict__ slot_of, const int32_t* __restrict__ num_live) {
     extern __shared__ double cpre_lds[];
+    h.resolve();
     if (num_live) {      // ids is a capacity-sized list: only its first min(*num_live, num_ids) entries are nodes of this batch
         const int64_t live = *num_live;
         if (live < num_ids) num_ids = live;
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void history_filter_runs_bwd_kernel(HistVie
                                                                           const int64_t* __restrict__ ids, int64_t num_ids,
                                                                           const float* __restrict__ grad, float* __restrict__ partial, int groups) {
     const int lane = lane_id();
+    h.resolve();
     const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t chunk = w / groups;
     const int grp = (int)(w - chunk * groups);
@@ -347,10 +354,26 @@ __global__ __launch_bounds__(kBlock) void history_runs_finish_kernel(const float
     }
 }
 
+// slot index from a device-resident ring position (lstep_ring_ref_t), or the host value
+struct SlotRef {
+    const int32_t* start;
+    int add, slots;
+    int64_t stride;
+    __device__ __forceinline__ int slot(int host_slot) const { return start ? (*start + add) % slots : host_slot; }
+};
+static SlotRef slot_ref(const lstep_ring_ref_t* r) { return r ? SlotRef{r->start, r->add, r->slots, r->slot_stride} : SlotRef{nullptr, 0, 1, 0}; }
+static int check_ring(const char* who, const lstep_ring_ref_t* r) {
+    if (r && (!r->start || r->slots <= 0 || r->add < 0 || r->slot_stride < 0)) return set_error(LSTEP_EINVAL, "%s: bad ring reference", who);
+    return LSTEP_OK;
+}
+
+__global__ void ring_tick_kernel(int32_t* start, int slots) { *start = (*start + 1) % slots; }
+
 __global__ __launch_bounds__(kBlock) void history_mark_kernel(uint32_t* __restrict__ mask, int words, int64_t num_rows, int slot,
-                                                               const int64_t* __restrict__ ids, int64_t num_ids, int world, int rank) {
+                                                               const int64_t* __restrict__ ids, int64_t num_ids, int world, int rank, SlotRef ring) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_ids) return;
+    slot = ring.slot(slot);
     int64_t node = ids[i];
     // the padding node: history_slot_bits_kernel sets its bit for every slot, and capacity-sized id lists end in a long run of zeros
     // (hundreds of thousands of atomics on ONE word took 4.5 ms per batch)
@@ -365,8 +388,9 @@ __global__ __launch_bounds__(kBlock) void history_mark_kernel(uint32_t* __restri
 
 // dst[r] = src[r] for the listed rows r (wave per row; rows outside [0, num_rows) are ignored)
 __global__ __launch_bounds__(kBlock) void copy_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, int width, int64_t ld,
-                                                            const int64_t* __restrict__ ids, int64_t num_ids, int64_t num_rows) {
+                                                            const int64_t* __restrict__ ids, int64_t num_ids, int64_t num_rows, SlotRef ring) {
     const int lane = lane_id();
+    if (ring.start) dst += (int64_t)ring.slot(0) * ring.stride;
     const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (i >= num_ids) return;
     const int64_t r = ids[i];
@@ -376,17 +400,24 @@ __global__ __launch_bounds__(kBlock) void copy_rows_kernel(float* __restrict__ d
 
 // oldest[r] = slot_rows[r] for every row whose bit of `slot` is set: the window's oldest snapshot moves on by one batch
 __global__ __launch_bounds__(kBlock) void history_advance_oldest_kernel(float* __restrict__ oldest, const float* __restrict__ slot_rows, int width, int64_t ld,
-                                                                         const uint32_t* __restrict__ mask, int words, int slot, int64_t num_rows) {
+                                                                         const uint32_t* __restrict__ mask, int words, int slot, int64_t num_rows,
+                                                                         SlotRef ring) {
     const int lane = lane_id();
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (r >= num_rows) return;
+    if (ring.start) {
+        slot = ring.slot(slot);
+        slot_rows += (int64_t)slot * ring.stride;
+    }
     if (!((mask[r * words + (slot >> 5)] >> (slot & 31)) & 1u)) return;
     for (int c = lane * 4; c < width; c += kWave * 4) st4(oldest + r * ld + c, ld4_stream(slot_rows + r * ld + c));
 }
 
-__global__ __launch_bounds__(kBlock) void history_slot_bits_kernel(uint32_t* __restrict__ mask, int words, int64_t num_rows, int slot, int value) {
+__global__ __launch_bounds__(kBlock) void history_slot_bits_kernel(uint32_t* __restrict__ mask, int words, int64_t num_rows, int slot, int value,
+                                                                    SlotRef ring) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_rows) return;
+    slot = ring.slot(slot);
     uint32_t* w = mask + i * words + (slot >> 5);
     const uint32_t bit = 1u << (slot & 31);
     // atomics: a word holds the bits of 32 slots, and history_mark_kernel may be setting another slot's bit of the same word from
@@ -448,24 +479,30 @@ static int check_mask(const char* who, const uint32_t* mask, int32_t words, int3
 }
 
 extern "C" int lstep_history_mark(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, const int64_t* ids, int64_t num_ids,
-                                  int32_t world, int32_t rank, void* stream) {
+                                  int32_t world, int32_t rank, const lstep_ring_ref_t* ring, void* stream) {
     if (num_ids < 0 || num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_history_mark: negative count");
     if (num_ids == 0) return LSTEP_OK;
+    if (int rc = check_ring("lstep_history_mark", ring)) return rc;
+    if (ring) slot = ring->slots - 1;     // (the mask must hold every slot the device may pick)
     if (int rc = check_mask("lstep_history_mark", mask, mask_words, slot + 1)) return rc;
     if (slot < 0 || !ids || world < 1 || rank < 0 || rank >= world) return set_error(LSTEP_EINVAL, "lstep_history_mark: bad argument");
     const unsigned grid = (unsigned)((num_ids + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(history_mark_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, mask, (int)mask_words, num_rows, (int)slot, ids, num_ids,
-                       (int)world, (int)rank);
+                       (int)world, (int)rank, slot_ref(ring));
     return check_launch("history_mark_kernel");
 }
 
-extern "C" int lstep_history_slot_bits(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, int32_t value, void* stream) {
+extern "C" int lstep_history_slot_bits(uint32_t* mask, int32_t mask_words, int64_t num_rows, int32_t slot, int32_t value,
+                                       const lstep_ring_ref_t* ring, void* stream) {
     if (num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_history_slot_bits: negative count");
     if (num_rows == 0) return LSTEP_OK;
+    if (int rc = check_ring("lstep_history_slot_bits", ring)) return rc;
+    if (ring) slot = ring->slots - 1;
     if (int rc = check_mask("lstep_history_slot_bits", mask, mask_words, slot + 1)) return rc;
     if (slot < 0) return set_error(LSTEP_EINVAL, "lstep_history_slot_bits: negative slot");
     const unsigned grid = (unsigned)((num_rows + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(history_slot_bits_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, mask, (int)mask_words, num_rows, (int)slot, (int)value);
+    hipLaunchKernelGGL(history_slot_bits_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, mask, (int)mask_words, num_rows, (int)slot, (int)value,
+                       slot_ref(ring));
     return check_launch("history_slot_bits_kernel");
 }
 
@@ -476,15 +513,17 @@ extern "C" int64_t lstep_history_filter_runs_workspace(int32_t t_len, int32_t pe
 extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                              int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                              const int64_t* node_ids, int64_t num_ids, const float* coef, void* workspace, float* out,
-                                             float* table_out, int32_t* slot_of, const int32_t* num_live, void* stream) {
+                                             float* table_out, int32_t* slot_of, const int32_t* num_live, const lstep_ring_ref_t* ring, void* stream) {
     if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: negative count");
     if (num_ids == 0) return LSTEP_OK;
+    if (int rc = check_ring("lstep_history_filter_runs_fwd", ring)) return rc;
     if (int rc = check_hist("lstep_history_filter_runs_fwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
     if (int rc = check_mask("lstep_history_filter_runs_fwd", mask, mask_words, time_slots)) return rc;
     if (!node_ids || !coef || !out || !workspace || (((uintptr_t)workspace) & 15) || (((uintptr_t)oldest) & 15))
         return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: NULL or misaligned pointer");
     if (((uintptr_t)table_out) & 15) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_fwd: misaligned table_out");
     HistView h{hist, node_stride, time_stride, time_slots, time_rot, oldest};
+    if (ring) { h.rot_dev = ring->start; h.rot_add = ring->add; }
     double* cpre = (double*)workspace;
     const size_t lds_bytes = (size_t)(t_len + 1) * pe_dim * sizeof(double);
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&history_filter_runs_fwd_kernel<true>),
@@ -508,13 +547,16 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
 
 extern "C" int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                              int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
-                                             const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial, void* stream) {
+                                             const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial,
+                                             const lstep_ring_ref_t* ring, void* stream) {
     if (num_ids < 0) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_bwd: negative count");
     if (num_ids == 0 || t_len == 0) return LSTEP_OK;
     if (int rc = check_hist("lstep_history_filter_runs_bwd", hist, node_stride, time_stride, time_slots, time_rot, t_len, pe_dim)) return rc;
     if (int rc = check_mask("lstep_history_filter_runs_bwd", mask, mask_words, time_slots)) return rc;
     if (!node_ids || !grad_out || !out_partial || (((uintptr_t)oldest) & 15)) return set_error(LSTEP_EINVAL, "lstep_history_filter_runs_bwd: NULL or misaligned pointer");
+    if (int rc = check_ring("lstep_history_filter_runs_bwd", ring)) return rc;
     HistView h{hist, node_stride, time_stride, time_slots, time_rot, oldest};
+    if (ring) { h.rot_dev = ring->start; h.rot_add = ring->add; }
     const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
     const int64_t waves = lstep_history_filter_bwd_chunks(num_ids) * groups;
     const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -534,25 +576,37 @@ extern "C" int lstep_history_filter_runs_finish(const float* partial_sum, int32_
 }
 
 extern "C" int lstep_copy_rows(float* dst, const float* src, int32_t width, int64_t ld, const int64_t* ids, int64_t num_ids, int64_t num_rows,
-                               void* stream) {
+                               const lstep_ring_ref_t* ring, void* stream) {
     if (num_ids < 0 || num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_copy_rows: negative count");
     if (num_ids == 0) return LSTEP_OK;
+    if (int rc = check_ring("lstep_copy_rows", ring)) return rc;
+    if (ring && (ring->slot_stride & 3)) return set_error(LSTEP_EINVAL, "lstep_copy_rows: slot stride must keep rows 16-byte aligned");
     if (!dst || !src || !ids || width <= 0 || (width & 3) || ld < width || (ld & 3) || (((uintptr_t)dst | (uintptr_t)src) & 15))
         return set_error(LSTEP_EINVAL, "lstep_copy_rows: rows must be 16-byte aligned, width a multiple of 4");
     const unsigned grid = (unsigned)((num_ids + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, dst, src, (int)width, ld, ids, num_ids, num_rows);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, dst, src, (int)width, ld, ids, num_ids, num_rows,
+                       slot_ref(ring));
     return check_launch("copy_rows_kernel");
 }
 
 extern "C" int lstep_history_advance_oldest(float* oldest, const float* slot_rows, int32_t width, int64_t ld, const uint32_t* mask,
-                                            int32_t mask_words, int32_t slot, int64_t num_rows, void* stream) {
+                                            int32_t mask_words, int32_t slot, int64_t num_rows, const lstep_ring_ref_t* ring, void* stream) {
     if (num_rows < 0) return set_error(LSTEP_EINVAL, "lstep_history_advance_oldest: negative count");
     if (num_rows == 0) return LSTEP_OK;
+    if (int rc = check_ring("lstep_history_advance_oldest", ring)) return rc;
+    if (ring && (ring->slot_stride & 3)) return set_error(LSTEP_EINVAL, "lstep_history_advance_oldest: slot stride must keep rows 16-byte aligned");
+    if (ring) slot = ring->slots - 1;
     if (int rc = check_mask("lstep_history_advance_oldest", mask, mask_words, slot + 1)) return rc;
     if (!oldest || !slot_rows || slot < 0 || width <= 0 || (width & 3) || ld < width || (ld & 3) || (((uintptr_t)oldest | (uintptr_t)slot_rows) & 15))
         return set_error(LSTEP_EINVAL, "lstep_history_advance_oldest: rows must be 16-byte aligned, width a multiple of 4");
     const unsigned grid = (unsigned)((num_rows + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(history_advance_oldest_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, oldest, slot_rows, (int)width, ld, mask,
-                       (int)mask_words, (int)slot, num_rows);
+                       (int)mask_words, (int)slot, num_rows, slot_ref(ring));
     return check_launch("history_advance_oldest_kernel");
+}
+
+extern "C" int lstep_ring_tick(int32_t* start, int32_t slots, void* stream) {
+    if (!start || slots <= 0) return set_error(LSTEP_EINVAL, "lstep_ring_tick: bad arguments");
+    hipLaunchKernelGGL(ring_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, start, (int)slots);
+    return check_launch("ring_tick_kernel");
 }

@@ -295,6 +295,9 @@ struct UpdateParams {
     float* table;          // [N + 1, pe_dim]
     float* mirror;         // optional second table of the same shape that receives the new rows too (the batch's history slot)
     const int32_t* live;   // optional device count: only the first min(*live, n) rows are updated (n is then the capacity the grid covers)
+    const int32_t* ring_start;   // optional lstep_ring_ref_t: `mirror` is the base of the history ring, the slot index lives on the device
+    int32_t ring_add, ring_slots;
+    int64_t ring_stride;
     int64_t n;
     int32_t ld_agg, pe_dim;
 };
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
         if (live < p.n) p.n = live;
     }
     if (r0 >= p.n) return;   // no barriers in this kernel
+    if (p.ring_start && p.mirror) p.mirror += (int64_t)((*p.ring_start + p.ring_add) % p.ring_slots) * p.ring_stride;
     bool live[S];
     const float *agg_l[S], *own_l[S];
     float* own_row[S];
@@ -446,12 +450,15 @@ extern "C" int lstep_tail_bwd(const float* grad_out, const float* cat1, const fl
 
 extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
                                  const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim,
-                                 const int32_t* num_live, void* stream) {
+                                 const int32_t* num_live, const lstep_ring_ref_t* ring, void* stream) {
     if (n < 0 || ld_agg < kCe || (ld_agg & 3) || pe_dim <= 0 || pe_dim > kPp || (pe_dim & 3)) return set_error(LSTEP_EINVAL, "lstep_update_rows: bad sizes");
     if (n == 0) return LSTEP_OK;
     if (!agg || !ids || !w1 || !b1 || !w2 || !b2 || !table || (ws && !bs)) return set_error(LSTEP_EINVAL, "lstep_update_rows: NULL pointer");
     if (((uintptr_t)mirror) & 15) return set_error(LSTEP_EINVAL, "lstep_update_rows: misaligned mirror table");
-    UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, mirror, num_live, n, ld_agg, pe_dim};
+    if (ring && (!ring->start || ring->slots <= 0 || ring->add < 0 || (ring->slot_stride & 3)))
+        return set_error(LSTEP_EINVAL, "lstep_update_rows: bad ring reference");
+    UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, mirror, num_live, ring ? ring->start : nullptr, ring ? ring->add : 0,
+                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim};
     const int S = tail_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);

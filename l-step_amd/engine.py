@@ -19,6 +19,7 @@ Edge streams live on the device (``EdgeStream``); a batch is a slice, no host ro
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import os
 import threading
 from dataclasses import dataclass
@@ -90,6 +91,41 @@ class HistoryRing:
             self.advance_stream = None               # stream ``apply_advance`` runs on (default: the ring's copy stream)
         else:
             self.oldest = None
+        # Optional device-resident ring position (``position_on_device``): the kernels then read the slot they work on from this word
+        # (``lstep_ring_ref_t``) instead of receiving it as a launch argument, so the launch sequence of an iteration does not change as
+        # the ring rotates -- the precondition for replaying a captured iteration (``GraphedTrainStep``).
+        self.dev_start = None
+        self._dev_mirror = 0     # the value the host knows ``dev_start`` to hold (it trails ``start`` between a commit and the tick)
+
+    def position_on_device(self):
+        """Keep the ring position on the device from now on (sparse rings whose window is full)."""
+        assert self.sparse and self.len == self.T
+        if self.dev_start is None:
+            self.dev_start = torch.zeros(1, dtype=torch.int32, device=self.buf.device)
+        self.dev_start.fill_(self.start)
+        self._dev_mirror = self.start
+
+    def _ref(self, slot: int):
+        """``lstep_ring_ref_t*`` for physical slot ``slot`` (None while the position lives on the host)."""
+        if self.dev_start is None:
+            return None
+        return ctypes.byref(nat.RingRef(self.dev_start.data_ptr(), (int(slot) - self._dev_mirror) % self.S, self.S, self.rows * self.P))
+
+    def tick(self):
+        """End of an iteration: the device-resident position follows the host's (one launch on the current stream)."""
+        if self.dev_start is None:
+            return
+        assert (self._dev_mirror + 1) % self.S == self.start, "exactly one commit per iteration"
+        if self._advanced[1] is not None:     # the advance of this iteration reads the position on another stream: it goes first
+            torch.cuda.current_stream(self.buf.device).wait_event(self._advanced[1])
+        with torch.cuda.device(self.buf.device):
+            nat.check(nat.load_library().lstep_ring_tick(nat.ptr(self.dev_start), self.S, nat.current_stream()))
+        self._dev_mirror = self.start
+
+    def replay_tick(self):
+        """A captured iteration was replayed: its kernels advanced the device position; the host mirrors follow."""
+        self.start = (self.start + 1) % self.S
+        self._dev_mirror = self.start
 
     def begin_slot(self, slot: int = None, all_changed: bool = False):
         """Reset the change bits of the snapshot about to be built (on the current stream): nothing changed yet, or everything."""
@@ -100,7 +136,7 @@ class HistoryRing:
         slot = (self.start + self.len) % self.S if slot is None else slot
         with torch.cuda.device(self.mask.device):
             nat.check(nat.load_library().lstep_history_slot_bits(nat.ptr(self.mask), self.words, self.rows, int(slot), int(all_changed),
-                                                                 nat.current_stream()))
+                                                                 self._ref(slot), nat.current_stream()))
 
     def written(self, ids: torch.Tensor, mirrored: bool = False):
         """``update_pe``'s callback: rows ``ids`` were written (``mirrored``: into ``building()`` as well, nothing left to copy)."""
@@ -109,6 +145,12 @@ class HistoryRing:
     def building(self):
         """Sparse rings: the slot of the snapshot being built, for writers that can put their rows there directly (``lstep_update_rows``)."""
         return self.buf[(self.start + self.len) % self.S] if self.sparse else None
+
+    def building_ref(self):
+        """(ring base, ``lstep_ring_ref_t*`` of the slot being built) when the position lives on the device, else (None, None)."""
+        if self.dev_start is None:
+            return None, None
+        return self.buf, self._ref((self.start + self.len) % self.S)
 
     def mark(self, ids: torch.Tensor, world: int = 1, rank: int = 0, copy: bool = True):
         """Rows ``ids`` (int64 node ids; ``world > 1``: only those owned by ``rank``, stored at row id // world) of the snapshot being built
@@ -120,11 +162,15 @@ class HistoryRing:
         slot = (self.start + self.len) % self.S
         with torch.cuda.device(self.mask.device):
             nat.check(nat.load_library().lstep_history_mark(nat.ptr(self.mask), self.words, self.rows, slot, nat.ptr(ids), ids.numel(),
-                                                            int(world), int(rank), nat.current_stream()))
+                                                            int(world), int(rank), self._ref(slot), nat.current_stream()))
 
     def geom(self):
         """(node_stride, time_stride, slots, rot, t_len, P) for ``lstep_history_filter_*`` (element strides)."""
         return (self.P, self.rows * self.P, self.S, self.start, self.len, self.P)
+
+    def window_ref(self):
+        """``lstep_ring_ref_t*`` of the window's oldest slot (the filter kernels' rotation), or None."""
+        return self._ref(self.start)
 
     def last(self) -> torch.Tensor:
         assert self.len > 0
@@ -145,9 +191,10 @@ class HistoryRing:
                 if self._all_written or self.len == 0:
                     dst.copy_(self.table)
                 else:
+                    ref = self._ref(slot)
                     for ids in self._written + [self._row0]:     # (row 0 is rewritten by every update_pe and always marked)
-                        nat.check(lib.lstep_copy_rows(nat.ptr(dst), nat.ptr(self.table), self.P, self.P, nat.ptr(ids), ids.numel(), self.rows,
-                                                      nat.current_stream()))
+                        nat.check(lib.lstep_copy_rows(nat.ptr(self.buf if ref is not None else dst), nat.ptr(self.table), self.P, self.P,
+                                                      nat.ptr(ids), ids.numel(), self.rows, ref, nat.current_stream()))
                 if self.len == 0:
                     self.oldest.copy_(self.table)
             self._written, self._all_written = [], False
@@ -175,11 +222,19 @@ class HistoryRing:
         side = self.advance_stream or self._copy_stream
         with torch.cuda.device(dev), torch.cuda.stream(side):
             side.wait_event(here)
-            nat.check(nat.load_library().lstep_history_advance_oldest(nat.ptr(self.oldest), nat.ptr(self.buf[slot]), self.P, self.P,
-                                                                      nat.ptr(self.mask), self.words, slot, self.rows, nat.current_stream()))
+            ref = self._ref(slot)
+            nat.check(nat.load_library().lstep_history_advance_oldest(nat.ptr(self.oldest), nat.ptr(self.buf if ref is not None else self.buf[slot]),
+                                                                      self.P, self.P, nat.ptr(self.mask), self.words, slot, self.rows, ref,
+                                                                      nat.current_stream()))
             ev = torch.cuda.Event()
             ev.record()
-        self._advanced = [self._advanced[1], ev]
+        if torch.cuda.is_current_stream_capturing():
+            # inside a captured iteration the graph orders everything: the caller joins the advance stream before the capture ends,
+            # and replays follow each other on one stream, so the next window read needs no event
+            torch.cuda.current_stream(dev).wait_event(ev)
+            self._advanced = [None, None]
+        else:
+            self._advanced = [self._advanced[1], ev]
 
     def wait_window(self):
         """Make the current stream wait until the window can be read: ``oldest`` is at most one slide behind."""
@@ -384,6 +439,8 @@ class LstepEngine:
         # no second host thread anywhere in an iteration.  Needs the change-mask ring and the fused kernels; LSTEP_HOST_COUNTS=1 (A/B
         # switch) restores the host-sized path, which also serves every other configuration.
         self._want_device_counts = os.environ.get("LSTEP_HOST_COUNTS") != "1"
+        # LSTEP_RING_ON_DEVICE=1: keep the ring position on the device in eager mode too (the graphed step always does)
+        self._ring_on_device = os.environ.get("LSTEP_RING_ON_DEVICE") == "1"
         # the engine joins the auxiliary stream before every optimiser step, so INSIDE its training iteration (``aux_streams``) the model
         # may put its weight-gradient products there; outside of it every backward() is self-contained on the caller's stream
         self.use_aux = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
@@ -414,7 +471,7 @@ class LstepEngine:
             # the run kernel writes the filtered rows into the current table and numbers them in slot_of on its way out
             cur = ring.base_for_next()
             rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest,
-                                                splice=(cur, self.slot_of), live=live)
+                                                splice=(cur, self.slot_of), live=live, ring=ring.window_ref())
         else:
             assert live is None, "device-resident counts need a ring with a change mask that already holds a snapshot"
             rows = self.backbone.filter_history(ring.buf, ring.geom(), batch_nodes, batch_idx, mask=ring.mask, oldest=ring.oldest)
@@ -492,6 +549,8 @@ class LstepEngine:
     def _train_iteration(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
         bb, ring = self.backbone, self.ring
         out, loss = None, None
+        if (self._ring_on_device and ring.dev_start is None and ring.sparse and ring.len == ring.T and ring._advance is None):
+            ring.position_on_device()
         bb.prepare_step()
         on_device = self.device_counts and (batch_idx == 0 or ring.len > 0)
         if on_device:
@@ -533,7 +592,9 @@ class LstepEngine:
 
         def update_and_append():
             if on_device:
-                bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building())
+                base, ref = ring.building_ref()
+                bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written,
+                                    mirror=base if ref is not None else ring.building(), mirror_ring=ref)
             else:
                 bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
                              node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G,
@@ -552,6 +613,7 @@ class LstepEngine:
                 optimizer.step()
                 self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
             ring.apply_advance()      # (after the backward pass, which still reads the window as it was)
+            ring.tick()
             return out
 
         # update_pe (forward-only, reads and writes only the current PE table) and the backward pass (never reads that table)
@@ -572,6 +634,7 @@ class LstepEngine:
             main.wait_stream(side)
             optimizer.step()      # after update_pe has read its weights
             self.slot_of.index_fill_(0, batch_nodes, -1)   # (the dead tail is node 0, whose entry is -1 anyway)
+            ring.tick()
             return out
         err = []
 
@@ -600,11 +663,14 @@ class LstepEngine:
             raise err[0]
         optimizer.step()      # after update_pe has read its weights
         self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
+        ring.tick()
         return out
 
     # ---- evaluate_model_utils.py:38-142 (call under torch.no_grad())
     def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
         bb, ring = self.backbone, self.ring
+        if (self._ring_on_device and ring.dev_start is None and ring.sparse and ring.len == ring.T and ring._advance is None):
+            ring.position_on_device()
         on_device = self.device_counts and ring.len > 0
         if on_device:
             batch_nodes, n_live, presorted = self.batch_nodes_device(src, dst)
@@ -625,11 +691,14 @@ class LstepEngine:
         if lookahead is not None:
             self.prefetch_batch_nodes(*lookahead)
         if on_device:
-            bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building())
+            base, ref = ring.building_ref()
+            bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written,
+                                mirror=base if ref is not None else ring.building(), mirror_ring=ref)
         else:
             bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
                          node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G, presorted=presorted,
                          changed=ring.written, mirror=ring.building())
         ring.commit()
         ring.apply_advance()
+        ring.tick()
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}

@@ -872,7 +872,7 @@ class _HistoryFilter(torch.autograd.Function):
     the ``*_runs_*`` kernels read one row per run of equal snapshots instead of one per snapshot."""
 
     @staticmethod
-    def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None, splice=None, live=None):
+    def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None, splice=None, live=None, ring=None):
         lib = nat.load_library()
         node_stride, time_stride, slots, rot, t_len, P = geom
         U = ids.numel()
@@ -890,11 +890,11 @@ class _HistoryFilter(torch.autograd.Function):
                 nat.check(lib.lstep_history_filter_runs_fwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P, nat.ptr(mask),
                                                             int(mask.shape[1]), nat.ptr(oldest), nat.ptr(ids), U, nat.ptr(cc), nat.ptr(ws),
                                                             nat.ptr(out), nat.ptr(splice[0]) if splice else None,
-                                                            nat.ptr(splice[1]) if splice else None, nat.ptr(live), nat.current_stream()))
+                                                            nat.ptr(splice[1]) if splice else None, nat.ptr(live), ring, nat.current_stream()))
         ctx.geom, ctx.coef_shape = geom, tuple(coef.shape)
         # NOT save_for_backward: the device ring appends its next snapshot (a slot outside this window) in place
         # before backward runs; the window itself (rows and mask bits) is guaranteed untouched by HistoryRing (engine.py).
-        ctx.hist, ctx.mask, ctx.oldest = hist_base, mask, oldest
+        ctx.hist, ctx.mask, ctx.oldest, ctx.ring = hist_base, mask, oldest, ring    # (ring: lstep_ring_ref_t*, the window's rotation on the device)
         ctx.save_for_backward(ids)
         return out
 
@@ -918,10 +918,10 @@ class _HistoryFilter(torch.autograd.Function):
                 else:
                     nat.check(lib.lstep_history_filter_runs_bwd(nat.ptr(hist_base), node_stride, time_stride, slots, rot, t_len, P,
                                                                 nat.ptr(mask), int(mask.shape[1]), nat.ptr(ctx.oldest), nat.ptr(ids), U,
-                                                                nat.ptr(g), nat.ptr(partial), nat.current_stream()))
+                                                                nat.ptr(g), nat.ptr(partial), ctx.ring, nat.current_stream()))
                     diff = partial.sum(dim=0)
                     nat.check(lib.lstep_history_filter_runs_finish(nat.ptr(diff), t_len, P, nat.ptr(g_coef), nat.current_stream()))
-        return g_coef, None, None, None, None, None, None, None
+        return g_coef, None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ backbone
@@ -1182,7 +1182,7 @@ class LSTEP(nn.Module):
         return self.filter_history(hist, geom, self._ids(node_ids), batch_idx)
 
     def filter_history(self, hist_base: torch.Tensor, geom, ids: torch.Tensor, batch_idx: int, mask: torch.Tensor = None,
-                       oldest: torch.Tensor = None, splice=None, live: torch.Tensor = None):
+                       oldest: torch.Tensor = None, splice=None, live: torch.Tensor = None, ring=None):
         """Shared by the drop-in method above and the device ring of ``lstep_amd.engine`` (geom = strides/rotation; ``mask`` = the
         ring's change bits, ``oldest`` = its table of the window's oldest snapshot when the slots only hold changed rows, see
         ``HistoryRing``)."""
@@ -1192,7 +1192,7 @@ class LSTEP(nn.Module):
                     or slot_of.dtype != torch.int32):
                 raise ValueError("filter_history: the fused splice needs the change-mask path, a contiguous fp32 table and an int32 slot map")
         coef = self.fft_coefficients(geom[4], batch_idx)
-        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask, oldest, splice, live)
+        return _HistoryFilter.apply(coef, hist_base, geom, ids, mask, oldest, splice, live, ring)
 
     # ---- U1 + U2 (models/LSTEP.py:268-340).  Forward only: in the reference no gradient ever reaches these
     # parameters (the loss is taken before update_pe and the history is detached, train:233-275,306).
@@ -1245,7 +1245,7 @@ class LSTEP(nn.Module):
         return self._padded_cached("update_mlp", (m1.weight, m1.bias, m2.weight, m2.bias), lambda: (
             _pad2(m1.weight.detach(), Pp, Cp).t(), _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).t(), _pad1(m2.bias.detach(), Pp)))
 
-    def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None, live: torch.Tensor = None):
+    def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None, live: torch.Tensor = None, ring=None):
         """``lstep_update_rows``: pe[ids] += tanh(pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(pe[ids])]) in place, one launch."""
         lib = nat.load_library()
         Pp = self.ld_self
@@ -1261,7 +1261,7 @@ class LSTEP(nn.Module):
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_update_rows(nat.ptr(agg), int(agg.stride(0)), nat.ptr(ids), ids.numel(), nat.ptr(w1), nat.ptr(b1), nat.ptr(w2),
                                             nat.ptr(b2), nat.ptr(ws), nat.ptr(bs), nat.ptr(pe), nat.ptr(mirror), self.pe_dim, nat.ptr(live),
-                                            nat.current_stream()))
+                                            ring, nat.current_stream()))
 
     @classmethod
     def _bucket_rows(cls, n: int) -> int:
@@ -1446,7 +1446,7 @@ class LSTEP(nn.Module):
         return touched
 
     @torch.no_grad()
-    def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None):
+    def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None, mirror_ring=None):
         """``update_pe`` for the engine, with every data-dependent size left on the device: no host synchronisation, no second host
         thread, a fixed launch sequence.
 
@@ -1456,7 +1456,8 @@ class LSTEP(nn.Module):
         out of the grouping, their change-mask marks hit row 0 (always marked) and their contribution to row 0's padding sum is
         K * pe[0] = 0 (pe[0] is zeroed first, models/LSTEP.py:317).  What does depend on the exact count reads it on the device:
         ``lstep_update_rows`` (which rows to write), ``lstep_segment_rows_sum`` (how many grouped slots are real) and the decision
-        whether row 0 takes part in phase 2 at all (``lstep_update_entries_p2_dev``)."""
+        whether row 0 takes part in phase 2 at all (``lstep_update_entries_p2_dev``).  ``mirror_ring`` (``lstep_ring_ref_t*``): ``mirror``
+        is the base of the history ring and the slot that receives the new rows is picked on the device."""
         lib = nat.load_library()
         dev, P, K = pe.device, self.pe_dim, int(num_neighbors)
         cap = bn.numel()
@@ -1471,7 +1472,7 @@ class LSTEP(nn.Module):
             nat.check(lib.lstep_update_entries_p1(nat.ptr(order32), n2, nat.ptr(src), nat.ptr(dst), nat.ptr(t), nat.ptr(now32), src.numel(),
                                                   nat.ptr(ent_row), nat.ptr(ent_dt), nat.current_stream()))
         agg = self._segment_sum(pe, cap, seg32, ent_row, ent_dt, exact=True)
-        self._update_rows(pe, bn, agg, with_self=True, mirror=mirror, live=n_live)
+        self._update_rows(pe, bn, agg, with_self=True, mirror=mirror, live=n_live, ring=mirror_ring)
         if changed is not None:
             changed(bn, mirror is not None)       # (the dead tail marks row 0, which every update_pe rewrites anyway)
         # ---- phase 2 (LSTEP.py:305-339): row i of bn is zipped with the i-th EDGE time, rows >= min(U, B) stay padding
@@ -1501,8 +1502,8 @@ class LSTEP(nn.Module):
             nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, nat.ptr(bn), cap, nat.ptr(pe), P, int(pe.stride(0)), nat.ptr(part),
                                                  nat.current_stream()))
         agg2[0, :P] = part.sum(dim=0)
-        self._update_rows(pe, touched[1:], agg2[1:], with_self=False, mirror=mirror, live=counts[0:1])
-        self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=counts[1:2])
+        self._update_rows(pe, touched[1:], agg2[1:], with_self=False, mirror=mirror, live=counts[0:1], ring=mirror_ring)
+        self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=counts[1:2], ring=mirror_ring)
         if changed is not None:
             changed(touched, mirror is not None)
         return pe

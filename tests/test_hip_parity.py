@@ -1150,3 +1150,51 @@ def test_engine_device_resident_counts_equal_host_counts(hip, monkeypatch, case)
     if case == "U-greater-than-B":
         src, dst = g["src"][start:start + B], g["dst"][start:start + B]
         assert len(np.unique(np.concatenate([src, dst]))) > B
+
+
+def test_engine_ring_position_on_device_equals_host_position(hip, monkeypatch):
+    """With LSTEP_RING_ON_DEVICE=1 the kernels read the ring slot they work on from a device word (lstep_ring_ref_t) that
+    lstep_ring_tick advances once per iteration, instead of receiving it as a launch argument -- what lets a whole iteration be
+    replayed as one captured graph.  Same results as the host-positioned ring over more than three full rotations of a 7-slot ring
+    (training and evaluation iterations, window reads, mirrored writes, change marks, the lagging `oldest` table)."""
+    from lstep_amd.optim import FusedAdam
+    N, E, K, T, B, start = 200, 8000, 10, 5, 48, 3000
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=71)
+    node_raw, edge_raw = synth.make_features(N, E, seed=72)
+    sd = synth.make_state_dict(K, T, seed=73)
+    res = []
+    for on_dev in (True, False):
+        if on_dev:
+            monkeypatch.setenv("LSTEP_RING_ON_DEVICE", "1")
+        else:
+            monkeypatch.delenv("LSTEP_RING_ON_DEVICE", raising=False)
+        model = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, sd, DEV)
+        model.train()
+        eng = hip.LstepEngine(model[0], model[1], K, 2000)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+        init = torch.from_numpy(synth.make_initial_pe(N, seed=74)).to(DEV)
+        tables, losses = [], []
+        for b in range(24):
+            lo = start + b * B
+            neg = torch.from_numpy(synth.make_negatives(N, 2 * B, seed=b)).to(DEV)
+            if b % 5 == 4:
+                model.eval()
+                with torch.no_grad():
+                    out = eng.eval_iteration(b, *stream.batch(lo, lo + B), neg[:B], neg[B:])
+                model.train()
+            else:
+                out = eng.train_iteration(opt, b, *stream.batch(lo, lo + B), neg[:B], initial_pe=init)
+            tables.append(eng.ring.last().clone())
+            if out is not None:
+                losses.append(float(out["loss"]))
+        assert (eng.ring.dev_start is not None) == on_dev
+        if on_dev:
+            assert int(eng.ring.dev_start.item()) == eng.ring.start
+        res.append((torch.stack(tables).cpu().numpy(), np.array(losses), eng.ring.as_reference_tensor().cpu().numpy()))
+    (ta, la, ha), (tb, lb, hb) = res
+    # (not bit-identical run to run: the loss kernel's float atomics sum in varying order and Adam turns rounding-level gradient
+    # differences into +-lr weight steps; a wrong slot anywhere would show at the 1e-1 level)
+    np.testing.assert_allclose(ta, tb, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ha, hb, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
