@@ -192,6 +192,9 @@ def _workspace(dev, need: int):
     thread) while the backward pass works on the main stream."""
     import torch
 
+    if torch.cuda.is_current_stream_capturing():
+        # inside a graph capture the scratch belongs to the graph's private pool: never cached, never shared with eager launches
+        return torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     wkey = (dev, _raw_stream(dev.index if hasattr(dev, "index") and dev.index is not None else None))
     ws = _WORKSPACES.get(wkey)
     if ws is None or ws.numel() < need:

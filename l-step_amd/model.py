@@ -240,6 +240,12 @@ class _TailWeightsGraph:
         return [p.detach() for p in self.params]
 
     def forward(self):
+        if torch.cuda.is_current_stream_capturing():
+            # the whole iteration is being captured (engine.GraphedTrainStep): no graph inside a graph, the ~25 launches are recorded
+            # as they are; the fixed gradient buffers and the deferred backward keep working
+            with torch.no_grad():
+                outs, transposed, self._cap_saved = _tail_weights_forward(self.dims, *self._detached())
+            return outs, transposed
         ptrs = tuple(p.data_ptr() for p in self.params)
         if self.g_fwd is None or ptrs != self.ptrs:     # first use, or a parameter's storage was replaced: (re)capture
             self.ptrs, self.g_bwd = ptrs, None
@@ -258,7 +264,8 @@ class _TailWeightsGraph:
 
     def prepare(self, aux):
         """Replay the forward graph on ``aux`` now (it only depends on the parameters); the next ``forward()`` waits for it."""
-        if self.g_fwd is None or tuple(p.data_ptr() for p in self.params) != self.ptrs or self.live > 0:
+        if (self.g_fwd is None or tuple(p.data_ptr() for p in self.params) != self.ptrs or self.live > 0
+                or torch.cuda.is_current_stream_capturing()):
             return
         aux.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(aux):
@@ -268,6 +275,12 @@ class _TailWeightsGraph:
 
     def backward(self):
         """Operand gradients in ``self.gin`` -> the 16 parameter gradients (static tensors, valid until the next call)."""
+        if torch.cuda.is_current_stream_capturing():
+            d = self._detached()
+            W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo = d[:10]
+            a_sum, M = self._cap_saved
+            with torch.no_grad():
+                return _tail_weights_backward(self.dims, aw.numel(), b1, W2, b2, Wn, bn, Wo, a_sum, M, *self.gin, True)
         if self.g_bwd is None:
             d = self._detached()
             W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo = d[:10]
@@ -637,9 +650,15 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
     keys = seg_of_entry.contiguous()
     key_bits = max(1, int(out.shape[0]).bit_length())
     track = mod.__dict__.setdefault("_live_counts", {}).setdefault((n, div), _LiveCount()) if div > 0 else None
-    last = track.poll() if track is not None else None
-    if last is not None and os.environ.get("LSTEP_SYNC_LIVE_SORT") != "1":
-        capacity = min(n, max(8192, (2 * last + 4095) // 4096 * 4096))
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:      # no read-back inside a captured iteration: the capacity comes from the eager iterations before it (overflow stays exact)
+        if track is None or track.last is None:
+            raise nat.LstepNativeError("a captured iteration needs one eager training iteration of the same shape first")
+        last = track.last
+    else:
+        last = track.poll() if track is not None else None
+    if last is not None and (capturing or os.environ.get("LSTEP_SYNC_LIVE_SORT") != "1"):
+        capacity = min(n, max(8192, ((3 if capturing else 2) * last + 4095) // 4096 * 4096))
         sorted_keys, order, live_index, count = nat.sort_live_bounded(keys, key_bits, int(out.shape[0]), capacity)
         ent_row = torch.div(order, div, rounding_mode="floor") if div > 1 else order
         with torch.cuda.device(dev):
@@ -648,7 +667,8 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
             if capacity < n:
                 nat.check(lib.lstep_scatter_add_overflow(nat.ptr(out), P, P, nat.ptr(keys), nat.ptr(live_index), nat.ptr(count), capacity,
                                                          max(div, 1), nat.ptr(table), int(table.stride(0)), nat.current_stream()))
-        track.send(count)
+        if not capturing:
+            track.send(count)
         return
     sorted_keys, order, n_hit = nat.sort_live(keys, key_bits)
     if track is not None:
@@ -725,6 +745,8 @@ class _GatherAggregate(torch.autograd.Function):
         tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
         s = mod.neighbor_sampler
         sink = getattr(mod, "gather_event_sink", None)   # bench.py: HIP events on the launch stream right around the launch (roofline.achieved)
+        if sink is not None and torch.cuda.is_current_stream_capturing():
+            sink = None                                  # (timed events cannot be recorded into a graph)
         if sink is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -1198,3 +1198,50 @@ def test_engine_ring_position_on_device_equals_host_position(hip, monkeypatch):
     np.testing.assert_allclose(ta, tb, rtol=0, atol=2e-5)
     np.testing.assert_allclose(ha, hb, rtol=0, atol=2e-5)
     np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,N", [(48, 200), (200, 60)])
+def test_graphed_train_step_matches_eager_iterations(hip, B, N):
+    """``GraphedTrainStep``: a steady-state training iteration captured once as a HIP graph (three streams = three branches, every
+    size on the device, ring position on the device) and replayed per batch, against the same iterations issued launch by launch.
+    More than three ring rotations; the second shape has U < B, most batch nodes re-appearing in every batch (long gradient-hit
+    lists, the overflow path of the fixed-capacity sort stays exact)."""
+    from lstep_amd.optim import FusedAdam
+    E, K, T, start = 12000, 10, 5, 3000
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=81)
+    node_raw, edge_raw = synth.make_features(N, E, seed=82)
+    sd = synth.make_state_dict(K, T, seed=83)
+    res = []
+    for graphed in (True, False):
+        model = hip.build(node_raw, edge_raw, hip_sampler(hip, g), K, T, sd, DEV)
+        model.train()
+        eng = hip.LstepEngine(model[0], model[1], K, 2000)
+        eng.use_step_graph = graphed
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+        init = torch.from_numpy(synth.make_initial_pe(N, seed=84)).to(DEV)
+        tables, losses, preds = [], [], []
+        for b in range(30):
+            lo = start + b * B
+            neg = torch.from_numpy(synth.make_negatives(N, B, seed=b)).to(DEV)
+            out = eng.train_iteration(opt, b, *stream.batch(lo, lo + B), neg, initial_pe=init)
+            tables.append(eng.ring.last().clone())
+            if out is not None:
+                losses.append([float(out["loss"]), float(out["lp_loss"]), float(out["pe_loss"])])
+                preds.append(out["predicts"].clone())
+        if graphed:
+            gs = eng._graphed.get(B)
+            assert gs is not None and gs.graph is not None, "the steady-state iterations must have been replayed from the captured graph"
+            assert int(eng.ring.dev_start.item()) == eng.ring.start
+        else:
+            assert not eng._graphed
+        weights = torch.cat([torch.view_as_real(p.detach()).reshape(-1) if p.is_complex() else p.detach().reshape(-1) for p in model.parameters()])
+        res.append((torch.stack(tables).cpu().numpy(), np.array(losses), torch.stack(preds).cpu().numpy(), weights.cpu().numpy(),
+                    eng.ring.as_reference_tensor().cpu().numpy()))
+    (ta, la, pa, wa, ha), (tb, lb, pb, wb, hb) = res
+    np.testing.assert_allclose(la, lb, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ta, tb, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(ha, hb, rtol=0, atol=5e-5)
+    d = np.abs(wa - wb)      # Adam turns rounding-level gradient differences into +-lr steps on single elements
+    assert float(d.max()) <= 3e-2 and float((d > 5e-4).mean()) <= 2e-3
