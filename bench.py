@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prime", type=int, default=12, help="training iterations run as part of the set-up pre-roll, before the warm-up steps")
+    ap.add_argument("--graph", choices=["on", "off"], default="on",
+                    help="on: steady-state training iterations are replayed from ONE captured HIP graph (engine.GraphedTrainStep, single GPU); "
+                         "off: every launch issued from Python")
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="eval = evaluate_model_utils.py:38-142 iteration (4x combine, no backward)")
     ap.add_argument("--zipf", type=float, default=None, help="power-law endpoint popularity exponent (hub-skew variant)")
     ap.add_argument("--history", choices=["evolved", "random"], default="evolved",
@@ -181,12 +184,13 @@ def main():
     opt = FusedAdam(model.parameters(), lr=1e-4)
     if not use_dist:
         runner = eng
+        eng.use_step_graph = args.graph == "on" and args.mode == "train"
     else:
         from lstep_amd.workload import prefill_distributed
         runner = DistributedLstep(eng, opt)
         prefill_distributed(runner, seed=0)
     B = wl.batch
-    need = (args.warmup + args.steps) * B * world
+    need = (args.warmup + args.steps + 10) * B * world      # (+10: the launch-by-launch iterations that time the gather kernel in graph mode)
     if need > wl.num_edges:
         raise SystemExit(f"{args.warmup + args.steps} batches of {B * world} edges do not fit the {wl.num_edges}-edge stream of workload {args.workload}")
     start = min(wl.num_edges // 2, wl.num_edges - need)   # from the middle of the stream when it fits
@@ -254,6 +258,19 @@ def main():
             rows.append(f"{(h - prev_h) * 1e3:.2f}/{(g - prev_g) if prev_g is not None else float('nan'):.2f}")
             prev_h, prev_g = h, g
         print("[trace] per step host-enqueue ms / GPU ms since previous step end: " + " ".join(rows), file=sys.stderr)
+    timing_note = "HIP events on the launch stream around every gather launch of the timed steps"
+    if not sink:
+        # the timed steps were graph replays (engine.GraphedTrainStep), and a graph cannot carry timed events: the gather kernel's launch
+        # duration is measured the same way on the next batches of the same stream, issued launch by launch right after the timed region
+        eng_g = getattr(runner, "use_step_graph", None)
+        runner.use_step_graph = False
+        extra = max(3, min(10, args.steps))
+        for i in range(extra):
+            step(args.warmup + args.steps + i)
+        barrier()
+        runner.use_step_graph = eng_g
+        timing_note = (f"the timed steps are graph replays, which cannot carry timed events: HIP events around the gather launch of the {extra} "
+                       "iterations issued launch by launch right after the timed region (same stream of batches, same state)")
     model[0].gather_event_sink = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -292,12 +309,13 @@ def main():
                        "per_gpu_batch": B, "workload_name": args.workload,
                        "history": (f"evolved: {prerolled} pre-roll batches through the engine's own eval iteration + {prime} through its training iteration"
                                    if args.history == "evolved" else f"random: T independent snapshots (+ {prime} training iterations of set-up)"),
+                       "step_graph": bool(getattr(runner, "use_step_graph", False)),
                        "parallelism": (f"x{world}: PE history, FFT filter and update_pe sharded by node owner (id % {world}); gather / dense tail / loss "
                                        f"on each rank's {B}-edge slice of the global batch; RCCL all-gather of updated PE rows") if use_dist
                                       else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "lstep::gather_aggregate_fwd_kernel<true, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
+                         "launch_ms": avg_ms, "launch_timing": timing_note, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
                          "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and not args.zipf:

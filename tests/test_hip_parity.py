@@ -1217,7 +1217,7 @@ def test_graphed_train_step_matches_eager_iterations(hip, B, N):
         model.train()
         eng = hip.LstepEngine(model[0], model[1], K, 2000)
         eng.use_step_graph = graphed
-        opt = FusedAdam(model.parameters(), lr=1e-3)
+        opt = FusedAdam(model.parameters(), lr=1e-4)      # the reference's learning rate (utils/load_configs.py:45)
         stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
         init = torch.from_numpy(synth.make_initial_pe(N, seed=84)).to(DEV)
         tables, losses, preds = [], [], []
@@ -1240,8 +1240,8 @@ def test_graphed_train_step_matches_eager_iterations(hip, B, N):
                     eng.ring.as_reference_tensor().cpu().numpy()))
     (ta, la, pa, wa, ha), (tb, lb, pb, wb, hb) = res
     np.testing.assert_allclose(la, lb, rtol=0, atol=5e-6)
-    np.testing.assert_allclose(pa, pb, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=5e-5)
     np.testing.assert_allclose(ta, tb, rtol=0, atol=5e-5)
     np.testing.assert_allclose(ha, hb, rtol=0, atol=5e-5)
     d = np.abs(wa - wb)      # Adam turns rounding-level gradient differences into +-lr steps on single elements
-    assert float(d.max()) <= 3e-2 and float((d > 5e-4).mean()) <= 2e-3
+    assert float(d.max()) <= 3e-3 and float((d > 5e-5).mean()) <= 2e-3
