@@ -243,6 +243,11 @@ class _TailWeightsGraph:
         if torch.cuda.is_current_stream_capturing():
             # the whole iteration is being captured (engine.GraphedTrainStep): no graph inside a graph, the ~25 launches are recorded
             # as they are; the fixed gradient buffers and the deferred backward keep working
+            pre = self.__dict__.pop("_cap_prepared", None)
+            if pre is not None:        # issued ahead of time on the auxiliary stream (``prepare``): a parallel branch of the graph
+                outs, transposed, self._cap_saved, ready = pre
+                torch.cuda.current_stream().wait_event(ready)
+                return outs, transposed
             with torch.no_grad():
                 outs, transposed, self._cap_saved = _tail_weights_forward(self.dims, *self._detached())
             return outs, transposed
@@ -264,8 +269,17 @@ class _TailWeightsGraph:
 
     def prepare(self, aux):
         """Replay the forward graph on ``aux`` now (it only depends on the parameters); the next ``forward()`` waits for it."""
-        if (self.g_fwd is None or tuple(p.data_ptr() for p in self.params) != self.ptrs or self.live > 0
-                or torch.cuda.is_current_stream_capturing()):
+        if torch.cuda.is_current_stream_capturing():
+            if self.live > 0:
+                return
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux), torch.no_grad():
+                outs, transposed, saved = _tail_weights_forward(self.dims, *self._detached())
+                ready = torch.cuda.Event()
+                ready.record()
+            self._cap_prepared = (outs, transposed, saved, ready)
+            return
+        if self.g_fwd is None or tuple(p.data_ptr() for p in self.params) != self.ptrs or self.live > 0:
             return
         aux.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(aux):
