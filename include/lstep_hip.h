@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 23
+#define LSTEP_ABI_VERSION 24
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -169,6 +169,8 @@ int lstep_history_filter_runs_fwd(const float* hist, int64_t node_stride, int64_
  * positional_encoding[:, -1][batch nodes] = filtered rows of train_LSTEP_link_prediction.py:230 -- and slot_of[node_ids[u]] = u.) */
 /* out_partial [lstep_history_filter_bwd_chunks(num_ids), t_len, P] holds per-chunk DIFFERENCE sums; the caller adds them over dim 0 and
  * passes the [t_len, P] result to lstep_history_filter_runs_finish, which turns it into d(coef) (running sums in float64). */
+/* rows of out_partial for lstep_history_filter_runs_bwd: [lstep_history_filter_runs_bwd_chunks(num_ids, t_len), t_len, P] */
+int64_t lstep_history_filter_runs_bwd_chunks(int64_t num_ids, int32_t t_len);
 int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                   int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                   const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial,

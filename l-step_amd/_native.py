@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 23
+ABI_VERSION = 24
 BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
 
 
@@ -88,6 +88,7 @@ SIGNATURES = {
     "lstep_history_filter_runs_workspace": (_I64, [_I32, _I32]),
     "lstep_history_filter_runs_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _P,
                                                C.POINTER(RingRef), _P]),
+    "lstep_history_filter_runs_bwd_chunks": (_I64, [_I64, _I32]),
     "lstep_history_filter_runs_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _P, _I64, _P, _P, C.POINTER(RingRef), _P]),
     "lstep_copy_rows": (C.c_int, [_P, _P, _I32, _I64, _P, _I64, _I64, C.POINTER(RingRef), _P]),
     "lstep_history_advance_oldest": (C.c_int, [_P, _P, _I32, _I64, _P, _I32, _I32, _I64, C.POINTER(RingRef), _P]),

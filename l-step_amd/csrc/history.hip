@@ -288,16 +288,17 @@ constexpr int kRunsTimeGroup = 16;   // snapshots per wave of the backward pass:
 // run begins s of the group (the group's first snapshot counts as a run begin with "previous row" = 0), zero elsewhere.
 __global__ __launch_bounds__(kBlock) void history_filter_runs_bwd_kernel(HistView h, int t_len, int P, const uint32_t* __restrict__ mask, int words,
                                                                           const int64_t* __restrict__ ids, int64_t num_ids,
-                                                                          const float* __restrict__ grad, float* __restrict__ partial, int groups) {
+                                                                          const float* __restrict__ grad, float* __restrict__ partial, int groups,
+                                                                          int nodes_per_chunk) {
     const int lane = lane_id();
     h.resolve();
     const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t chunk = w / groups;
     const int grp = (int)(w - chunk * groups);
-    const int64_t u0 = chunk * kBwdNodesPerChunk;
+    const int64_t u0 = chunk * nodes_per_chunk;
     if (u0 >= num_ids) return;
     const int s0 = grp * kRunsTimeGroup;
-    const int64_t u1 = (u0 + kBwdNodesPerChunk < num_ids) ? u0 + kBwdNodesPerChunk : num_ids;
+    const int64_t u1 = (u0 + nodes_per_chunk < num_ids) ? u0 + nodes_per_chunk : num_ids;
     const bool active = lane < (P >> 2);
     const int col = active ? lane * 4 : 0;
     float4 acc[kRunsTimeGroup];
@@ -545,6 +546,22 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
     return check_launch("history_filter_runs_fwd_kernel");
 }
 
+// Nodes per wave of the run backward: 128 when there are enough nodes to fill the chip (1 M-node workload: 32 768 batch nodes -> 1 792 waves),
+// fewer for small batches -- a wave walks its nodes one after the other, a few dependent row loads each, so 400 nodes in 4 chunks of
+// 128 took 250 us (28 waves on 1 024 SIMDs) where 8-node chunks take 20.
+static int runs_bwd_nodes_per_chunk(int64_t num_ids, int32_t t_len) {
+    const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
+    int per = kBwdNodesPerChunk;
+    while (per > 4 && ((num_ids + per - 1) / per) * groups < 1024) per >>= 1;
+    return per;
+}
+
+extern "C" int64_t lstep_history_filter_runs_bwd_chunks(int64_t num_ids, int32_t t_len) {
+    if (num_ids <= 0 || t_len <= 0) return 0;
+    const int per = runs_bwd_nodes_per_chunk(num_ids, t_len);
+    return (num_ids + per - 1) / per;
+}
+
 extern "C" int lstep_history_filter_runs_bwd(const float* hist, int64_t node_stride, int64_t time_stride, int32_t time_slots, int32_t time_rot,
                                              int32_t t_len, int32_t pe_dim, const uint32_t* mask, int32_t mask_words, const float* oldest,
                                              const int64_t* node_ids, int64_t num_ids, const float* grad_out, float* out_partial,
@@ -558,10 +575,11 @@ extern "C" int lstep_history_filter_runs_bwd(const float* hist, int64_t node_str
     HistView h{hist, node_stride, time_stride, time_slots, time_rot, oldest};
     if (ring) { h.rot_dev = ring->start; h.rot_add = ring->add; }
     const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
-    const int64_t waves = lstep_history_filter_bwd_chunks(num_ids) * groups;
+    const int per = runs_bwd_nodes_per_chunk(num_ids, t_len);
+    const int64_t waves = ((num_ids + per - 1) / per) * groups;
     const unsigned grid = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(history_filter_runs_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, h, (int)t_len, (int)pe_dim, mask,
-                       (int)mask_words, node_ids, num_ids, grad_out, out_partial, groups);
+                       (int)mask_words, node_ids, num_ids, grad_out, out_partial, groups, per);
     return check_launch("history_filter_runs_bwd_kernel");
 }
 

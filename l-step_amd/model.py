@@ -943,7 +943,7 @@ class _HistoryFilter(torch.autograd.Function):
         U = ids.numel()
         g_coef = torch.zeros(ctx.coef_shape, dtype=torch.float32, device=ids.device)
         if ctx.needs_input_grad[0] and t_len > 0 and U > 0:
-            chunks = int(lib.lstep_history_filter_bwd_chunks(U))
+            chunks = int(lib.lstep_history_filter_bwd_chunks(U) if mask is None else lib.lstep_history_filter_runs_bwd_chunks(U, t_len))
             partial = torch.empty((chunks, t_len, P), dtype=torch.float32, device=ids.device)
             g = g_out.contiguous()
             with torch.cuda.device(ids.device):

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--marker", default="gather_aggregate_fwd_kernel")
     ap.add_argument("--last", type=int, default=0, help="use only the last N iterations (the bench's history pre-roll runs up to T evaluation "
                     "iterations before the training steps)")
+    ap.add_argument("--count", type=int, default=0, help="use only this many iterations after --skip")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -37,6 +38,8 @@ def main():
         a.skip = max(a.skip, len(marks) - 1 - a.last)
     lo, hi = marks[a.skip], marks[-1]
     n_iter = len(marks) - 1 - a.skip
+    if a.count and a.count < n_iter:
+        hi, n_iter = marks[a.skip + a.count], a.count
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in rows[lo:hi]:
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
