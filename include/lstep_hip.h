@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 24
+#define LSTEP_ABI_VERSION 25
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -60,6 +60,7 @@ int lstep_ring_tick(int32_t* start, int32_t slots, void* stream);
 /* Branch selection for lstep_gather_aggregate_fwd/bwd */
 #define LSTEP_BRANCH_EDGE_NODE 1u /* A + N: models/LSTEP.py:147-158,177-211 */
 #define LSTEP_BRANCH_PE 2u        /* C:     models/LSTEP.py:223-238 */
+#define LSTEP_WEIGHTED_SUM 4u     /* with LSTEP_BRANCH_EDGE_NODE: the `weighted_sum` ablation of the node channel, models/LSTEP.py:190-206 */
 
 int lstep_abi_version(void);
 const char* lstep_last_error(void);
@@ -119,6 +120,27 @@ int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* edge_raw, in
                                const float* grad_edge, const float* grad_pe_agg, const float* grad_self,
                                int32_t ld_edge, int32_t ld_pe, int32_t ld_self, const int32_t* slot_of,
                                float* out_slot_dot, float* grad_pe_rows, int32_t* out_hits, void* stream);
+
+/* The gather stage on EXPLICIT neighbourhoods, for the RNG-defined sampling strategies ('uniform', 'time_interval_aware':
+ * utils/utils.py:175-198), whose draws are defined by numpy's RandomState call order and therefore made on the host
+ * (lstep_amd.sampler.NeighborSampler._sample_random_host).  The reference draws three independent neighbourhoods per
+ * combining_pe_raw_feat call (models/LSTEP.py:147 K slots, :177 time_gap slots, :223 K slots again), so each call serves ONE branch:
+ *   LSTEP_BRANCH_EDGE_NODE  nbr / eid / nt [batch, K] for the edge channel, nbr_gap (and nt_gap with LSTEP_WEIGHTED_SUM) [batch, time_gap]
+ *   LSTEP_BRANCH_PE         nbr / nt [batch, K]
+ * lists exactly as get_historical_neighbors returned them (int64 ids, float32 times; padding slots are id 0 and gather row 0 like any
+ * id).  num_rows = rows of the node / PE tables (bound of the self-row lookups).  Outputs as lstep_gather_aggregate_fwd.
+ * lstep_gather_explicit_bwd: as lstep_gather_aggregate_bwd on the same lists, one channel per call. */
+int lstep_gather_explicit_fwd(const float* node_raw, const float* edge_raw, const float* pe, int32_t feat_dim, int32_t pe_dim,
+                              const float* time_w, const float* time_b, int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids,
+                              const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap, uint32_t branches,
+                              const int64_t* nbr, const int64_t* eid, const float* nt, const int64_t* nbr_gap, const float* nt_gap,
+                              int64_t num_rows, float* out_edge, float* out_node, float* out_pe, float* out_self, int32_t ld_edge,
+                              int32_t ld_node, int32_t ld_pe, int32_t ld_self, void* stream);
+int lstep_gather_explicit_bwd(const float* edge_raw, int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                              int32_t time_dim, const int64_t* node_ids, const double* times, int64_t batch, int32_t num_neighbors,
+                              const int64_t* nbr, const int64_t* eid, const float* nt, int64_t num_rows, const float* grad_edge,
+                              const float* grad_pe_agg, const float* grad_self, int32_t ld_edge, int32_t ld_pe, int32_t ld_self,
+                              const int32_t* slot_of, float* out_slot_dot, float* grad_pe_rows, int32_t* out_hits, void* stream);
 
 /* F -- the linear core of fourier_transform_pe (models/LSTEP.py:104-137).  fft -> mask -> filter -> mask ->
  * ifft -> mask -> real part -> fft_agg is linear in the history, so for fixed weights it is a [T, P] real

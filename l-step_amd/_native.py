@@ -19,8 +19,8 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 24
-BRANCH_EDGE_NODE, BRANCH_PE = 1, 2
+ABI_VERSION = 25
+BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
 class LstepNativeError(RuntimeError):
@@ -79,6 +79,10 @@ SIGNATURES = {
                                              _I32, _U32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "lstep_gather_aggregate_bwd": (C.c_int, [C.POINTER(CsrStruct), _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32, _P, _P, _P,
                                              _I32, _I32, _I32, _P, _P, _P, _P, _P]),
+    "lstep_gather_explicit_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P, _P, _P, _P, _P, _I64,
+                                           _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "lstep_gather_explicit_bwd": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _I64, _I32, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32,
+                                           _P, _P, _P, _P, _P]),
     "lstep_history_filter_fwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),
     "lstep_history_filter_bwd_chunks": (_I64, [_I64]),
     "lstep_history_filter_bwd": (C.c_int, [_P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P, _P, _P]),

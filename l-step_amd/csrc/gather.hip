@@ -30,6 +30,14 @@ struct GatherParams {
     float* out_self;
     int32_t* out_count;
     int ld_edge, ld_node, ld_pe, ld_self;  // row strides (floats) of the four outputs; padding columns up to the next multiple of 16 are zeroed
+    // explicit neighbourhoods (kExplicit kernels: RNG-defined sampling strategies, utils/utils.py:175-198, drawn on the host): the K slots
+    // of every row for the edge / PE branch and the time_gap slots for the node branch, exactly as get_historical_neighbors returned them
+    const int64_t* ex_nbr;    // [batch, K]
+    const int64_t* ex_eid;    // [batch, K]  (edge branch)
+    const float* ex_nt;       // [batch, K]  float32 neighbour times
+    const int64_t* ex_nbr_g;  // [batch, G]  (node branch)
+    const float* ex_nt_g;     // [batch, G]  (node branch with weighted_sum)
+    int weighted_sum;         // models/LSTEP.py:190-206: node rows weighted by exp(-(t - neighbour time)), normalised over the row's distinct times
 };
 
 // zero the padding columns of one output row: [width, width rounded up to 16), clipped to the row stride.  A stride wider than that
@@ -43,7 +51,7 @@ __device__ __forceinline__ void zero_tail(float* row, int width, int ld, int lan
 constexpr int kRowsInFlight = 8;      // edge rows + PE rows per group (2 x 8 loads in flight per wave)
 constexpr int kNodeRowsInFlight = 8;  // node rows per group
 
-template <bool kEdgeNode, bool kPe>
+template <bool kEdgeNode, bool kPe, bool kExplicit = false>
 __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherParams p) {
     const int lane = lane_id();
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -55,11 +63,12 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
     const double t = p.times[row];
     int64_t lo = 0, cnt = 0;
     const bool in_range = node >= 0 && node < p.csr.num_rows;
-    if (in_range) {
+    if (in_range && !kExplicit) {
         lo = p.csr.indptr[node];
         cnt = wave_count_before(p.csr.ts, lo, p.csr.indptr[node + 1], t, lane);
     }
-    const int k = (int)(cnt < K ? cnt : K);
+    // explicit lists: every slot is given (padding slots carry neighbour id 0 and gather row 0 like any other id)
+    const int k = kExplicit ? K : (int)(cnt < K ? cnt : K);
     const int npad = K - k;
     const int64_t kfirst = lo + cnt - k;
 
@@ -74,10 +83,17 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         int nb = 0, ed = 0;
         float dt = 0.f, aw = 0.f;
         if (lane < m) {
-            const int64_t e = kfirst + c0 + lane;
-            nb = p.csr.nbr[e];
-            ed = p.csr.eid[e];
-            dt = delta_t(t, p.csr.ts[e]);
+            if (kExplicit) {
+                const int64_t e = row * K + c0 + lane;
+                nb = (int)p.ex_nbr[e];
+                if (kEdgeNode) ed = (int)p.ex_eid[e];
+                dt = (float)(t - (double)p.ex_nt[e]);
+            } else {
+                const int64_t e = kfirst + c0 + lane;
+                nb = p.csr.nbr[e];
+                ed = p.csr.eid[e];
+                dt = delta_t(t, p.csr.ts[e]);
+            }
             if (kEdgeNode) aw = p.edge_agg_w[npad + c0 + lane];
         }
         // Settle the slot metadata BEFORE the row loop: otherwise hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front
@@ -146,15 +162,55 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         zero_tail(oe, D + F, p.ld_edge, lane);
 
         // node channel: the last v = min(cnt, G) interactions; score 1/valid on ids > 0, then mean over G slots
-        const int64_t v = cnt < p.G ? cnt : p.G;
+        const int64_t v = kExplicit ? (int64_t)p.G : (cnt < p.G ? cnt : p.G);
         const int64_t vfirst = lo + cnt - v;
+        // weighted_sum (models/LSTEP.py:190-206): every slot's node row is also scaled by w = clamp(e(time) / sum of e over the row's
+        // DISTINCT non-zero neighbour times, 0, 1), e(x) = exp(-(t - x)) in float64; x is what scatter_mean makes of the slot's float32 time
+        // (the sequential float32 sum of the c slots that share it, divided by c).  First pass: the denominator.
+        double wden = 1.0;
+        if (p.weighted_sum) {
+            double part = 0.0;
+            for (int64_t c0 = 0; c0 < v; c0 += kWave) {
+                const int64_t s = c0 + lane;
+                if (s < v) {
+                    const float ts = kExplicit ? p.ex_nt_g[row * (int64_t)p.G + s] : (float)p.csr.ts[vfirst + s];
+                    // one term per distinct time: counted at the FIRST slot of its run (slots are time-sorted in both sampling modes)
+                    const float prev = s > 0 ? (kExplicit ? p.ex_nt_g[row * (int64_t)p.G + s - 1] : (float)p.csr.ts[vfirst + s - 1]) : 0.f;
+                    if ((s == 0 || prev != ts) && ts != 0.f) {
+                        int c = 1;
+                        while (s + c < v && (kExplicit ? p.ex_nt_g[row * (int64_t)p.G + s + c] : (float)p.csr.ts[vfirst + s + c]) == ts) ++c;
+                        float sum = 0.f;
+                        for (int i = 0; i < c; ++i) sum += ts;
+                        const float mean = sum / (float)c;
+                        if (mean != 0.f) part += exp(-(t - (double)mean));
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, kWave);
+            wden = part + (part == 0.0 ? 1.0 : 0.0);
+        }
         float4 accN = make_float4(0.f, 0.f, 0.f, 0.f);
         int valid = 0;
         for (int64_t c0 = 0; c0 < v; c0 += kWave) {
             const int m = (int)((v - c0) < kWave ? (v - c0) : kWave);
-            const int idx = lane < m ? p.csr.nbr[vfirst + c0 + lane] : 0;
+            const int idx = lane < m ? (kExplicit ? (int)p.ex_nbr_g[row * (int64_t)p.G + c0 + lane] : p.csr.nbr[vfirst + c0 + lane]) : 0;
+            float wslot = 1.f;
+            if (p.weighted_sum && lane < m) {
+                const int64_t s = c0 + lane;
+                const float ts = kExplicit ? p.ex_nt_g[row * (int64_t)p.G + s] : (float)p.csr.ts[vfirst + s];
+                int64_t a = s, b = s;       // the run of slots that share this time
+                while (a > 0 && (kExplicit ? p.ex_nt_g[row * (int64_t)p.G + a - 1] : (float)p.csr.ts[vfirst + a - 1]) == ts) --a;
+                while (b + 1 < v && (kExplicit ? p.ex_nt_g[row * (int64_t)p.G + b + 1] : (float)p.csr.ts[vfirst + b + 1]) == ts) ++b;
+                float sum = 0.f;
+                for (int64_t i = a; i <= b; ++i) sum += ts;
+                const float mean = sum / (float)(b - a + 1);
+                double w = mean != 0.f ? exp(-(t - (double)mean)) / wden : 0.0;
+                w = w < 0.0 ? 0.0 : (w > 1.0 ? 1.0 : w);
+                wslot = (float)w;
+            }
             valid += __popcll(__ballot(idx > 0));
-            settle(idx);
+            settle(idx ^ __float_as_int(wslot));
             for (int j = 0; j < m; j += kNodeRowsInFlight) {
                 int64_t nj[kNodeRowsInFlight];
                 float lj[kNodeRowsInFlight];
@@ -163,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
                     const bool live = (j + u) < m;
                     const int r = bcast_i32(idx, live ? (j + u) : (m - 1));
                     nj[u] = r > 0 ? r : 0;
-                    lj[u] = (live && r > 0) ? 1.f : 0.f;
+                    lj[u] = (live && r > 0) ? bcast_f32(wslot, live ? (j + u) : (m - 1)) : 0.f;
                 }
                 if (fa) {
                     float4 rn[kNodeRowsInFlight];
@@ -180,10 +236,10 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             if (valid > 0) {
                 const float s = (1.0f / (float)valid) / (float)p.G;
                 r0 = make_float4(accN.x * s, accN.y * s, accN.z * s, accN.w * s);
-            } else {  // all slots padded: softmax is uniform 1/G over G copies of row 0, then /G again
+            } else if (!p.weighted_sum) {  // all slots padded: softmax is uniform 1/G over G copies of row 0, then /G again
                 const float4 z = ld4(p.node_raw + lane * 4);
                 r0 = make_float4(z.x * invG, z.y * invG, z.z * invG, z.w * invG);
-            }
+            }    // (weighted_sum: every slot's time is 0 -> every weight is 0)
             float4 self = make_float4(0.f, 0.f, 0.f, 0.f);
             if (in_range) self = ld4(p.node_raw + node * F + lane * 4);
             st4(p.out_node + row * (int64_t)p.ld_node + lane * 4, make_float4(r0.x + self.x, r0.y + self.y, r0.z + self.z, r0.w + self.w));
@@ -199,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         zero_tail(op, P + D, p.ld_pe, lane);
         zero_tail(p.out_self + row * (int64_t)p.ld_self, P, p.ld_self, lane);
     }
-    if (p.out_count != nullptr && lane == 0) p.out_count[row] = (int32_t)cnt;
+    if (p.out_count != nullptr && lane == 0) p.out_count[row] = kExplicit ? K : (int32_t)cnt;
 }
 
 struct GatherBwdParams {
@@ -221,6 +277,9 @@ struct GatherBwdParams {
     float* grad_pe_rows;
     int32_t* out_hits;  // [B, K]: spliced-row index of every slot's neighbour (or -1); when set, no atomics are issued
     int ld_edge, ld_pe, ld_self;  // row strides (floats) of grad_edge / grad_pe_agg / grad_self
+    const int64_t* ex_nbr;        // explicit neighbourhoods (kExplicit): [batch, K] ids, edge ids, float32 times of the slots
+    const int64_t* ex_eid;
+    const float* ex_nt;
 };
 
 // atomically add a P-wide gradient row held as g[i] = elements lane + 64*i (contiguous dwords per wave-instruction)
@@ -232,6 +291,7 @@ __device__ __forceinline__ void atomic_add_row(float* dst, const float g[4], int
     }
 }
 
+template <bool kExplicit = false>
 __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdParams p) {
     const int lane = lane_id();
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -241,9 +301,9 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
     const int64_t node = p.node_ids[row];
     const bool in_range = node >= 0 && node < p.csr.num_rows;
     const double t = p.times[row];
-    const int64_t cnt = in_range ? p.count[row] : 0;
-    const int64_t lo = in_range ? p.csr.indptr[node] : 0;
-    const int k = (int)(cnt < K ? cnt : K);
+    const int64_t cnt = (in_range && !kExplicit) ? p.count[row] : 0;
+    const int64_t lo = (in_range && !kExplicit) ? p.csr.indptr[node] : 0;
+    const int k = kExplicit ? K : (int)(cnt < K ? cnt : K);
     const int npad = K - k;
     const int64_t kfirst = lo + cnt - k;
     const bool do_edge = p.grad_edge != nullptr && p.out_slot_dot != nullptr;
@@ -270,10 +330,17 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
         int nb = 0, ed = 0;
         float dt = 0.f;
         if (lane < m) {
-            const int64_t e = kfirst + c0 + lane;
-            nb = p.csr.nbr[e];
-            ed = p.csr.eid[e];
-            dt = delta_t(t, p.csr.ts[e]);
+            if (kExplicit) {
+                const int64_t e = row * K + c0 + lane;
+                nb = (int)p.ex_nbr[e];
+                ed = p.ex_eid ? (int)p.ex_eid[e] : 0;
+                dt = (float)(t - (double)p.ex_nt[e]);
+            } else {
+                const int64_t e = kfirst + c0 + lane;
+                nb = p.csr.nbr[e];
+                ed = p.csr.eid[e];
+                dt = delta_t(t, p.csr.ts[e]);
+            }
         }
         if (do_edge) {
             float mine = 0.f;  // lane j keeps the dot product of slot c0 + j
@@ -379,13 +446,49 @@ extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* n
     if (ld_self == 0) ld_self = pe_dim;
     if (int rc = check_ld("lstep_gather_aggregate_fwd", ld_edge, time_dim + feat_dim, ld_node, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
     GatherParams p{*csr, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
-                   batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, out_count, ld_edge, ld_node, ld_pe, ld_self};
+                   batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, out_count, ld_edge, ld_node, ld_pe, ld_self,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
     if (en && pb) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true>), grid, block, 0, s, p);
     else if (en) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true>), grid, block, 0, s, p);
     return check_launch("gather_aggregate_fwd_kernel");
+}
+
+// The gather stage on EXPLICIT neighbourhoods: one branch per call, the slots exactly as a sampler returned them (the RNG-defined
+// strategies of utils/utils.py:175-198 draw three independent neighbourhoods per combining_pe_raw_feat call: K slots for the edge
+// channel, time_gap slots for the node channel, K slots for the PE channel -- models/LSTEP.py:147,177,223).
+extern "C" int lstep_gather_explicit_fwd(const float* node_raw, const float* edge_raw, const float* pe, int32_t feat_dim, int32_t pe_dim,
+                                         const float* time_w, const float* time_b, int32_t time_dim, const float* edge_agg_w,
+                                         const int64_t* node_ids, const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap,
+                                         uint32_t branches, const int64_t* nbr, const int64_t* eid, const float* nt, const int64_t* nbr_gap,
+                                         const float* nt_gap, int64_t num_rows, float* out_edge, float* out_node, float* out_pe,
+                                         float* out_self, int32_t ld_edge, int32_t ld_node, int32_t ld_pe, int32_t ld_self, void* stream) {
+    if (num_neighbors <= 0 || time_gap <= 0)
+        return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
+    if (int rc = check_dims("lstep_gather_explicit_fwd", feat_dim, pe_dim, time_dim)) return rc;
+    const bool en = branches & LSTEP_BRANCH_EDGE_NODE, pb = branches & LSTEP_BRANCH_PE;
+    if (en == pb) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_fwd: exactly one branch per call (their neighbourhoods differ)");
+    if (batch < 0 || num_rows <= 0) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_fwd: bad sizes");
+    if (batch == 0) return LSTEP_OK;
+    if (!time_w || !time_b || !node_ids || !times || !nbr || !nt) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_fwd: NULL pointer");
+    if (en && (!node_raw || !edge_raw || !edge_agg_w || !out_edge || !out_node || !eid || !nbr_gap || ((branches & LSTEP_WEIGHTED_SUM) && !nt_gap)))
+        return set_error(LSTEP_EINVAL, "lstep_gather_explicit_fwd: edge/node branch needs tables, edge ids, the time_gap list and both outputs");
+    if (pb && (!pe || !out_pe || !out_self)) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_fwd: PE branch needs pe, out_pe, out_self");
+    if (ld_edge == 0) ld_edge = time_dim + feat_dim;
+    if (ld_node == 0) ld_node = feat_dim;
+    if (ld_pe == 0) ld_pe = pe_dim + time_dim;
+    if (ld_self == 0) ld_self = pe_dim;
+    if (int rc = check_ld("lstep_gather_explicit_fwd", ld_edge, time_dim + feat_dim, ld_node, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
+    lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0};   // (only num_rows is read: the bound of the self-row lookups)
+    GatherParams p{none, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
+                   batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, nullptr, ld_edge, ld_node, ld_pe, ld_self,
+                   nbr, eid, nt, nbr_gap, nt_gap, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0};
+    const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    if (en) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true, true>), grid, block, 0, (hipStream_t)stream, p);
+    return check_launch("gather_aggregate_fwd_kernel<explicit>");
 }
 
 extern "C" int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* edge_raw, int32_t feat_dim, int32_t pe_dim,
@@ -408,8 +511,36 @@ extern "C" int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* e
     if (ld_self == 0) ld_self = pe_dim;
     if (int rc = check_ld("lstep_gather_aggregate_bwd", ld_edge, time_dim + feat_dim, feat_dim, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
     GatherBwdParams p{*csr, edge_raw, feat_dim, pe_dim, time_dim, time_w, time_b, node_ids, times, count, batch, num_neighbors,
-                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows, out_hits, ld_edge, ld_pe, ld_self};
+                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows, out_hits, ld_edge, ld_pe, ld_self,
+                      nullptr, nullptr, nullptr};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
-    hipLaunchKernelGGL(gather_aggregate_bwd_kernel, grid, block, 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gather_aggregate_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
     return check_launch("gather_aggregate_bwd_kernel");
+}
+
+// Backward of lstep_gather_explicit_fwd on the same slot lists: call it once with the edge channel's list (grad_edge -> out_slot_dot) and once
+// with the PE channel's list (grad_pe_agg / grad_self -> grad_pe_rows or out_hits).
+extern "C" int lstep_gather_explicit_bwd(const float* edge_raw, int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                                         int32_t time_dim, const int64_t* node_ids, const double* times, int64_t batch, int32_t num_neighbors,
+                                         const int64_t* nbr, const int64_t* eid, const float* nt, int64_t num_rows, const float* grad_edge,
+                                         const float* grad_pe_agg, const float* grad_self, int32_t ld_edge, int32_t ld_pe, int32_t ld_self,
+                                         const int32_t* slot_of, float* out_slot_dot, float* grad_pe_rows, int32_t* out_hits, void* stream) {
+    if (num_neighbors <= 0) return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
+    if (int rc = check_dims("lstep_gather_explicit_bwd", feat_dim, pe_dim, time_dim)) return rc;
+    if (batch < 0 || num_rows <= 0) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_bwd: bad sizes");
+    if (batch == 0) return LSTEP_OK;
+    if (!time_w || !time_b || !node_ids || !times || !nbr || !nt) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_bwd: NULL pointer");
+    if (grad_edge && (!edge_raw || !out_slot_dot || !eid)) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_bwd: grad_edge needs edge_raw, edge ids and out_slot_dot");
+    if ((grad_pe_agg || grad_self) && !grad_pe_rows && !out_hits) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_bwd: PE gradients need grad_pe_rows or out_hits");
+    if (out_hits && !slot_of) return set_error(LSTEP_EINVAL, "lstep_gather_explicit_bwd: out_hits needs slot_of");
+    if (ld_edge == 0) ld_edge = time_dim + feat_dim;
+    if (ld_pe == 0) ld_pe = pe_dim + time_dim;
+    if (ld_self == 0) ld_self = pe_dim;
+    if (int rc = check_ld("lstep_gather_explicit_bwd", ld_edge, time_dim + feat_dim, feat_dim, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
+    lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0};
+    GatherBwdParams p{none, edge_raw, feat_dim, pe_dim, time_dim, time_w, time_b, node_ids, times, nullptr, batch, num_neighbors,
+                      grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows, out_hits, ld_edge, ld_pe, ld_self, nbr, eid, nt};
+    const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    hipLaunchKernelGGL(gather_aggregate_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    return check_launch("gather_aggregate_bwd_kernel<explicit>");
 }

@@ -639,7 +639,7 @@ class LstepEngine:
             cur, spliced = self._splice(batch_nodes, batch_idx, live=n_live)
             n = src.numel()
             ids3 = torch.cat([src, dst, neg_dst])
-            emb_p = bb.combining_pe_raw_feat(cur, ids3, torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced, padded=True)
+            emb_p = bb.combining_pe_raw_feat(cur, ids3, torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced, padded=True, row_blocks=3)
             emb = emb_p[:, :bb.feat_dim]
             pos_src = emb[:n]
             # both predictor calls of train:254-255 in one launch: rows [pos_src | pos_dst] and [pos_src | neg_dst] (neg_src = pos_src, train:245)
@@ -753,7 +753,8 @@ class LstepEngine:
         cur, _ = self._splice(batch_nodes, batch_idx, live=n_live)
         self.slot_of.index_fill_(0, batch_nodes, -1)
         n = src.numel()
-        emb_p = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_src, neg_dst]), torch.cat([ts, ts, ts, ts]), self.K, self.G, padded=True)
+        emb_p = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_src, neg_dst]), torch.cat([ts, ts, ts, ts]), self.K, self.G, padded=True,
+                                         row_blocks=4)
         if self.predictor.fused_ok(emb_p):      # both predictor calls of evaluate_model_utils.py:100-101 in one launch, no concatenation
             predicts = self.predictor.pair_logits(emb_p, n, (0, n, 2 * n, 3 * n)).sigmoid().clamp(0, 1)
         else:

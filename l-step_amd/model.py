@@ -735,7 +735,7 @@ class _GatherAggregate(torch.autograd.Function):
     16-aligned K: hipBLASLt runs 176-wide fp32 GEMMs up to 2.5x faster than 172-wide ones (tools/gemm_shapes.py)."""
 
     @staticmethod
-    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False, self_groups=None):
+    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False, self_groups=None, explicit=None):
         lib = nat.load_library()
         dev = ids.device
         B = ids.numel()
@@ -764,16 +764,35 @@ class _GatherAggregate(torch.autograd.Function):
         if sink is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        ws_flag = nat.WEIGHTED_SUM if (en and mod.weighted_sum) else 0
         with torch.cuda.device(dev):
-            nat.check(lib.lstep_gather_aggregate_fwd(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
-                                                     Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
-                                                     int(K), int(G), int(branches), nat.ptr(out_edge), nat.ptr(out_node), nat.ptr(out_pe),
-                                                     nat.ptr(out_self), mod.ld_edge, ld_node, mod.ld_pe, ld_self, nat.ptr(count),
-                                                     nat.current_stream()))
+            if explicit is None:
+                nat.check(lib.lstep_gather_aggregate_fwd(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
+                                                         Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
+                                                         int(K), int(G), int(branches) | ws_flag, nat.ptr(out_edge), nat.ptr(out_node),
+                                                         nat.ptr(out_pe), nat.ptr(out_self), mod.ld_edge, ld_node, mod.ld_pe, ld_self,
+                                                         nat.ptr(count), nat.current_stream()))
+            else:
+                # explicit neighbourhoods (RNG-defined sampling): one launch per channel, each on its own draw
+                l1, lg, l3 = explicit
+                num_rows = int(mod.node_raw_features.shape[0])
+                if en:
+                    nat.check(lib.lstep_gather_explicit_fwd(nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), None, Fd, P, nat.ptr(tw),
+                                                            nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B, int(K), int(G),
+                                                            nat.BRANCH_EDGE_NODE | ws_flag, nat.ptr(l1[0]), nat.ptr(l1[1]), nat.ptr(l1[2]),
+                                                            nat.ptr(lg[0]), nat.ptr(lg[2]), num_rows, nat.ptr(out_edge), nat.ptr(out_node), None, None,
+                                                            mod.ld_edge, ld_node, mod.ld_pe, ld_self, nat.current_stream()))
+                if pb:
+                    nat.check(lib.lstep_gather_explicit_fwd(None, None, nat.ptr(pe_c), Fd, P, nat.ptr(tw), nat.ptr(tb), D, None, nat.ptr(ids),
+                                                            nat.ptr(times), B, int(K), int(G), nat.BRANCH_PE, nat.ptr(l3[0]), None, nat.ptr(l3[2]),
+                                                            None, None, num_rows, None, None, nat.ptr(out_pe), nat.ptr(out_self), mod.ld_edge,
+                                                            ld_node, mod.ld_pe, ld_self, nat.current_stream()))
+                count.fill_(int(K))
         if sink is not None:
             e1.record()
             sink.append((e0, e1, count))
         ctx.mod, ctx.sampler, ctx.K, ctx.branches, ctx.ld_self, ctx.self_groups = mod, s, int(K), int(branches), ld_self, self_groups
+        ctx.explicit = explicit
         ctx.pe_shape = tuple(pe.shape) if pe is not None else None
         ctx.rows_shape = tuple(rows.shape) if rows is not None else None
         ctx.save_for_backward(ids, times, count, slot_of if slot_of is not None else torch.empty(0, device=dev))
@@ -807,7 +826,21 @@ class _GatherAggregate(torch.autograd.Function):
             else:
                 grad_rows = torch.zeros(ctx.pe_shape, dtype=torch.float32, device=dev)
         tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
-        if g_edge is not None or grad_rows is not None or hits is not None:
+        if ctx.explicit is not None and (g_edge is not None or grad_rows is not None or hits is not None):
+            l1, lg, l3 = ctx.explicit
+            num_rows = int(mod.node_raw_features.shape[0])
+            with torch.cuda.device(dev):
+                if g_edge is not None:       # edge channel on ITS draw
+                    nat.check(lib.lstep_gather_explicit_bwd(nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(ids),
+                                                            nat.ptr(times), B, K, nat.ptr(l1[0]), nat.ptr(l1[1]), nat.ptr(l1[2]), num_rows,
+                                                            nat.ptr(g_edge), None, None, mod.ld_edge, mod.ld_pe, ctx.ld_self, None,
+                                                            nat.ptr(slot_dot), None, None, nat.current_stream()))
+                if grad_rows is not None or hits is not None:      # PE channel on its own draw
+                    nat.check(lib.lstep_gather_explicit_bwd(None, Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(ids), nat.ptr(times), B, K,
+                                                            nat.ptr(l3[0]), None, nat.ptr(l3[2]), num_rows, None, nat.ptr(g_pe), nat.ptr(g_self),
+                                                            mod.ld_edge, mod.ld_pe, ctx.ld_self, nat.ptr(slot_of) if use_slot else None, None,
+                                                            nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
+        elif g_edge is not None or grad_rows is not None or hits is not None:
             with torch.cuda.device(dev):
                 nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
                                                          nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, nat.ptr(g_edge), nat.ptr(g_pe),
@@ -834,14 +867,14 @@ class _GatherAggregate(torch.autograd.Function):
             g_w = slot_dot.sum(dim=0)
         g_table = None
         if grad_rows is not None and not use_slot:
-            if g_pe is not None:  # padding slots all read row 0: one weighted column sum instead of a hot atomic row
-                npad = (K - count.clamp(max=K)).to(torch.float32)
+            if g_pe is not None and ctx.explicit is None:  # padding slots all read row 0: one weighted column sum instead of a hot atomic row
+                npad = (K - count.clamp(max=K)).to(torch.float32)      # (explicit lists carry their padding slots as id 0: already added)
                 grad_rows[0] += npad @ g_pe[:, :P]
             g_table = grad_rows
         elif grad_rows is not None and g_pe is not None:
             # spliced mode: row 0 only has gradient if node 0 is itself a spliced row (never in the reference data)
             pass
-        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None, None, None)
+        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None, None, None, None)
 
 
 class _FftCoefficients(torch.autograd.Function):
@@ -969,8 +1002,6 @@ class LSTEP(nn.Module):
         nat.load_library()  # fail loudly: no HIP library, no model
         if use_dropout:
             raise NotImplementedError("use_dropout=True is never set by the reference drivers (SURVEY.md appendix A.8)")
-        if weighted_sum:
-            raise NotImplementedError("weighted_sum ablation is out of scope for the MI355X path (SURVEY.md 8f-4)")
         edge_feat_dim = edge_raw_features.shape[-1]
         node_feat_dim = node_raw_features.shape[-1]
         if edge_feat_dim != node_feat_dim:
@@ -1040,13 +1071,46 @@ class LSTEP(nn.Module):
             if lo < 0 or hi >= self.neighbor_sampler.num_rows or hi >= self.node_raw_features.shape[0]:
                 raise IndexError(f"node id out of range [0, {self.node_raw_features.shape[0]})")
 
-    def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None, wide: bool = False):
+    def _draw_neighbourhoods(self, node_ids, node_interact_times, K, G, branches, row_blocks: int = 1):
+        """RNG-defined sampling strategies ('uniform', 'time_interval_aware', utils/utils.py:175-198): the draws are defined by the call
+        order of numpy's RandomState, so they are made by the host sampler in EXACTLY the reference's order -- per
+        combining_pe_raw_feat call K slots (edge channel, models/LSTEP.py:147), time_gap slots (node channel, :177), K slots again (PE
+        channel, :223) -- and handed to the explicit-neighbourhood kernels.  ``row_blocks``: the rows are that many equal blocks which
+        the reference would have passed in separate calls (the engine merges src | dst | negatives into one launch)."""
+        ids = node_ids.cpu().numpy() if isinstance(node_ids, torch.Tensor) else np.asarray(node_ids)
+        ts = node_interact_times.cpu().numpy() if isinstance(node_interact_times, torch.Tensor) else np.asarray(node_interact_times)
+        n = len(ids)
+        if row_blocks < 1 or n % row_blocks:
+            raise ValueError("row_blocks must divide the number of rows")
+        step = n // row_blocks
+        en, pb = bool(branches & nat.BRANCH_EDGE_NODE), bool(branches & nat.BRANCH_PE)
+        draws = ([], [], [])
+        for b in range(row_blocks):
+            sl = slice(b * step, (b + 1) * step)
+            if en:
+                draws[0].append(self.neighbor_sampler.get_historical_neighbors(ids[sl], ts[sl], K))
+                draws[1].append(self.neighbor_sampler.get_historical_neighbors(ids[sl], ts[sl], G))
+            if pb:
+                draws[2].append(self.neighbor_sampler.get_historical_neighbors(ids[sl], ts[sl], K))
+
+        def to_dev(parts):
+            if not parts:
+                return None
+            cat = [np.concatenate([p[i] for p in parts], axis=0) for i in range(3)]
+            return (torch.from_numpy(np.ascontiguousarray(cat[0], dtype=np.int64)).to(self.device),
+                    torch.from_numpy(np.ascontiguousarray(cat[1], dtype=np.int64)).to(self.device),
+                    torch.from_numpy(np.ascontiguousarray(cat[2], dtype=np.float32)).to(self.device))
+        return tuple(to_dev(d) for d in draws)
+
+    def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None, wide: bool = False, row_blocks: int = 1):
         if K != self.num_neighbors and (branches & nat.BRANCH_EDGE_NODE):
             raise RuntimeError(f"edge_agg was built for num_neighbors={self.num_neighbors}, got {K} "
                                "(the reference fails the same way at models/LSTEP.py:164)")
+        explicit = None
         if getattr(self.neighbor_sampler, "sample_neighbor_strategy", "recent") != "recent":
-            raise NotImplementedError("the fused MI355X path implements sample_neighbor_strategy='recent' (the reference default, "
-                                      "utils/load_configs.py:22); RNG-defined strategies only have the host sampler API")
+            if len(node_ids) != len(node_interact_times):
+                raise ValueError("node_ids and node_interact_times must have the same length")
+            explicit = self._draw_neighbourhoods(node_ids, node_interact_times, K, G, branches, row_blocks)
         self._check_rows(node_ids)
         ids, times = self._ids(node_ids), self._times(node_interact_times)
         if ids.numel() != times.numel():
@@ -1062,7 +1126,7 @@ class LSTEP(nn.Module):
         if slot_of is not None and (slot_of.dtype != torch.int32 or slot_of.numel() < self.neighbor_sampler.num_rows):
             raise ValueError("slot_of must be an int32 map with one entry per node id")
         return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide,
-                                      getattr(spliced, "self_groups", None))
+                                      getattr(spliced, "self_groups", None), explicit)
 
     def _edge_node_tail(self, x_edge, x_node):
         """edge_mlp_1 -> edge_agg (reassociated) -> relu -> edge_mlp_2 ; node_mlp(cat[node, edge])  (models/LSTEP.py:161-170,219)."""
@@ -1089,10 +1153,11 @@ class LSTEP(nn.Module):
 
     # ---- O (models/LSTEP.py:251-266): one fused gather launch serves A, N and C
     def combining_pe_raw_feat(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, time_gap: int = 2000, testing=False,
-                              spliced: SplicedRows = None, padded: bool = False):
+                              spliced: SplicedRows = None, padded: bool = False, row_blocks: int = 1):
+        """``row_blocks`` (RNG-defined sampling only): see ``_draw_neighbourhoods``."""
         fused = self._fused_tail_ok()
         x_edge, x_node, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, time_gap,
-                                                    nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced, wide=fused)
+                                                    nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced, wide=fused, row_blocks=row_blocks)
         out = self._combined_tail(x_edge, x_node, x_pe, own, fused)
         # padded: the [B, 176] rows the kernels work on (columns >= 172 are 0), for lstep_head_fwd; default: the reference's [B, 172]
         return out if padded else out[:, :self.feat_dim]
@@ -1405,7 +1470,12 @@ class LSTEP(nn.Module):
         dev = pe.device
         P, D = self.pe_dim, self.time_dim
         U = bn.numel()
-        nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, num_neighbors)
+        if getattr(self.neighbor_sampler, "sample_neighbor_strategy", "recent") == "recent":
+            nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, num_neighbors)
+        else:   # RNG-defined strategies draw on the host, in the reference's call order (one call per update_pe, models/LSTEP.py:306)
+            a, _, c = self.neighbor_sampler.get_historical_neighbors(bn.cpu().numpy(), t.cpu().numpy(), num_neighbors)
+            nbr = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
+            nt = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).to(dev)
         key = nbr.reshape(-1)
         rows = pe.shape[0]
         pe[0].zero_()

@@ -133,8 +133,9 @@ class OracleLSTEP(nn.Module):
     """Same parameters (names, shapes, dtypes) and same method surface as reference ``models.LSTEP.LSTEP``."""
 
     def __init__(self, node_raw_features, edge_raw_features, neighbor_sampler, full_neighbor_sampler=None, pe_dim=172,
-                 num_neighbors=20, time_feat_dim=100, num_fft_batches=100, device="cpu"):
+                 num_neighbors=20, time_feat_dim=100, num_fft_batches=100, device="cpu", weighted_sum=False):
         super().__init__()
+        self.weighted_sum = weighted_sum      # the `weighted_sum` ablation (models/LSTEP.py:74,190-206; train_LSTEP_link_prediction.py:126)
         f_edge = edge_raw_features.shape[-1]
         f_node = node_raw_features.shape[-1]
         self.num_fft_batches = num_fft_batches
@@ -207,12 +208,26 @@ class OracleLSTEP(nn.Module):
         x = self.edge_agg(x.permute(0, 2, 1)).squeeze()                                           # Linear over the K axis
         x = self.edge_mlp_2(torch.relu(x))
 
-        nbr_g, _, _ = self.neighbor_sampler.get_historical_neighbors(node_ids, node_interact_times, time_gap)
+        nbr_g, _, nts_g = self.neighbor_sampler.get_historical_neighbors(node_ids, node_interact_times, time_gap)
         node_rows = self.node_raw_features[self._idx(nbr_g)]                                      # [B, G, F] dense
         m = torch.from_numpy((nbr_g > 0).astype(np.float32))
         m[m == 0] = -1e10
         scores = torch.softmax(m, dim=1).to(self.device)                                          # 1/valid on valid slots
-        pooled = torch.mean(node_rows * scores.unsqueeze(-1), dim=1)                              # divides by G again (:208)
+        if self.weighted_sum:
+            # (:190-206) per row, one weight per DISTINCT neighbour time u: exp(-(t - mean of the row's slots with time u)), 0 for the
+            # padding time 0.0, normalised over the row's distinct times, handed back to the slots and clamped to [0, 1]
+            tg = torch.from_numpy(nts_g)                                                          # float32 [B, G]
+            uniq, inv = torch.unique(tg, return_inverse=True)
+            off = inv + (torch.arange(inv.shape[0]) * uniq.shape[0]).unsqueeze(-1)
+            but = scatter_mean_restated(tg.flatten(), off.flatten(), inv.shape[0] * uniq.shape[0]).view(inv.shape[0], uniq.shape[0])
+            w = torch.exp(-(torch.from_numpy(node_interact_times).unsqueeze(-1) - but)) * (but != 0.0)     # float64
+            sw = torch.sum(w, dim=-1)
+            sw = sw + (sw == 0)
+            w = w / sw.unsqueeze(-1)
+            w = w.flatten()[off.flatten()].view(tg.shape).clamp(0, 1).to(torch.float32)
+            pooled = torch.mean(node_rows * scores.unsqueeze(-1) * w.to(self.device).unsqueeze(-1), dim=1)
+        else:
+            pooled = torch.mean(node_rows * scores.unsqueeze(-1), dim=1)                          # divides by G again (:208)
         node_part = pooled + self.node_raw_features[self._idx(node_ids)]
         return self.node_mlp(torch.cat([node_part, x], dim=-1))
 
@@ -265,11 +280,20 @@ class OracleLSTEP(nn.Module):
         return pe
 
 
+def scatter_mean_restated(src: torch.Tensor, index: torch.Tensor, size: int) -> torch.Tensor:
+    """``torch_scatter.scatter_mean(src, index, out=zeros(size))`` (third-party wheel, absent here; version unpinned by the reference,
+    which has no requirements file): its documented definition -- out[i] = (sum of the src entries with index i) / max(their count, 1),
+    summed in src's dtype in memory order.  Only call site: models/LSTEP.py:194."""
+    out = torch.zeros(size, dtype=src.dtype).scatter_add_(0, index, src)
+    cnt = torch.zeros(size, dtype=src.dtype).scatter_add_(0, index, torch.ones_like(src)).clamp_(min=1)
+    return out / cnt
+
+
 def build_oracle_model(node_raw, edge_raw, sampler, num_neighbors, num_fft_batches, state_dict=None, feat_dim=172,
-                       time_dim=100, pe_dim=172):
+                       time_dim=100, pe_dim=172, weighted_sum=False):
     """``nn.Sequential(backbone, link_predictor)`` as the reference wraps it (train_LSTEP_link_prediction.py:140-142)."""
     bb = OracleLSTEP(node_raw, edge_raw, sampler, sampler, pe_dim=pe_dim, num_neighbors=num_neighbors,
-                     time_feat_dim=time_dim, num_fft_batches=num_fft_batches)
+                     time_feat_dim=time_dim, num_fft_batches=num_fft_batches, weighted_sum=weighted_sum)
     pred = OracleMergeLayer(feat_dim, feat_dim, feat_dim, 1)
     model = nn.Sequential(bb, pred)
     if state_dict is not None:

@@ -37,8 +37,13 @@ def import_reference():
         assert dim == 0 and out is not None and reduce == "sum"
         return out.scatter_add_(0, index.view(-1, 1).expand_as(src), src)
 
-    def scatter_mean(*a, **k):
-        raise NotImplementedError("weighted_sum ablation is out of scope (SURVEY.md 8f-4)")
+    def scatter_mean(src, index, out=None, dim=-1):
+        # documented semantics of torch_scatter.scatter_mean for the one call shape on the path (models/LSTEP.py:194: 1-D src / index,
+        # zero-initialised `out`): out[i] = sum of the entries with index i / max(count, 1)
+        assert out is not None and src.dim() == 1 and index.dim() == 1 and dim in (-1, 0)
+        out.scatter_add_(0, index, src)
+        cnt = torch.zeros_like(out).scatter_add_(0, index, torch.ones_like(src)).clamp_(min=1)
+        return out.div_(cnt)
 
     ts.scatter, ts.scatter_mean = scatter, scatter_mean
     sys.modules["torch_scatter"] = ts
@@ -65,11 +70,11 @@ def ref_sampler(g, upto=None):
     return get_neighbor_sampler(data, sample_neighbor_strategy="recent", seed=None)
 
 
-def ref_model(node_raw, edge_raw, sampler, K, T, seed=3):
+def ref_model(node_raw, edge_raw, sampler, K, T, seed=3, weighted_sum=False):
     torch.manual_seed(0)
     bb = LSTEP(node_raw_features=node_raw, edge_raw_features=edge_raw, neighbor_sampler=sampler,
                full_neighbor_sampler=sampler, pe_dim=synth.PE_DIM, num_neighbors=K, time_feat_dim=synth.TIME_DIM,
-               num_fft_batches=T, device="cpu")
+               num_fft_batches=T, weighted_sum=weighted_sum, device="cpu")
     pred = MergeLayer(input_dim1=synth.FEAT_DIM, input_dim2=synth.FEAT_DIM, hidden_dim=synth.FEAT_DIM, output_dim=1)
     model = torch.nn.Sequential(bb, pred)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(K, T, seed=seed).items()}
@@ -364,6 +369,55 @@ def gen_eval_loop():
     print("eval_loop.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------- weighted_sum + RNG strategies through the model
+WS_GRAPH = dict(num_nodes=40, num_edges=1200, seed=90, time_span=60.0, tie_quantum=0.25)    # times a few units apart (exp(-dt) is not all 0), with ties
+
+
+def gen_variants():
+    """(1) the `weighted_sum` ablation of the node channel (models/LSTEP.py:190-206, --ablation weighted_sum) with 'recent' sampling;
+    (2) the RNG-defined sampling strategies driving combining_pe_raw_feat / update_pe (three independent draws per combine call)."""
+    from utils.utils import get_neighbor_sampler as ref_get
+    g = synth.make_temporal_graph(**WS_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=91)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=92)
+    pe0[0] = 0.03
+    data = Data(g["src"], g["dst"], g["ts"], g["eid"], np.zeros(len(g["src"])))
+    K, T = 5, 4
+    out = {}
+    sl = slice(900, 924)
+    src, dst, t, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+    # (1)
+    model = ref_model(node_raw, edge_raw, ref_get(data, sample_neighbor_strategy="recent", seed=None), K, T, weighted_sum=True)
+    with torch.no_grad():
+        for G in (6, 2000):
+            out[f"ws/agg_G{G}"] = model[0].aggregated_node_embeddings(src, t, K, G).numpy()
+            out[f"ws/out_G{G}"] = model[0].combining_pe_raw_feat(torch.from_numpy(pe0.copy()), dst, t, K, G).numpy()
+    # (2)
+    for strat, tsf in (("uniform", 0.0), ("time_interval_aware", 1e-2)):
+        for ws in (False, True):
+            sampler = ref_get(data, sample_neighbor_strategy=strat, time_scaling_factor=tsf, seed=5)
+            model = ref_model(node_raw, edge_raw, sampler, K, T, weighted_sum=ws)
+            model[0].set_neighbor_sampler(sampler)
+            tag = f"{strat}/ws{int(ws)}"
+            pe = torch.from_numpy(pe0.copy())
+            with torch.no_grad():
+                out[f"{tag}/out_src"] = model[0].combining_pe_raw_feat(pe, src, t, K, 7).numpy()
+                out[f"{tag}/out_dst"] = model[0].combining_pe_raw_feat(pe, dst, t, K, 7).numpy()
+                out[f"{tag}/agg"] = model[0].aggregated_node_embeddings(src, t, K, 7).numpy()
+                out[f"{tag}/cpe"] = model[0].compute_neighborhood_pe(pe, dst, t, K).numpy()
+                bn = protocol.unique_batch_nodes(src, dst)
+                out[f"{tag}/pe_updated"] = model[0].update_pe(pe, bn, eid, src, dst, t, t.max(), num_neighbors=K).numpy().copy()
+            # gradients of one loss through the three draws
+            pe_g = torch.from_numpy(pe0.copy()).requires_grad_(True)
+            w = torch.from_numpy(np.random.RandomState(93).standard_normal((len(src), synth.FEAT_DIM)).astype(np.float32))
+            (model[0].combining_pe_raw_feat(pe_g, src, t, K, 7) * w).sum().backward()
+            out[f"{tag}/grad_pe"] = pe_g.grad.numpy().copy()
+            out[f"{tag}/grad_edge_agg"] = model[0].edge_agg.weight.grad.numpy().copy()
+            out[f"{tag}/grad_edge_mlp_1"] = model[0].edge_mlp_1.weight.grad.numpy()[::GRAD_ROW_STRIDE].copy()
+    np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
+    print("variants.npz", len(out), "arrays")
+
+
 # ----------------------------------------------------------------------------------------------- RNG-defined sampling
 def gen_random_sampling():
     from utils.utils import get_neighbor_sampler as ref_get
@@ -420,7 +474,7 @@ def gen_loader():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop"]
+    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop", "variants"]
     if "sampler" in which:
         gen_sampler()
     if "time" in which:
@@ -435,3 +489,5 @@ if __name__ == "__main__":
         gen_random_sampling()
     if "eval_loop" in which:
         gen_eval_loop()
+    if "variants" in which:
+        gen_variants()

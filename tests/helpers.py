@@ -23,6 +23,8 @@ TRACE_GRAPH = dict(num_nodes=64, num_edges=2000, seed=30)
 TRACE_K, TRACE_T, TRACE_B, TRACE_G = 5, 4, 16, 2000
 TRACE_START, TRACE_BATCHES, GRAD_ROW_STRIDE = 640, 7, 4
 EVAL_LOOP = dict(first=1200, edges=6 * 16 + 5, batch=16, stored=2)
+WS_GRAPH = dict(num_nodes=40, num_edges=1200, seed=90, time_span=60.0, tie_quantum=0.25)
+WS_K, WS_T = 5, 4
 
 
 def method_inputs():
@@ -88,3 +90,13 @@ def eval_loop_expected(z, strategy, b):
     logits = np.concatenate([z[f"{strategy}/b{b}/pos_logits"], z[f"{strategy}/b{b}/neg_logits"]])
     prob = np.clip(1.0 / (1.0 + np.exp(-logits.astype(np.float64))), 0.0, 1.0)
     return prob, z[f"{strategy}/b{b}/snapshot"], float(z[f"{strategy}/losses"][b])
+
+
+def variant_inputs():
+    """Inputs of tests/golden/variants.npz (weighted_sum ablation, RNG-defined sampling strategies through the model)."""
+    g = synth.make_temporal_graph(**WS_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=91)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=92)
+    pe0[0] = 0.03
+    sl = slice(900, 924)
+    return g, node_raw, edge_raw, pe0, (g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl])
