@@ -209,3 +209,42 @@ def test_lookahead_batch_key_survives_allocator_reuse():
     gc.collect()
     c, d = torch.arange(64) + 3, torch.arange(64) + 4
     assert (c.data_ptr(), d.data_ptr()) != ptrs and not key.matches(c, d)
+
+
+def test_initial_positional_encodings_properties():
+    """LapPE / RWPE initial encodings (utils/PositionalEncoding.py:42-62,69-91; parity UNPINNED: torch_geometric is absent and the
+    reference's ARPACK output is an arbitrary basis of hugely degenerate eigenspaces).  What is well defined is checked: the
+    eigen-equation, orthonormal columns, ascending eigenvalues in [0, 2], +-1 column signs from the seeded generator, and the
+    return-probability definition of RWPE against dense matrix powers."""
+    import torch
+
+    from lstep_amd import init_pe
+    g = synth.make_temporal_graph(num_nodes=60, num_edges=300, seed=9)
+    src, dst = g["src"][:80], g["dst"][:80]          # the first batch only (train_LSTEP_link_prediction.py:168-189)
+    n, k = 61, 12
+    ei = init_pe.first_batch_edge_index(src, dst)
+    assert tuple(ei.shape) == (2, 160) and torch.equal(ei[0, :80], torch.from_numpy(src)) and torch.equal(ei[1, :80], torch.from_numpy(dst))
+    lap, ew = init_pe.sym_normalised_laplacian(ei, n)
+    dense = lap.toarray()
+    assert np.allclose(dense, dense.T) and ew.numel() == 160 + n
+    deg = np.bincount(ei[0].numpy(), minlength=n)
+    iso = deg == 0
+    assert iso.sum() > 0 and np.all(np.diag(dense)[iso] == 1.0) and np.all(np.abs(dense[iso]).sum(1) == 1.0)   # isolated nodes: a lone 1 on the diagonal
+    gen = torch.Generator().manual_seed(3)
+    pe, _ = init_pe.laplacian_pe(ei, n, k, generator=gen)
+    assert pe.dtype == torch.float64 and tuple(pe.shape) == (n, k)
+    v = pe.numpy()
+    lam = np.einsum("ij,ij->j", v, dense @ v)
+    assert np.allclose(dense @ v, v * lam, atol=1e-8), "columns must be eigenvectors"
+    assert np.allclose(v.T @ v, np.eye(k), atol=1e-8)
+    assert np.all(np.diff(lam) >= -1e-9) and lam.min() >= -1e-9 and lam.max() <= 2 + 1e-9
+    full = np.linalg.eigvalsh(dense)
+    assert np.allclose(lam, full[1:k + 1], atol=1e-8), "eigenvalues 1..k of the spectrum (the smallest one is dropped)"
+    rw = init_pe.random_walk_pe(ei, n, 5)
+    p = np.zeros((n, n))
+    np.add.at(p, (ei[0].numpy(), ei[1].numpy()), 1.0 / np.maximum(deg, 1)[ei[0].numpy()])
+    q = np.eye(n)
+    for i in range(5):
+        q = q @ p
+        assert np.allclose(rw[:, i].numpy(), np.diag(q), atol=1e-6)
+    assert rw.dtype == torch.float32 and float(rw[deg == 0].abs().max()) == 0.0
