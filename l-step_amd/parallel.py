@@ -177,6 +177,11 @@ def unpack_ids(z: torch.Tensor, width: int) -> torch.Tensor:
     return z[:, width:width + 2].contiguous().view(torch.int32).view(torch.int64).reshape(-1)
 
 
+def nat_branch(name: str) -> int:
+    from . import _native as nat
+    return nat.BRANCH_EDGE_NODE if name == "edge_node" else nat.BRANCH_PE
+
+
 def owned_rows(num_rows: int, world: int, rank: int) -> int:
     """Number of node ids in [0, num_rows) with id % world == rank."""
     return (num_rows - rank + world - 1) // world if num_rows > rank else 0
@@ -262,6 +267,12 @@ class DistributedLstep:
 
     def _splice(self, bn: torch.Tensor, batch_idx: int, owner_counts=None):
         """Owner-sharded FFT filter + all-gather of the filtered rows; returns (local rows with grad, leaf of all rows, perm)."""
+        return self._splice_finish(self._splice_start(bn, batch_idx, owner_counts))
+
+    def _splice_start(self, bn: torch.Tensor, batch_idx: int, owner_counts=None):
+        """The local half of the splice: filter the history of the batch nodes this rank owns and put the all-gather of the filtered rows
+        IN FLIGHT (``PendingGather``).  Whatever does not read the PE table -- the edge / node channels of the gather stage, 70 % of
+        its bytes -- can be enqueued before ``_splice_finish`` and runs underneath the collective."""
         self._wait_snapshot()
         owner = bn % self.W
         # every rank derives the same counts: no size exchange.  With a look-ahead they were computed one iteration ago and are already
@@ -273,7 +284,11 @@ class DistributedLstep:
         self._owned_idx = owned_idx
         mine = bn[owned_idx]                                           # (sizes known on the host: no boolean-mask compaction)
         rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx, mask=self.ring.mask)
-        gathered, _ = all_gather_var(rows_mine.detach(), self.group, counts=counts)
+        return bn, rows_mine, PendingGather(rows_mine.detach(), self.group, counts=counts), order, counts
+
+    def _splice_finish(self, started):
+        bn, rows_mine, pending, order, counts = started
+        gathered = pending.wait()
         # gathered is ordered by (owner rank, node id); bn is ordered by node id
         rows_all = torch.empty_like(gathered)
         rows_all[order] = gathered
@@ -366,11 +381,21 @@ class DistributedLstep:
             self.table.copy_(initial_pe)
             owner_counts = None
         else:
-            rows_mine, leaf, (owner_order, owner_counts) = self._splice(bn, batch_idx, owner_counts)
-            spliced = SplicedRows(leaf, self.slot_of)
+            started = self._splice_start(bn, batch_idx, owner_counts)
             s_, d_, n_, t_ = src[sl], dst[sl], neg_dst[sl], ts[sl]
-            ids3 = torch.cat([s_, d_, n_])
-            emb_p = self.bb.combining_pe_raw_feat(self.table, ids3, torch.cat([t_, t_, t_]), self.K, self.G, spliced=spliced, padded=True)
+            ids3, t3 = torch.cat([s_, d_, n_]), torch.cat([t_, t_, t_])
+            fused = self.bb._fused_tail_ok()
+            split = self.W > 1 or os.environ.get("LSTEP_FORCE_COLLECTIVES") == "1"
+            if split:
+                # edge + node channels first: they read no PE row, so their launch overlaps the all-gather of the filtered rows
+                x_edge, x_node, _, _, _ = self.bb._gather(None, ids3, t3, self.K, self.G, nat_branch("edge_node"), wide=fused, row_blocks=3)
+            rows_mine, leaf, (owner_order, owner_counts) = self._splice_finish(started)
+            spliced = SplicedRows(leaf, self.slot_of)
+            if split:
+                _, _, x_pe, own, _ = self.bb._gather(self.table, ids3, t3, self.K, self.G, nat_branch("pe"), spliced, wide=fused, row_blocks=3)
+                emb_p = self.bb._combined_tail(x_edge, x_node, x_pe, own, fused)
+            else:
+                emb_p = self.bb.combining_pe_raw_feat(self.table, ids3, t3, self.K, self.G, spliced=spliced, padded=True, row_blocks=3)
             emb = emb_p[:, :self.bb.feat_dim]
             pos_src, pos_dst, neg_emb = emb[:b], emb[b:2 * b], emb[2 * b:]
             if self.eng.fused_loss and self.predictor.fused_ok(emb_p):   # predictor + loss terms + their gradient: three launches
@@ -414,12 +439,14 @@ class DistributedLstep:
         if loss is not None:
             optimizer.zero_grad()
             (loss / self.W).backward()                       # global mean = mean of the rank means
-            self.bb.join_aux_stream()
             g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
-            # every rank's loss touches every spliced row; each rank needs the summed gradient of the rows it owns
+            # every rank's loss touches every spliced row; each rank needs the summed gradient of the rows it owns.  The reduce-scatter
+            # only needs the critical stream's activation backward: the weight-gradient products are still running on the auxiliary
+            # stream underneath it, and are joined only where the flat parameter all-reduce needs them
             g_mine = reduce_scatter_var(g_rows[owner_order].contiguous(), owner_counts, self.group)
             if rows_mine.numel():
                 rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
+            self.bb.join_aux_stream()
             all_reduce_gradients(self._trainable, self.group)
             if overlap:
                 with torch.cuda.stream(side):
