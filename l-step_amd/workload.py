@@ -45,6 +45,18 @@ class Workload:
                 f"batch_size={self.batch}, num_neighbors={self.K}, time_gap={self.G}, num_fft_batches={self.T}, recent sampling")
 
 
+def build_hip_model(node_raw, edge_raw, sampler, K, T, state_dict=None, device="cuda"):
+    """``nn.Sequential(LSTEP, MergeLayer)`` as the reference wraps it (train_LSTEP_link_prediction.py:140-142), optionally loaded from a
+    reference-keyed ``state_dict`` (``strict=True``: same names, shapes and dtypes)."""
+    bb = LSTEP(node_raw, edge_raw, sampler, sampler, pe_dim=synth.PE_DIM, num_neighbors=K, time_feat_dim=synth.TIME_DIM,
+               num_fft_batches=T, device=device)
+    pred = MergeLayer(synth.FEAT_DIM, synth.FEAT_DIM, synth.FEAT_DIM, 1).to(device)
+    model = torch.nn.Sequential(bb, pred)
+    if state_dict is not None:
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()}, strict=True)
+    return model
+
+
 def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int = 100, seed: int = 0, batch: int = None,
                    sharded: bool = False, zipf: float = None) -> Workload:
     """``sharded=True`` (multi-GPU): no full history ring is allocated; ``prefill_distributed`` fills the owner shards."""

@@ -31,7 +31,7 @@ def hip():
     from lstep_amd import _native
     from lstep_amd.engine import EdgeStream, LstepEngine
     from lstep_amd.sampler import NeighborSampler
-    from lstep_amd.smoke import build_hip_model
+    from lstep_amd.workload import build_hip_model
 
     _native.load_library()
 

@@ -24,7 +24,7 @@ def hip():
     from lstep_amd.engine import EdgeStream, LstepEngine
     from lstep_amd.model import LSTEP, MergeLayer, TimeEncoder
     from lstep_amd.sampler import NeighborSampler
-    from lstep_amd.smoke import build_hip_model
+    from lstep_amd.workload import build_hip_model
 
     _native.load_library()
 
@@ -657,7 +657,7 @@ def test_fused_dense_kernels_match_library_path(hip, monkeypatch):
     from lstep_amd import synth
     from lstep_amd.engine import EdgeStream, LstepEngine
     from lstep_amd.sampler import NeighborSampler
-    from lstep_amd.smoke import build_hip_model
+    from lstep_amd.workload import build_hip_model
     g = synth.make_temporal_graph(num_nodes=300, num_edges=6000, seed=5, zipf=1.1)
     node_raw, edge_raw = synth.make_features(300, 6000, seed=5)
     K, T, B = 20, 4, 500
@@ -738,7 +738,7 @@ def test_engine_lookahead_and_streams_do_not_change_results(hip, monkeypatch):
     from lstep_amd.engine import EdgeStream, LstepEngine
     from lstep_amd.optim import FusedAdam
     from lstep_amd.sampler import NeighborSampler
-    from lstep_amd.smoke import build_hip_model
+    from lstep_amd.workload import build_hip_model
     g = synth.make_temporal_graph(num_nodes=400, num_edges=8000, seed=9)
     node_raw, edge_raw = synth.make_features(400, 8000, seed=9)
     K, T, B = 20, 4, 256
@@ -803,7 +803,7 @@ def test_update_entry_kernels_match_framework_path(hip, monkeypatch):
     from lstep_amd import synth
     from lstep_amd.engine import LstepEngine, EdgeStream
     from lstep_amd.sampler import NeighborSampler
-    from lstep_amd.smoke import build_hip_model
+    from lstep_amd.workload import build_hip_model
     g = synth.make_temporal_graph(num_nodes=500, num_edges=5000, seed=3, zipf=1.2)
     node_raw, edge_raw = synth.make_features(500, 5000, seed=3)
     K, T, B = 20, 4, 300
@@ -943,7 +943,7 @@ def test_engine_change_mask_equals_dense_history(hip, monkeypatch):
     from lstep_amd.engine import EdgeStream, LstepEngine
     from lstep_amd.optim import FusedAdam
     from lstep_amd.sampler import NeighborSampler
-    from lstep_amd.smoke import build_hip_model
+    from lstep_amd.workload import build_hip_model
     g = synth.make_temporal_graph(num_nodes=20000, num_edges=40000, seed=11)
     node_raw, edge_raw = synth.make_features(20000, 40000, seed=11)
     K, T, B = 20, 4, 128

@@ -102,7 +102,7 @@ def _gpu_worker(rank, world, port, q, backend="gloo"):
         from lstep_amd.engine import EdgeStream, LstepEngine
         from lstep_amd.parallel import DistributedLstep, all_gather_var
         from lstep_amd.sampler import NeighborSampler
-        from lstep_amd.smoke import build_hip_model
+        from lstep_amd.workload import build_hip_model
         z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces.npz"))
         g, node_raw, edge_raw, pe0 = trace_inputs()
         sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=g["num_nodes"], device=dev)

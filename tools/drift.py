@@ -5,7 +5,7 @@ import numpy as np, torch
 from lstep_amd import protocol, synth
 from lstep_amd.engine import EdgeStream, LstepEngine
 from lstep_amd.sampler import NeighborSampler
-from lstep_amd.smoke import build_hip_model
+from lstep_amd.workload import build_hip_model
 from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model
 
 N, E, B, K, T, G, batches = 300, 20000, 64, 10, 8, 2000, int(sys.argv[1]) if len(sys.argv) > 1 else 40
