@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+GATHER_KERNEL = "lstep::gather_aggregate_fwd_kernel<true, true, false>"   # edge + node + PE channels, CSR search (not the explicit-list variant)
 
 
 def gather_algorithmic_bytes(count: torch.Tensor, K: int, G: int, row_bytes: int = 688) -> float:
@@ -285,7 +286,8 @@ def main():
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
             if cands:
-                rec = json.load(open(cands[-1])).get("lstep::gather_aggregate_fwd_kernel<true, true>")
+                table = json.load(open(cands[-1]))
+                rec = table.get(GATHER_KERNEL) or table.get("lstep::gather_aggregate_fwd_kernel<true, true>")   # (name before the explicit-list variant)
                 if rec:
                     traffic, traffic_src = rec["traffic_bytes"], os.path.relpath(cands[-1], ROOT)
         ms = [a.elapsed_time(b) for a, b, _ in sink]
@@ -313,7 +315,7 @@ def main():
                        "parallelism": (f"x{world}: PE history, FFT filter and update_pe sharded by node owner (id % {world}); gather / dense tail / loss "
                                        f"on each rank's {B}-edge slice of the global batch; RCCL all-gather of updated PE rows") if use_dist
                                       else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "lstep::gather_aggregate_fwd_kernel<true, true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": GATHER_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "launch_timing": timing_note, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
                          "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
