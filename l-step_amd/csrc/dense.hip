@@ -26,6 +26,9 @@ struct WgradParams {
     int64_t part_stride;   // floats per partial block
     int32_t ldy, ldx, n, k;
     int32_t bias_off;      // offset of the db partial inside a partial block
+    int32_t k_blocks;      // v2 kernels: wave task t of a row slice owns n-block t / k_blocks and k-block t % k_blocks (0: the (y, z) grid mapping)
+    int32_t tasks;         // with k_blocks: wave-tasks per row slice; waves are numbered over (slice, task) so that no SIMD slot idles
+    int32_t slices;
 };
 
 // One workgroup = 4 waves; wave w owns k-tiles [(blockIdx.y * 4 + w) * KTW, +KTW) x n-tiles [blockIdx.z * NT, +NT).
@@ -142,10 +145,19 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const Wgrad
 
     const int lane = lane_id(), wave = wave_in_block();
     const int kk = lane >> 4, c = lane & 15;
-    const int n0 = blockIdx.z * (NT * 16);
-    const int k0 = (blockIdx.y * kWavesPerBlock + wave) * (KTW * 16);
-    if (k0 >= p.k) return;  // no barriers in this kernel
-    const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_wg;
+    int task = blockIdx.y * kWavesPerBlock + wave, slice = blockIdx.x;
+    if (p.k_blocks) {      // flattened: 4 consecutive (slice, task) pairs per workgroup
+        const int gid = blockIdx.x * kWavesPerBlock + wave;
+        slice = gid / p.tasks;
+        task = gid - slice * p.tasks;
+        if (slice >= p.slices) return;
+    }
+    const int nblock = p.k_blocks ? task / p.k_blocks : (int)blockIdx.z;
+    const int kblock = p.k_blocks ? task % p.k_blocks : task;
+    const int n0 = nblock * (NT * 16);
+    const int k0 = kblock * (KTW * 16);
+    if (k0 >= p.k || n0 >= p.n) return;  // no barriers in this kernel
+    const int64_t r_begin = (int64_t)slice * p.rows_per_wg;
     int64_t r_end = r_begin + p.rows_per_wg;
     if (r_end > p.m) r_end = p.m;
 
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const Wgrad
     // C/D layout of the 16x16 forms: lane l, register q -> tile row 4 * (l >> 4) + q, tile column l & 15.  Tile rows / columns of a
     // 64-column group are the columns base + 4 * index + v: the four tiles v = 0..3 of a k-group hold four consecutive columns per
     // lane, stored as one float4.
-    float* out = p.part + (int64_t)blockIdx.x * p.part_stride;
+    float* out = p.part + (int64_t)slice * p.part_stride;
     auto store_row = [&](int a, int q, int n) {
         if (n >= p.n) return;
         float* dst = out + (int64_t)n * p.k;
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const Wgrad
 #pragma unroll
         for (int q = 0; q < 4; ++q) store_row(4 * NG + t, q, n0 + 64 * NG + 16 * t + 4 * kk + q);
     }
-    if (blockIdx.y == 0 && wave == 0) {
+    if (kblock == 0) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             f32x4 t = bsum4[g];
@@ -340,14 +352,45 @@ static inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * 
 
 struct WgradPlan {
     int nt, ktw;          // template instance
+    int small;            // 1: 6 x 4 tiles per wave (<= 256 registers: leaves half of every SIMD's register file to other kernels)
+    int k_blocks, tasks;  // small: flattened (slice, n-block, k-block) wave numbering
     int gy, gz, splits;   // grid
     int64_t rows_per_wg, part_stride;
     int32_t bias_off;
 };
 
-static WgradPlan wgrad_plan(int64_t m, int32_t n, int32_t k) {
+// Two tilings.  "big": 9-11 x 3-5 tiles per wave (up to 220 accumulator registers, 512 registers per lane, one wave per SIMD): the fewest
+// partial blocks and operand loads, but its waves own the whole register file for the whole kernel -- NOTHING else runs on the chip
+// meanwhile (tools/overlap_probe.py: 6 products beside a 2 GiB copy take 1.07 ms, more than the 0.93 ms of one after the other).
+// "small": 6 x 4 tiles per wave (96 accumulators, <= 256 registers): a wave of another kernel fits beside it on every SIMD, so the
+// HBM-bound backward chain of the training step (gather backward, gradient sort, segment sums, history filter backward) runs
+// UNDERNEATH the weight gradients instead of around them; 2.5x fewer partial blocks on top.  Default for operands that allow 16-byte
+// loads; LSTEP_WGRAD_BIG=1 keeps the big tiling (A/B).
+static WgradPlan wgrad_plan(int64_t m, int32_t n, int32_t k, bool allow_small = true) {
     WgradPlan pl;
     const int ntiles = (n + 15) / 16, ktiles = (k + 15) / 16;
+    static const bool force_big = getenv("LSTEP_WGRAD_BIG") != nullptr;
+    pl.small = 0;
+    pl.k_blocks = pl.tasks = 0;
+    if (allow_small && !force_big && n % 4 == 0 && k % 4 == 0 && n >= 4 && k >= 4) {
+        pl.small = 1;
+        pl.nt = 6;
+        pl.ktw = 4;
+        const int n_blocks = (ntiles + 5) / 6;
+        pl.k_blocks = (ktiles + 3) / 4;
+        const int tasks = n_blocks * pl.k_blocks;
+        pl.tasks = tasks;
+        pl.gz = pl.gy = 1;
+        int splits = 1024 / tasks;       // one wave per SIMD, no idle slot: waves are numbered over (slice, task)
+        if (splits < 1) splits = 1;
+        pl.rows_per_wg = round_up((m + splits - 1) / splits, 40);   // whole ping-pong rounds (2 blocks x 5 steps x 4 rows)
+        if (pl.rows_per_wg < 40) pl.rows_per_wg = 40;
+        pl.splits = (int)((m + pl.rows_per_wg - 1) / pl.rows_per_wg);
+        if (pl.splits < 1) pl.splits = 1;
+        pl.bias_off = (int32_t)round_up((int64_t)n * k, 4);
+        pl.part_stride = pl.bias_off + round_up(n, 4);
+        return pl;
+    }
     // n-tiles per workgroup: 11 (N = 176) or 9 (N = 288 in two halves), whichever wastes fewer tile slots
     const int waste11 = (ntiles + 10) / 11 * 11 - ntiles, waste9 = (ntiles + 8) / 9 * 9 - ntiles;
     pl.nt = waste9 < waste11 ? 9 : 11;
@@ -373,8 +416,9 @@ using namespace lstep;
 
 extern "C" int64_t lstep_linear_wgrad_workspace(int64_t m, int32_t n, int32_t k) {
     if (m < 0 || n <= 0 || k <= 0) return 0;
-    const WgradPlan pl = wgrad_plan(m, n, k);
-    return (int64_t)pl.splits * pl.part_stride * (int64_t)sizeof(float);
+    const WgradPlan a = wgrad_plan(m, n, k, true), b = wgrad_plan(m, n, k, false);     // (the operands' alignment decides at launch time)
+    const int64_t need_a = (int64_t)a.splits * a.part_stride, need_b = (int64_t)b.splits * b.part_stride;
+    return (need_a > need_b ? need_a : need_b) * (int64_t)sizeof(float);
 }
 
 extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t m, int32_t n, int32_t k, float* dw,
@@ -385,17 +429,21 @@ extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, 
     if (workspace_bytes < lstep_linear_wgrad_workspace(m, n, k)) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: workspace too small");
     if (((uintptr_t)workspace & 15) != 0) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const WgradPlan pl = wgrad_plan(m, n, k);
-    WgradParams p;
-    p.dy = dy; p.x = x; p.part = (float*)workspace;
-    p.m = m; p.rows_per_wg = pl.rows_per_wg; p.part_stride = pl.part_stride;
-    p.ldy = ldy; p.ldx = ldx; p.n = n; p.k = k; p.bias_off = pl.bias_off;
-    const dim3 grid((unsigned)pl.splits, (unsigned)pl.gy, (unsigned)pl.gz), block(kBlock);
     // 16-byte operand loads need 16-byte aligned rows and whole float4s inside the matrices; anything else takes the dword kernel
     static const bool no_wide = getenv("LSTEP_WGRAD_DWORD") != nullptr;      // A/B switch (tools/wgrad_bench.py)
     const bool wide = !no_wide && n % 4 == 0 && k % 4 == 0 && n >= 4 && k >= 4 && ldy % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dy & 15) == 0 &&
                       ((uintptr_t)x & 15) == 0;
-    if (wide) {
+    const WgradPlan pl = wgrad_plan(m, n, k, wide);
+    WgradParams p;
+    p.dy = dy; p.x = x; p.part = (float*)workspace;
+    p.m = m; p.rows_per_wg = pl.rows_per_wg; p.part_stride = pl.part_stride;
+    p.ldy = ldy; p.ldx = ldx; p.n = n; p.k = k; p.bias_off = pl.bias_off; p.k_blocks = pl.k_blocks;
+    p.tasks = pl.small ? pl.tasks : 0; p.slices = pl.splits;
+    const dim3 grid((unsigned)pl.splits, (unsigned)pl.gy, (unsigned)pl.gz), block(kBlock);
+    if (pl.small) {
+        const dim3 flat((unsigned)(((int64_t)pl.splits * pl.tasks + kWavesPerBlock - 1) / kWavesPerBlock));
+        hipLaunchKernelGGL((wgrad_partial_v2_kernel<1, 2, 1, 0, 5>), flat, block, 0, s, p);
+    } else if (wide) {
         if (pl.nt == 11 && pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_v2_kernel<2, 3, 1, 1, 4>), grid, block, 0, s, p);
         else if (pl.nt == 11) hipLaunchKernelGGL((wgrad_partial_v2_kernel<2, 3, 0, 3, 4>), grid, block, 0, s, p);
         else if (pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_v2_kernel<2, 1, 1, 1, 4>), grid, block, 0, s, p);

@@ -15,6 +15,7 @@
 //     lane (i, g) -- exactly the B element the MFMA "v" above wants for k = 16t + 4g + v.  So h1, p1 and q never leave the
 //     registers between the layers (they are also written out once, for the backward pass).
 // The weights stream from L2 (1.2 MB, shared by every wave); the activations are read once from HBM.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "lstep_mma.h"
