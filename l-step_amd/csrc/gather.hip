@@ -291,6 +291,8 @@ __device__ __forceinline__ void atomic_add_row(float* dst, const float g[4], int
     }
 }
 
+constexpr int kBwdRows = 8;      // edge rows in flight per wave in the backward kernel (power of two <= 32)
+
 template <bool kExplicit = false>
 __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdParams p) {
     const int lane = lane_id();
@@ -343,27 +345,63 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
             }
         }
         if (do_edge) {
+            // Settled metadata, kBwdRows edge rows in flight, the slots' time-feature dots computed while they travel, and ONE butterfly
+            // reduce-scatter per group: at offsets 32 / 16 / 8 a lane hands the half of the partial sums its partner keeps across and
+            // adds what it receives (4 + 2 + 1 exchanges), offsets 4 / 2 / 1 finish the one sum left (3 more): 10 exchanges for 8 slots
+            // instead of 48, and the first seven are independent of each other within a level.
+            settle(nb ^ ed ^ __float_as_int(dt));
             float mine = 0.f;  // lane j keeps the dot product of slot c0 + j
-            for (int j = 0; j < m; j += 4) {
-                float4 re[4];
+            for (int j = 0; j < m; j += kBwdRows) {
+                int64_t ej[kBwdRows];
+                float4 re[kBwdRows];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool live = (j + u) < m;
-                    const int64_t ej = bcast_i32(ed, live ? (j + u) : (m - 1));
-                    re[u] = (fa && live) ? ld4_stream(p.edge_raw + ej * F + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < kBwdRows; ++u) {     // tail slots re-read the last live row (cache hit, no branch); their sums are dropped
+                    ej[u] = bcast_i32(ed, (j + u) < m ? (j + u) : (m - 1));
                 }
+                if (fa) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if ((j + u) >= m) break;
-                    float part = dot4(gE, re[u]);
-                    if (bcast_i32(nb, j + u) != 0) {
+                    for (int u = 0; u < kBwdRows; ++u) re[u] = ld4_stream(p.edge_raw + ej[u] * F + lane * 4);
+                }
+                float part[kBwdRows];
+#pragma unroll
+                for (int u = 0; u < kBwdRows; ++u) {
+                    part[u] = 0.f;
+                    if ((j + u) < m && bcast_i32(nb, j + u) != 0) {     // wave-uniform
                         const float dj = bcast_f32(dt, j + u);
-                        if (lane < D) part = fmaf(gt0, time_feat(dj, w0, b0), part);
-                        if (lane + kWave < D) part = fmaf(gt1, time_feat(dj, w1, b1), part);
+                        part[u] = gt0 * time_feat(dj, w0, b0);          // (lanes past D hold gt = 0)
+                        part[u] = fmaf(gt1, time_feat(dj, w1, b1), part[u]);
                     }
-                    part = wave_sum(part);
-                    if (lane == j + u) mine = part;
                 }
+                if (fa) {      // (same predicate as the loads: the rows need no merge value)
+#pragma unroll
+                    for (int u = 0; u < kBwdRows; ++u) {
+                        // opaque to the optimiser up to here: otherwise it re-pairs the components of neighbouring rows for packed
+                        // multiplies with copies placed right behind the loads, and waits for every row before the cosines start
+                        asm volatile("" : "+v"(re[u].x), "+v"(re[u].y), "+v"(re[u].z), "+v"(re[u].w));
+                        part[u] += dot4(gE, re[u]);
+                    }
+                }
+#pragma unroll
+                for (int half = kBwdRows / 2, off = 32; half >= 1; half >>= 1, off >>= 1) {
+                    const bool upper = (lane & off) != 0;
+#pragma unroll
+                    for (int i = 0; i < half; ++i) {
+                        const float send = upper ? part[i] : part[i + half];
+                        const float keep = upper ? part[i + half] : part[i];
+                        part[i] = keep + __shfl_xor(send, off, kWave);
+                    }
+                }
+                float v = part[0];
+#pragma unroll
+                for (int off = 64 / kBwdRows / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+                // slot u of the group ended up in the lanes whose bits 5, 4, 3 spell u (bit 5 picked the upper half first); lane j + u
+                // fetches it, and the chunk's dots leave with ONE store after the loop (a store per group would make the next group's
+                // loads wait for it: stores and loads share the vmcnt counter)
+                int src = 0;
+#pragma unroll
+                for (int half = kBwdRows / 2, off = 32; half >= 1; half >>= 1, off >>= 1) src += ((lane & (kBwdRows - 1)) & half) ? off : 0;
+                const float got = __shfl(v, src, kWave);
+                if (lane >= j && lane < j + kBwdRows) mine = got;
             }
             if (lane < m) p.out_slot_dot[row * (int64_t)K + npad + c0 + lane] = mine;
         }
