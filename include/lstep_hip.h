@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 25
+#define LSTEP_ABI_VERSION 27
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -405,6 +405,21 @@ int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_
 int lstep_update_entries_p2(const int32_t* order, const int32_t* seg, int64_t n_real, const int64_t* bn, const float* nt, const float* now32,
                             int32_t num_neighbors, int32_t shift, const int32_t* uniq, int64_t nseg, int32_t* ent_row, float* ent_dt,
                             int32_t* ent_seg, int64_t* touched, void* stream);
+
+/* Operands of lstep_head_fwd / _bwd from the reference-shaped parameters of MergeLayer (models/modules.py:52-53: fc1.weight
+ * [hidden, 2 * half], fc1.bias [hidden], fc2.weight [1, hidden]; hidden, half <= 176) in one launch: w [176, 352] = [first half | second half]
+ * zero-padded, wt [352, 176] its transpose, b1 [176], w2 [176]. */
+int lstep_head_pack(const float* fc1_w, const float* fc1_b, const float* fc2_w, int32_t hidden, int32_t half, float* w, float* wt, float* b1,
+                    float* w2, void* stream);
+
+/* `optimizer.step()` of the training loop (train_LSTEP_link_prediction.py:283; utils/utils.py:49-67 creates a plain torch.optim.Adam: no
+ * amsgrad, L2-style weight decay) for up to LSTEP_ADAM_MAX_TENSORS fp32 tensors in ONE launch: host arrays of device pointers (they travel
+ * in the kernel arguments), numel per tensor, `steps` float32 on the device = step counts INCLUDING this step; tensor t uses
+ * steps[step_index[t]] (host array; NULL = t).
+ * Same arithmetic as torch._fused_adam_ (bias corrections in double, moments and update in float). */
+#define LSTEP_ADAM_MAX_TENSORS 48
+int lstep_adam_step(int32_t num_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* numel, const float* steps, const int32_t* step_index, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

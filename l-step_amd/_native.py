@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
-SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip", "update.hip"]
+SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip", "update.hip", "adam.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 25
+ABI_VERSION = 27
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -72,6 +72,7 @@ _LIB = None
 _P, _I32, _I64, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
 SIGNATURES = {
     "lstep_abi_version": (C.c_int, []),
+    "lstep_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "lstep_last_error": (C.c_char_p, []),
     "lstep_sample_recent": (C.c_int, [C.POINTER(CsrStruct), _P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "lstep_time_encode": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P, _P]),
@@ -119,6 +120,7 @@ SIGNATURES = {
     "lstep_update_entries_p2_dev": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_fwd": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_bwd": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "lstep_head_pack": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "lstep_link_loss_workspace": (_I64, [_I64]),
     "lstep_link_loss": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _I64, _P]),
     "lstep_sort_live_workspace": (_I64, [_I64, _I32]),

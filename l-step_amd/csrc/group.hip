@@ -3,6 +3,8 @@
 //   (2) sampled neighbour ids of update_pe phase 2 -> touched rows + their message segments   (LSTEP.py:319-324)
 //   (3) spliced-row hits of the gather backward -> gradient segments
 // One stable radix sort (hipCUB) + head flags + one scan instead of ~50 small framework launches per use.
+#include <stdlib.h>
+
 #include <hipcub/hipcub.hpp>
 #include <rocprim/rocprim.hpp>
 
@@ -42,6 +44,67 @@ __global__ void widen_ids_kernel(const int32_t* __restrict__ ids32, int64_t capa
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---- up to 4096 keys: the whole grouping in ONE workgroup (block radix sort, head flags, block scan, unique, summary).  The reference's
+// own batch sizes (200 / 600 edges: 400 / 1200 endpoints) otherwise pay for ~12 dependent library launches of a few microseconds each at
+// the very start of every iteration.  Same outputs as the multi-launch path (the sort is stable in both).
+constexpr int kSmallThreads = 256;
+template <int ITEMS>
+__global__ __launch_bounds__(kSmallThreads) void group_small_kernel(const int32_t* __restrict__ keys, int n, int bits, int32_t limit,
+                                                                    int32_t* __restrict__ sorted_keys, int32_t* __restrict__ order,
+                                                                    int32_t* __restrict__ seg, int32_t* __restrict__ uniq,
+                                                                    int32_t* __restrict__ summary) {
+    using Sort = rocprim::block_radix_sort<uint32_t, kSmallThreads, ITEMS, int32_t>;
+    using Scan = rocprim::block_scan<int32_t, kSmallThreads>;
+    __shared__ union {
+        typename Sort::storage_type sort;
+        typename Scan::storage_type scan;
+    } tmp;
+    __shared__ uint32_t sk[kSmallThreads * ITEMS + 1];
+    const int t = threadIdx.x;
+    uint32_t k[ITEMS];
+    int32_t v[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = t * ITEMS + j;                     // blocked arrangement: stability = input order
+        k[j] = idx < n ? (uint32_t)keys[idx] : 0xFFFFFFFFu;   // padding sorts last (real keys are non-negative int32)
+        v[j] = idx;
+    }
+    // pad keys have bits above `bits` set; sort them on one more bit range so that they stay behind every real key
+    Sort().sort(k, v, tmp.sort, 0u, 32u);
+    (void)bits;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) sk[t * ITEMS + j + 1] = k[j];
+    if (t == 0) sk[0] = 0xFFFFFFFFu;
+    __syncthreads();
+    int32_t flag[ITEMS], local = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = t * ITEMS + j;
+        flag[j] = (idx > 0 && idx < n && sk[idx] != k[j]) ? 1 : 0;     // sk[idx] = the key before entry idx
+        local += flag[j];
+    }
+    int32_t before = 0;
+    Scan().exclusive_scan(local, before, 0, tmp.scan);
+    int32_t run = before;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = t * ITEMS + j;
+        run += flag[j];
+        if (idx < n) {
+            const int32_t key = (int32_t)k[j];
+            sorted_keys[idx] = key;
+            order[idx] = v[j];
+            seg[idx] = run;
+            if (idx == 0 || flag[j]) uniq[run] = key;
+            if (idx == n - 1) summary[0] = run + 1;
+            const bool below = key < limit;
+            const uint32_t next = idx + 1 < n ? sk[idx + 2] : 0xFFFFFFFFu;     // the key after entry idx
+            if (below && (idx == n - 1 || (int64_t)next >= (int64_t)limit)) { summary[1] = idx + 1; summary[2] = run + 1; }
+            if (idx == 0 && !below) { summary[1] = 0; summary[2] = 0; }
+        }
+    }
+}
 
 // Stable LSD radix sort of (key, value) pairs on the low `bits` key bits.  The library's default switches to a merge sort below
 // 1 M items; measured here (MI355X, 15-20 key bits): merge sort 8 launches / 36 us at 32 k items but 21 launches / 250 us at 330 k,
@@ -114,6 +177,16 @@ extern "C" int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bi
     }
     if (!keys || !workspace || !sorted_keys || !order || !seg || !uniq) return set_error(LSTEP_EINVAL, "lstep_group_by_key: NULL pointer");
     if (workspace_bytes < lstep_group_by_key_workspace(n, key_bits)) return set_error(LSTEP_EINVAL, "lstep_group_by_key: workspace too small");
+    const char* no_small = getenv("LSTEP_GROUP_NO_SMALL");      // A/B and the parity test: read per call
+    if (n <= kSmallThreads * 16 && !(no_small && no_small[0] == '1')) {
+        if (n <= kSmallThreads * 2)
+            hipLaunchKernelGGL(group_small_kernel<2>, dim3(1), dim3(kSmallThreads), 0, s, keys, (int)n, key_bits, limit, sorted_keys, order, seg, uniq, summary);
+        else if (n <= kSmallThreads * 8)
+            hipLaunchKernelGGL(group_small_kernel<8>, dim3(1), dim3(kSmallThreads), 0, s, keys, (int)n, key_bits, limit, sorted_keys, order, seg, uniq, summary);
+        else
+            hipLaunchKernelGGL(group_small_kernel<16>, dim3(1), dim3(kSmallThreads), 0, s, keys, (int)n, key_bits, limit, sorted_keys, order, seg, uniq, summary);
+        return check_launch("group_small_kernel");
+    }
     char* ws = (char*)workspace;
     int32_t* idx = (int32_t*)ws;
     int32_t* flag = (int32_t*)(ws + align256((size_t)n * 4));

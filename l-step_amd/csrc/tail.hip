@@ -287,6 +287,293 @@ __global__ __launch_bounds__(kBlock, 1) void tail_bwd_kernel(const TailBwdParams
     }
 }
 
+// ---- few rows: ONE slab per workgroup, the output tiles of every layer dealt out to its four waves --------------------------------------
+// At the reference's own batch sizes (B = 200 .. 4096: 38 .. 768 slabs) the kernels above leave most SIMDs idle while one wave walks a slab
+// through the whole layer chain (4 588 dependent-issue MFMAs, ~105 us whatever the row count).  Here wave w of a workgroup owns the output
+// tiles w, w + 4, w + 8, ... of each layer; a finished layer goes to LDS in its accumulator layout -- which IS the B-operand layout of the
+// next product (lstep_mma.h) -- and one barrier later every wave reads all of it.  Same sums per output element, a quarter of the chain per wave.
+constexpr int kSplitMaxSlabs = 800;     // measured: 12 288 rows 107 / 88 us split vs 116 / 99 us whole (fwd / bwd); 16 384 rows 133 / 116 vs 112 / 101
+
+// tile j of a wave: t = w + 4 j; waves whose last tile does not exist recompute their first one and drop it
+template <int T>
+struct WaveTiles {
+    int t[T];
+    bool valid[T];
+    __device__ __forceinline__ WaveTiles(int w, int tiles) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            valid[j] = w + 4 * j < tiles;
+            t[j] = valid[j] ? w + 4 * j : w;
+        }
+    }
+};
+
+// acc[j] += sum over `chunks` 16-wide k chunks of (weight tile at wt[j])[i][k] * X[row i][k], X from global memory (xl = this lane's position)
+template <int T>
+__device__ __forceinline__ void mma1_wx(f32x4 (&acc)[T], const float* const (&wt)[T], int chunks, const float* xl) {
+    struct Ch { f32x4 a[T]; f32x4 b; };
+    auto load = [&](Ch& o, int c) {
+        o.b = ldv4(xl + 16 * c);
+#pragma unroll
+        for (int j = 0; j < T; ++j) o.a[j] = ldv4(wt[j] + 16 * c);
+    };
+    auto run = [&](const Ch& o) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = mfma4(o.a[j][v], o.b[v], acc[j]);
+        }
+    };
+    Ch c0, c1;
+    load(c0, 0);
+    for (int c = 0; c < chunks; c += 2) {
+        const bool two = c + 1 < chunks;
+        if (two) load(c1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(c0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) {
+            if (c + 2 < chunks) load(c0, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            run(c1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// acc[j] += sum over the TK tiles of a layer held in LDS (tile tk of lane l at lds[tk * 64 + l]) of (weight tile at wt[j])[i][16 tk + k] * tile
+template <int T, int TK>
+__device__ __forceinline__ void mma1_wl(f32x4 (&acc)[T], const float* const (&wt)[T], const f32x4* lds, int lane) {
+    f32x4 a[2][T], b[2];
+#pragma unroll
+    for (int j = 0; j < T; ++j) a[0][j] = ldv4(wt[j]);
+    b[0] = lds[lane];
+#pragma unroll
+    for (int tk = 0; tk < TK; ++tk) {
+        if (tk + 1 < TK) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) a[(tk + 1) & 1][j] = ldv4(wt[j] + 16 * (tk + 1));
+            b[(tk + 1) & 1] = lds[(tk + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[j] = mfma4(a[tk & 1][j][v], b[tk & 1][v], acc[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+constexpr int kSplitTp = (kTp + 3) / 4, kSplitTe = (kTe + 3) / 4, kSplitTn = (kTn + 3) / 4;   // tiles per wave: 3, 5, 3
+
+__global__ __launch_bounds__(kBlock) void tail_fwd_split_kernel(const TailFwdParams p) {
+    __shared__ f32x4 s_p1[kTp * 64], s_q[kTp * 64], s_h1[kTe * 64];
+    const int lane = lane_id(), w = wave_in_block();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    const bool live = r0 + i < p.m;
+    const int64_t row = live ? r0 + i : p.m - 1;
+    const float* xe_l = p.xe + row * p.ld_e + 4 * g;
+    const float* xp_l = p.xp + row * p.ld_p + 4 * g;
+    const float* c1_l = p.c1 + row * kC1 + 4 * g;
+    const float* c2_l = p.c2 + row * kC2 + 4 * g;
+    const WaveTiles<kSplitTp> tp(w, kTp);
+    const WaveTiles<kSplitTe> te(w, kTe);
+    const WaveTiles<kSplitTn> tn(w, kTn);
+
+    {   // ---- p1 = relu(Wn1 x_pe + bn1)
+        f32x4 acc[kSplitTp];
+        const float* wt[kSplitTp];
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            acc[j] = ldv4(p.bn1 + 16 * tp.t[j] + 4 * g);
+            wt[j] = p.wn1 + (size_t)(16 * tp.t[j] + i) * kCe + 4 * g;
+        }
+        mma1_wx<kSplitTp>(acc, wt, kTe, xp_l);
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[j][v] = fmaxf(acc[j][v], 0.f);
+            if (tp.valid[j]) {
+                s_p1[tp.t[j] * 64 + lane] = acc[j];
+                if (live) *reinterpret_cast<f32x4*>(p.c2 + row * kC2 + kPp + 16 * tp.t[j] + 4 * g) = acc[j];
+            }
+        }
+    }
+    {   // ---- h1 = relu(W1 x_edge + b1)
+        f32x4 acc[kSplitTe];
+        const float* wt[kSplitTe];
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j) {
+            acc[j] = ldv4(p.b1 + 16 * te.t[j] + 4 * g);
+            wt[j] = p.w1 + (size_t)(16 * te.t[j] + i) * kCe + 4 * g;
+        }
+        mma1_wx<kSplitTe>(acc, wt, kTe, xe_l);
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[j][v] = fmaxf(acc[j][v], 0.f);
+            if (te.valid[j]) {
+                s_h1[te.t[j] * 64 + lane] = acc[j];
+                if (live) *reinterpret_cast<f32x4*>(p.c1 + row * kC1 + kFn + 16 * te.t[j] + 4 * g) = acc[j];
+            }
+        }
+    }
+    __syncthreads();
+    {   // ---- q = own + tanh(Wq [own ; p1] + bq)
+        f32x4 acc[kSplitTp];
+        const float *wt[kSplitTp], *wt2[kSplitTp];
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            acc[j] = ldv4(p.bq + 16 * tp.t[j] + 4 * g);
+            wt[j] = p.wq + (size_t)(16 * tp.t[j] + i) * kC2 + 4 * g;
+            wt2[j] = wt[j] + kPp;
+        }
+        mma1_wx<kSplitTp>(acc, wt, kTp, c2_l);
+        mma1_wl<kSplitTp, kTp>(acc, wt2, s_p1, lane);
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            const f32x4 own = ldv4(p.c2 + row * kC2 + 16 * tp.t[j] + 4 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[j][v] = own[v] + tanhf(acc[j][v]);
+            if (tp.valid[j]) {
+                s_q[tp.t[j] * 64 + lane] = acc[j];
+                if (live) *reinterpret_cast<f32x4*>(p.c1 + row * kC1 + kFn + kCe + 16 * tp.t[j] + 4 * g) = acc[j];
+            }
+        }
+    }
+    __syncthreads();
+    {   // ---- out = Wall [x_node ; h1 ; q] + ball
+        f32x4 acc[kSplitTn];
+        const float *wt[kSplitTn], *wt_h[kSplitTn], *wt_q[kSplitTn];
+#pragma unroll
+        for (int j = 0; j < kSplitTn; ++j) {
+            acc[j] = ldv4(p.ball + 16 * tn.t[j] + 4 * g);
+            wt[j] = p.wall + (size_t)(16 * tn.t[j] + i) * kC1 + 4 * g;
+            wt_h[j] = wt[j] + kFn;
+            wt_q[j] = wt[j] + kFn + kCe;
+        }
+        mma1_wx<kSplitTn>(acc, wt, kTn, c1_l);
+        mma1_wl<kSplitTn, kTp>(acc, wt_q, s_q, lane);
+        mma1_wl<kSplitTn, kTe>(acc, wt_h, s_h1, lane);
+#pragma unroll
+        for (int j = 0; j < kSplitTn; ++j)
+            if (tn.valid[j] && live) *reinterpret_cast<f32x4*>(p.out + row * kFn + 16 * tn.t[j] + 4 * g) = acc[j];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tail_bwd_split_kernel(const TailBwdParams p) {
+    __shared__ f32x4 s_dz[kTp * 64], s_dp1[kTp * 64], s_dh1[kTe * 64];
+    const int lane = lane_id(), w = wave_in_block();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    const bool live = r0 + i < p.m;
+    const int64_t row = live ? r0 + i : p.m - 1;
+    const float* g_l = p.g + row * kFn + 4 * g;
+    const WaveTiles<kSplitTp> tp(w, kTp);
+    const WaveTiles<kSplitTe> te(w, kTe);
+    auto zero = [](auto& a) {
+        for (auto& x : a) x = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    f32x4 dq[kSplitTp];
+    {   // ---- d_q = WallT[q rows] g;  d_z = d_q (1 - tanh^2)
+        const float* wt[kSplitTp];
+        zero(dq);
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) wt[j] = p.wallt + (size_t)(kFn + kCe + 16 * tp.t[j] + i) * kFn + 4 * g;
+        mma1_wx<kSplitTp>(dq, wt, kTn, g_l);
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            const f32x4 qv = ldv4(p.c1 + row * kC1 + kFn + kCe + 16 * tp.t[j] + 4 * g);
+            const f32x4 ov = ldv4(p.c2 + row * kC2 + 16 * tp.t[j] + 4 * g);
+            f32x4 dz;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float th = qv[v] - ov[v];
+                dz[v] = dq[j][v] * (1.f - th * th);
+            }
+            if (tp.valid[j]) {
+                s_dz[tp.t[j] * 64 + lane] = dz;
+                if (live) *reinterpret_cast<f32x4*>(p.dz + row * kPp + 16 * tp.t[j] + 4 * g) = dz;
+            }
+        }
+    }
+    {   // ---- d_h1 = WallT[h1 rows] g * [h1 > 0]
+        f32x4 dh[kSplitTe];
+        const float* wt[kSplitTe];
+        zero(dh);
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j) wt[j] = p.wallt + (size_t)(kFn + 16 * te.t[j] + i) * kFn + 4 * g;
+        mma1_wx<kSplitTe>(dh, wt, kTn, g_l);
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j) {
+            const f32x4 hv = ldv4(p.c1 + row * kC1 + kFn + 16 * te.t[j] + 4 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dh[j][v] = hv[v] > 0.f ? dh[j][v] : 0.f;
+            if (te.valid[j]) {
+                s_dh1[te.t[j] * 64 + lane] = dh[j];
+                if (live) *reinterpret_cast<f32x4*>(p.dh1 + row * kCe + 16 * te.t[j] + 4 * g) = dh[j];
+            }
+        }
+    }
+    __syncthreads();
+    {   // ---- d_own = d_q + WqT[own rows] d_z;  d_p1 = WqT[p1 rows] d_z * [p1 > 0]
+        const float *wt[kSplitTp], *wt2[kSplitTp];
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            wt[j] = p.wqt + (size_t)(16 * tp.t[j] + i) * kPp + 4 * g;
+            wt2[j] = wt[j] + (size_t)kPp * kPp;
+        }
+        mma1_wl<kSplitTp, kTp>(dq, wt, s_dz, lane);
+        f32x4 dp[kSplitTp];
+        zero(dp);
+        mma1_wl<kSplitTp, kTp>(dp, wt2, s_dz, lane);
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            const f32x4 pv = ldv4(p.c2 + row * kC2 + kPp + 16 * tp.t[j] + 4 * g);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dp[j][v] = pv[v] > 0.f ? dp[j][v] : 0.f;
+            if (tp.valid[j]) {
+                s_dp1[tp.t[j] * 64 + lane] = dp[j];
+                if (live) {
+                    *reinterpret_cast<f32x4*>(p.down + row * p.ld_down + 16 * tp.t[j] + 4 * g) = dq[j];
+                    *reinterpret_cast<f32x4*>(p.dp1 + row * kPp + 16 * tp.t[j] + 4 * g) = dp[j];
+                }
+            }
+        }
+    }
+    {   // ---- d_xedge = W1T d_h1
+        f32x4 dx[kSplitTe];
+        const float* wt[kSplitTe];
+        zero(dx);
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j) wt[j] = p.w1t + (size_t)(16 * te.t[j] + i) * kCe + 4 * g;
+        mma1_wl<kSplitTe, kTe>(dx, wt, s_dh1, lane);
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j)
+            if (te.valid[j] && live) *reinterpret_cast<f32x4*>(p.dxe + row * kCe + 16 * te.t[j] + 4 * g) = dx[j];
+    }
+    __syncthreads();
+    {   // ---- d_xpe = Wn1T d_p1
+        f32x4 dx[kSplitTe];
+        const float* wt[kSplitTe];
+        zero(dx);
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j) wt[j] = p.wn1t + (size_t)(16 * te.t[j] + i) * kPp + 4 * g;
+        mma1_wl<kSplitTe, kTp>(dx, wt, s_dp1, lane);
+#pragma unroll
+        for (int j = 0; j < kSplitTe; ++j)
+            if (te.valid[j] && live) *reinterpret_cast<f32x4*>(p.dxp + row * kCe + 16 * te.t[j] + 4 * g) = dx[j];
+    }
+}
+
+static bool tail_split(int64_t m) {
+    const char* off = getenv("LSTEP_TAIL_NO_SPLIT");   // A/B and the split-vs-whole parity test: read per call
+    return !(off && off[0] == '1') && (m + 15) / 16 <= kSplitMaxSlabs;
+}
+
 // ---- update_pe: z = pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(own)], table[id] += tanh(z)  (models/LSTEP.py:292-303, 327-339) ----
 struct UpdateParams {
     const float* agg;      // [>= n, ld_agg]  aggregated messages cat[pe, time] (kCe used)
@@ -419,10 +706,14 @@ extern "C" int lstep_tail_fwd(const float* x_edge, int32_t ld_edge, const float*
     p.xe = x_edge; p.xp = x_pe; p.c1 = cat1; p.c2 = cat2; p.out = out;
     p.w1 = w1; p.b1 = b1; p.wn1 = wn1; p.bn1 = bn1; p.wq = wq; p.bq = bq; p.wall = wall; p.ball = ball;
     p.m = m; p.ld_e = ld_edge; p.ld_p = ld_pe;
+    hipStream_t s = (hipStream_t)stream;
+    if (tail_split(m)) {
+        hipLaunchKernelGGL(tail_fwd_split_kernel, dim3((unsigned)((m + 15) / 16)), dim3(kBlock), 0, s, p);
+        return check_launch("lstep_tail_fwd<split>");
+    }
     const int S = tail_slabs_per_wave(m);
     const int64_t tasks = ((m + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
-    hipStream_t s = (hipStream_t)stream;
     if (S == 1) hipLaunchKernelGGL(tail_fwd_kernel<1>, grid, block, 0, s, p);
     else if (S == 2) hipLaunchKernelGGL(tail_fwd_kernel<2>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(tail_fwd_kernel<3>, grid, block, 0, s, p);
@@ -439,10 +730,14 @@ extern "C" int lstep_tail_bwd(const float* grad_out, const float* cat1, const fl
     TailBwdParams p;
     p.g = grad_out; p.c1 = cat1; p.c2 = cat2; p.w1t = w1t; p.wn1t = wn1t; p.wqt = wqt; p.wallt = wallt;
     p.dxe = d_xedge; p.dxp = d_xpe; p.down = d_own; p.dh1 = d_h1; p.dp1 = d_p1; p.dz = d_z; p.m = m; p.ld_down = ld_down;
+    hipStream_t s = (hipStream_t)stream;
+    if (tail_split(m)) {
+        hipLaunchKernelGGL(tail_bwd_split_kernel, dim3((unsigned)((m + 15) / 16)), dim3(kBlock), 0, s, p);
+        return check_launch("lstep_tail_bwd<split>");
+    }
     const int S = tail_slabs_per_wave(m);
     const int64_t tasks = ((m + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
-    hipStream_t s = (hipStream_t)stream;
     if (S == 1) hipLaunchKernelGGL(tail_bwd_kernel<1>, grid, block, 0, s, p);
     else if (S == 2) hipLaunchKernelGGL(tail_bwd_kernel<2>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(tail_bwd_kernel<3>, grid, block, 0, s, p);

@@ -457,8 +457,9 @@ class GraphedTrainStep:
         ring._advanced = [None, None]          # events of eager iterations must not be waited for inside the capture
         if ring.dev_start is None:
             ring.position_on_device()
+        from .model import _no_gc
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with _no_gc(), torch.cuda.graph(graph):
             with eng.aux_streams():
                 self.out = eng._train_iteration(self.optimizer, batch_idx, self.src, self.dst, self.ts, self.eid, self.neg, None, None)
             main = torch.cuda.current_stream(eng.device)

@@ -20,6 +20,8 @@ filter is applied as its equivalent real ``[T, P]`` coefficient table (everythin
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import math
 import os
 import warnings
@@ -258,7 +260,7 @@ class _TailWeightsGraph:
                 _tail_weights_forward(self.dims, *self._detached())   # warm-up outside the capture (library handles, workspaces)
                 torch.cuda.current_stream().synchronize()
                 self.g_fwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
                     self.outs, self.transposed, self.saved = _tail_weights_forward(self.dims, *self._detached())
         if self.prepared is not None:        # replayed ahead of time on the auxiliary stream (LSTEP.prepare_step): just wait for it
             torch.cuda.current_stream().wait_event(self.prepared)
@@ -305,12 +307,26 @@ class _TailWeightsGraph:
                 _tail_weights_backward(*args)
                 torch.cuda.current_stream().synchronize()
                 self.g_bwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_bwd, capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(self.g_bwd, capture_error_mode="thread_local"):
                     self.pgrads = _tail_weights_backward(*args)
                 for g, k in zip(self.gin, keep):
                     g.copy_(k)
         self.g_bwd.replay()
         return self.pgrads
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream is capturing: a collection that happens to run inside the capture may destroy an
+    unrelated ``torch.cuda.CUDAGraph`` (an earlier model's) on the capturing thread, which the runtime refuses mid-capture and the
+    destructor turns into an abort (seen once in a long test session, in the autograd thread)."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class _LiveToken:
@@ -493,19 +509,21 @@ class _Head(torch.autograd.Function):
         dev = emb.device
         half = fc1_w.shape[1] // 2                      # 172
         Hd = emb.shape[1]                               # 176
-        flat = torch.zeros(Hd * 2 * Hd + 2 * Hd, dtype=torch.float32, device=dev)
-        wp, b1p, w2p = flat[:Hd * 2 * Hd].view(Hd, 2 * Hd), flat[Hd * 2 * Hd:Hd * 2 * Hd + Hd], flat[Hd * 2 * Hd + Hd:]
-        wp[:half, :half] = fc1_w[:, :half]
-        wp[:half, Hd:Hd + half] = fc1_w[:, half:]
-        b1p[:half] = fc1_b
-        w2p[:half] = fc2_w[0]
+        # the padded operands of both directions in one launch (lstep_head_pack) instead of a fill, four slice copies and a transpose
+        flat = torch.empty(2 * Hd * 2 * Hd + 2 * Hd, dtype=torch.float32, device=dev)
+        wp, wt = flat[:Hd * 2 * Hd].view(Hd, 2 * Hd), flat[Hd * 2 * Hd:2 * Hd * 2 * Hd].view(2 * Hd, Hd)
+        b1p, w2p = flat[2 * Hd * 2 * Hd:2 * Hd * 2 * Hd + Hd], flat[2 * Hd * 2 * Hd + Hd:]
         b2 = fc2_b.contiguous()
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_head_pack(nat.ptr(fc1_w.detach().contiguous()), nat.ptr(fc1_b.detach().contiguous()),
+                                          nat.ptr(fc2_w.detach().contiguous()), fc1_w.shape[0], half, nat.ptr(wp), nat.ptr(wt), nat.ptr(b1p),
+                                          nat.ptr(w2p), nat.current_stream()))
         h = torch.empty((2 * n, Hd), dtype=torch.float32, device=dev)
         logits = torch.empty(2 * n, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             nat.check(lib.lstep_head_fwd(nat.ptr(emb), n, *layout, nat.ptr(wp), nat.ptr(b1p), nat.ptr(w2p), nat.ptr(b2), nat.ptr(h),
                                          nat.ptr(logits), nat.current_stream()))
-        ctx.save_for_backward(emb, wp, w2p, h)
+        ctx.save_for_backward(emb, wt, w2p, h)
         ctx.n, ctx.half, ctx.layout = n, half, tuple(layout)
         ctx.aux, ctx.params = aux, (fc1_w, fc1_b, fc2_w, fc2_b)
         return logits
@@ -513,12 +531,11 @@ class _Head(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_logits):
         lib = nat.load_library()
-        emb, wp, w2p, h = ctx.saved_tensors
+        emb, wt, w2p, h = ctx.saved_tensors
         n, half, Hd, dev = ctx.n, ctx.half, emb.shape[1], emb.device
         if ctx.layout != (0, n, 0, 2 * n):
             raise NotImplementedError("lstep_head_bwd implements the training layout (src | dst | negative dst)")
         d_logits = d_logits.contiguous()
-        wt = wp.t().contiguous()
         d_emb = torch.empty((3 * n, Hd), dtype=torch.float32, device=dev)
         d_h = torch.empty((2 * n, Hd), dtype=torch.float32, device=dev)
         d_hsum = torch.empty((n, Hd), dtype=torch.float32, device=dev)

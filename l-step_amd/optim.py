@@ -1,15 +1,21 @@
 """Single-kernel Adam for the L-STEP parameter set.
 
-The reference optimises with plain ``torch.optim.Adam`` (``utils/utils.py:49-67``).  PyTorch's fused multi-tensor kernel
-(``torch._fused_adam_``) refuses complex parameters, and L-STEP has exactly one (``fft_filter.weight``, complex64).  Adam treats a
-complex tensor as its real view, so that parameter enters through ``view_as_real`` (same storage), its gradient likewise.  The kernel
-is called directly on cached tensor lists: ``torch.optim.Adam.step`` spends ~0.3 ms of host time per step on bookkeeping, which is
-5 % of a training iteration here.  Same update rule as ``torch.optim.Adam`` (no amsgrad, L2-style weight decay), checked against it
-in tests/test_hip_parity.py.
+The reference optimises with plain ``torch.optim.Adam`` (``utils/utils.py:49-67``).  L-STEP has one complex parameter
+(``fft_filter.weight``, complex64); Adam treats a complex tensor as its real view, so it enters through ``view_as_real`` (same storage),
+its gradient likewise.  The update is ONE native launch (``lstep_adam_step``, csrc/adam.hip: the ~45 tensor pointers travel in the kernel
+arguments, a workgroup takes 1024 elements): a few microseconds, where ``torch._fused_adam_`` takes 40 (a workgroup there loops over
+64 K elements) and ``torch.optim.Adam.step`` adds ~0.3 ms of host bookkeeping.  Same arithmetic as ``torch._fused_adam_`` (no amsgrad,
+L2-style weight decay), checked against ``torch.optim.Adam`` in tests/test_hip_parity.py.  ``LSTEP_TORCH_ADAM=1`` routes the step
+through ``torch._fused_adam_`` for A/B.
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
+
+from . import _native as nat
 
 
 class FusedAdam:
@@ -18,7 +24,7 @@ class FusedAdam:
         if not self._params:
             raise ValueError("optimizer got an empty parameter list")
         if not all(p.is_cuda for p in self._params):
-            raise ValueError("FusedAdam drives torch._fused_adam_: parameters must live on the GPU")
+            raise ValueError("FusedAdam is a GPU kernel: parameters must live on the GPU")
         self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), (float(betas[0]), float(betas[1])), float(eps)
         dev = self._params[0].device
         self._real = [torch.view_as_real(p.data) if p.is_complex() else p.data for p in self._params]
@@ -52,8 +58,22 @@ class FusedAdam:
             g = self._params[i].grad
             grads.append(torch.view_as_real(g) if g.is_complex() else g)
         self._steps.add_(bump)   # parameters without a gradient keep their step count, like torch.optim.Adam
-        torch._fused_adam_(params, grads, exp_avg, exp_avg_sq, [], steps, amsgrad=False, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                           weight_decay=self.weight_decay, eps=self.eps, maximize=False, grad_scale=None, found_inf=None)
+        if os.environ.get("LSTEP_TORCH_ADAM") == "1" or any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+            torch._fused_adam_(params, grads, exp_avg, exp_avg_sq, [], steps, amsgrad=False, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                               weight_decay=self.weight_decay, eps=self.eps, maximize=False, grad_scale=None, found_inf=None)
+            return
+        lib = nat.load_library()
+        dev = self._steps.device
+        cap = 48                  # LSTEP_ADAM_MAX_TENSORS
+        with torch.cuda.device(dev):
+            for lo in range(0, len(idx), cap):
+                hi = min(len(idx), lo + cap)
+                n = hi - lo
+                arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts[lo:hi]])  # noqa: E731
+                numel = (ctypes.c_int64 * n)(*[t.numel() for t in params[lo:hi]])
+                nat.check(lib.lstep_adam_step(n, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel,
+                                              self._steps.data_ptr(), (ctypes.c_int32 * n)(*idx[lo:hi]), self.lr, self.betas[0], self.betas[1], self.eps,
+                                              self.weight_decay, nat.current_stream()))
 
     def state_dict(self):
         return {"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps, "steps": self._steps.clone(),

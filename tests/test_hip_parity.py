@@ -452,7 +452,9 @@ def test_group_by_key_vs_torch(hip):
     from lstep_amd import _native as nat
     gen = torch.Generator(device=DEV)
     gen.manual_seed(3)
-    for n, hi, limit in ((1, 5, 5), (1000, 17, 10), (655360, 1_000_001, 1_000_001), (70000, 300, 300), (5000, 50, 0)):
+    # (up to 4096 keys the whole grouping is one workgroup: sizes at the edges of its three instantiations, limits inside and outside the key range)
+    for n, hi, limit in ((1, 5, 5), (1000, 17, 10), (655360, 1_000_001, 1_000_001), (70000, 300, 300), (5000, 50, 0), (400, 184, 185), (512, 9, 4),
+                         (513, 9000, 9001), (1200, 9227, 9228), (2048, 3, 0), (2049, 100000, 50000), (4096, 7, 8), (4097, 7, 8)):
         keys = torch.randint(0, hi + 1, (n,), generator=gen, device=DEV, dtype=torch.int32)
         bits = max(1, int(hi).bit_length())
         sk, order, seg, uniq, (nu, n_below, nu_below) = nat.group_by_key(keys, bits, limit)
@@ -525,11 +527,14 @@ def test_fused_adam_matches_torch_adam(hip):
     """lstep_amd.optim.FusedAdam (one fused kernel, complex parameter through its real view) vs torch.optim.Adam."""
     from lstep_amd.optim import FusedAdam
     torch.manual_seed(0)
+    # sizes around the kernel's 1024-element workgroups and 4-element vectors, one complex tensor, more tensors than one launch takes (48)
     mk = lambda: [torch.nn.Parameter(torch.randn(7, 5, dtype=torch.complex64, device=DEV)), torch.nn.Parameter(torch.randn(9, 4, device=DEV)),  # noqa: E731
-                  torch.nn.Parameter(torch.randn(4, device=DEV))]
+                  torch.nn.Parameter(torch.randn(4, device=DEV)), torch.nn.Parameter(torch.randn(272, 272, device=DEV)),
+                  torch.nn.Parameter(torch.randn(1025, device=DEV)), torch.nn.Parameter(torch.randn(3, device=DEV))] + \
+                 [torch.nn.Parameter(torch.randn(5 + i, device=DEV)) for i in range(50)]
     a = mk()
     b = [torch.nn.Parameter(p.detach().clone()) for p in a]
-    oa, ob = torch.optim.Adam(a, lr=1e-2), FusedAdam(b, lr=1e-2)
+    oa, ob = torch.optim.Adam(a, lr=1e-2, weight_decay=1e-3), FusedAdam(b, lr=1e-2, weight_decay=1e-3)
     for step in range(5):
         grads = [torch.randn_like(p) for p in a]
         oa.zero_grad(); ob.zero_grad()
@@ -697,6 +702,104 @@ def test_fused_dense_kernels_match_library_path(hip, monkeypatch):
     for name in ga:
         scale = max(1e-6, float(gb[name].abs().max()))
         assert float((ga[name] - gb[name]).abs().max()) <= 2e-4 * scale + 1e-7, name
+
+
+@pytest.mark.parametrize("m", [1, 37, 600, 4099, 12800, 16384])
+def test_dense_tail_split_kernels_match_whole_slab_kernels_and_float64(hip, monkeypatch, m):
+    """lstep_tail_fwd / _bwd pick the one-slab-per-workgroup kernels (a layer's output tiles dealt out to the four waves, layers handed on
+    through LDS) for up to 800 slabs and the slab-chain kernels beyond; LSTEP_TAIL_NO_SPLIT=1 forces the latter.  Both against a float64
+    evaluation of the same layer chain (models/LSTEP.py:161-170,219,240-247,264) and its autograd gradients."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    gen = torch.Generator(device=DEV).manual_seed(m)
+    rnd = lambda *sh, s=1.0: s * torch.randn(*sh, device=DEV, generator=gen)  # noqa: E731
+    xe, xp, xn, own, go = rnd(m, 272), rnd(m, 272), rnd(m, 176), rnd(m, 176, s=0.1), rnd(m, 176)
+    w1, b1, wn1, bn1, wq, bq, wall, ball = [rnd(*sh, s=0.06) for sh in ((272, 272), (272,), (176, 272), (176,), (176, 352), (176,), (176, 624), (176,))]
+    d = lambda t, grad=False: t.detach().double().requires_grad_(grad)  # noqa: E731
+    xe_, xp_, own_ = d(xe), d(xp), d(own)
+    h1 = torch.relu(xe_ @ d(w1).t() + d(b1))
+    p1 = torch.relu(xp_ @ d(wn1).t() + d(bn1))
+    q = own_ + torch.tanh(torch.cat([own_, p1], 1) @ d(wq).t() + d(bq))
+    o = torch.cat([d(xn), h1, q], 1) @ d(wall).t() + d(ball)
+    ref = dict(h1=h1.detach(), p1=p1.detach(), q=q.detach(), out=o.detach())
+
+    def ref_backward(mask_h1, mask_p1):
+        """float64 gradients with the relu masks the kernel itself saw: among millions of pre-activations a few lie within rounding of
+        zero, where float32 and float64 disagree about the sign and whole gradient rows legitimately differ"""
+        dq = d(go) @ d(wall)[:, 448:]
+        th = (q - own_).detach()
+        dz_ = dq * (1.0 - th * th)
+        dp1_ = (dz_ @ d(wq)[:, 176:]) * mask_p1
+        dh1_ = (d(go) @ d(wall)[:, 176:448]) * mask_h1
+        return dict(dz=dz_, down=dq + dz_ @ d(wq)[:, :176], dp1=dp1_, dxp=dp1_ @ d(wn1), dh1=dh1_, dxe=dh1_ @ d(w1))
+
+    got = {}
+    for split in (True, False):
+        monkeypatch.setenv("LSTEP_TAIL_NO_SPLIT", "0" if split else "1")
+        c1 = torch.zeros(m, 624, device=DEV); c2 = torch.zeros(m, 352, device=DEV)
+        c1[:, :176] = xn; c2[:, :176] = own
+        out = torch.empty(m, 176, device=DEV)
+        nat.check(lib.lstep_tail_fwd(nat.ptr(xe), 272, nat.ptr(xp), 272, nat.ptr(c1), nat.ptr(c2), nat.ptr(out), nat.ptr(w1), nat.ptr(b1),
+                                     nat.ptr(wn1), nat.ptr(bn1), nat.ptr(wq), nat.ptr(bq), nat.ptr(wall), nat.ptr(ball), m, nat.current_stream()))
+        dxe, dxp, dh1 = (torch.empty(m, 272, device=DEV) for _ in range(3))
+        down, dp1, dz = (torch.empty(m, 176, device=DEV) for _ in range(3))
+        w1t, wn1t, wqt, wallt = (w.t().contiguous() for w in (w1, wn1, wq, wall))
+        nat.check(lib.lstep_tail_bwd(nat.ptr(go), nat.ptr(c1), nat.ptr(c2), nat.ptr(w1t), nat.ptr(wn1t), nat.ptr(wqt), nat.ptr(wallt), nat.ptr(dxe),
+                                     nat.ptr(dxp), nat.ptr(down), 176, nat.ptr(dh1), nat.ptr(dp1), nat.ptr(dz), m, nat.current_stream()))
+        torch.cuda.synchronize()
+        got[split] = dict(h1=c1[:, 176:448], p1=c2[:, 176:], q=c1[:, 448:], out=out, dxe=dxe, dxp=dxp, down=down, dh1=dh1, dp1=dp1, dz=dz)
+        full = dict(ref, **ref_backward((got[split]["h1"] > 0).double(), (got[split]["p1"] > 0).double()))
+        for name, r in full.items():
+            err = float((got[split][name].double() - r).abs().max())
+            assert err <= 2e-5 * max(1.0, float(r.abs().max())), (split, name, err)
+    same_masks = bool(((got[True]["h1"] > 0) == (got[False]["h1"] > 0)).all() and ((got[True]["p1"] > 0) == (got[False]["p1"] > 0)).all())
+    for name in got[True]:      # the two kernel families add the same products in a different order
+        if not same_masks and name in ("dxe", "dxp", "dh1", "dp1"):
+            continue
+        a, b = got[True][name], got[False][name]
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), name
+
+
+@pytest.mark.parametrize("n", [1, 200, 601, 8192])
+def test_link_predictor_split_kernels_match_whole_slab_kernels_and_float64(hip, monkeypatch, n):
+    """lstep_head_fwd / _bwd: the one-slab-per-workgroup kernels (up to 512 slabs of 16 edges) and the one-slab-per-wave kernels
+    (LSTEP_HEAD_NO_SPLIT=1) against float64 (models/modules.py:42-68 on the pairs of train_LSTEP_link_prediction.py:254-255)."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    rnd = lambda *sh, s=1.0: s * torch.randn(*sh, device=DEV, generator=gen)  # noqa: E731
+    emb = torch.zeros(3 * n, 176, device=DEV); emb[:, :172] = rnd(3 * n, 172)
+    w = torch.zeros(176, 352, device=DEV); w[:172, :172] = rnd(172, 172, s=0.08); w[:172, 176:348] = rnd(172, 172, s=0.08)
+    b1 = torch.zeros(176, device=DEV); b1[:172] = rnd(172, s=0.1)
+    w2 = torch.zeros(176, device=DEV); w2[:172] = rnd(172, s=0.1)
+    b2 = rnd(1)
+    dl = rnd(2 * n)
+    d = lambda t: t.double()  # noqa: E731
+    pair = lambda a, b: torch.cat([d(emb[a:a + n]), d(emb[b:b + n])], 1)  # noqa: E731
+    hid = torch.relu(torch.cat([pair(0, n), pair(0, 2 * n)], 0) @ d(w).t() + d(b1))      # [2 n, 176]
+    ref_logits = hid @ d(w2) + d(b2)
+    got = {}
+    for split in (True, False):
+        monkeypatch.setenv("LSTEP_HEAD_NO_SPLIT", "0" if split else "1")
+        h = torch.empty(2 * n, 176, device=DEV); logits = torch.empty(2 * n, device=DEV)
+        nat.check(lib.lstep_head_fwd(nat.ptr(emb), n, 0, n, 0, 2 * n, nat.ptr(w), nat.ptr(b1), nat.ptr(w2), nat.ptr(b2), nat.ptr(h), nat.ptr(logits),
+                                     nat.current_stream()))
+        wt = w.t().contiguous()
+        d_emb = torch.empty(3 * n, 176, device=DEV); d_h = torch.empty(2 * n, 176, device=DEV); d_hsum = torch.empty(n, 176, device=DEV)
+        part = torch.empty((n + 15) // 16, 176, device=DEV)
+        nat.check(lib.lstep_head_bwd(nat.ptr(dl), nat.ptr(h), n, nat.ptr(wt), nat.ptr(w2), nat.ptr(d_emb), nat.ptr(d_h), nat.ptr(d_hsum), nat.ptr(part),
+                                     nat.current_stream()))
+        torch.cuda.synchronize()
+        got[split] = dict(h=h, logits=logits, d_emb=d_emb, d_h=d_h, d_hsum=d_hsum, col=part.sum(0))
+        mask = (h > 0).double()                          # the relu mask the kernel saw (see the dense-tail test)
+        r_dh = d(dl)[:, None] * d(w2)[None, :] * mask
+        r_pair = r_dh @ d(w)                              # [2 n, 352]
+        r_emb = torch.cat([r_pair[:n, :176] + r_pair[n:, :176], r_pair[:n, 176:], r_pair[n:, 176:]], 0)
+        r_col = (d(dl)[:, None] * hid).sum(0)
+        r_col[172] = d(dl).sum()
+        for name, r in dict(h=hid, logits=ref_logits, d_h=r_dh, d_hsum=r_dh[:n] + r_dh[n:], d_emb=r_emb, col=r_col).items():
+            err = float((got[split][name].double() - r).abs().max())
+            assert err <= 2e-5 * max(1.0, float(r.abs().max())), (split, name, err)
 
 
 @pytest.mark.parametrize("T,t_len,batch_idx", [(100, 100, 1000), (100, 37, 37), (6, 3, 3), (8, 8, 5)])
