@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 27
+#define LSTEP_ABI_VERSION 28
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -344,13 +344,23 @@ int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int6
                       const lstep_ring_ref_t* ring, void* stream);
 /* num_live (optional, device): only the first min(*num_live, n) rows are updated; n is then the capacity the launch covers. */
 
+/* U2 with the first layer pre-multiplied into the messages.  pe_mlp_1 (models/LSTEP.py:327) is linear in the message sum and every
+ * message's PE row is one of the U batch-node rows (:319-322), so W1 [sum pe ; sum time] = sum (W1[:, :pe_dim] pe) + W1[:, pe_dim:] sum time:
+ * the caller forms y[u] = W1[:, :pe_dim] pe[batch node u] once ([U, 176], columns >= 172 zero), runs lstep_segment_rows_sum over y (entry rows
+ * = positions in the batch-node list: lstep_update_entries_p2_dev with bn == NULL) and passes agg [>= n, ld_agg >= 176 + time_dim] =
+ * [sum y (176) | sum time features (time_dim)] with w1b [176, 112] = W1[:, pe_dim:] zero-padded.  36 % fewer multiply-adds per touched
+ * row than lstep_update_rows; the sums are re-associated (differences at the 1e-7 level). */
+int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1b, const float* b1, const float* w2,
+                          const float* b2, float* table, float* mirror, int32_t pe_dim, int32_t time_dim, const int32_t* num_live,
+                          const lstep_ring_ref_t* ring, void* stream);
+
 /* Device-resident counts for the engine's update_pe (no host synchronisation anywhere in models/LSTEP.py:268-340):
  *   lstep_widen_ids             out[i] = i < *count ? ids32[i] : 0 -- lstep_group_by_key's distinct keys as an int64 id list of fixed
  *                               capacity whose dead tail is the padding node 0 (no history, no neighbours).
  *   lstep_update_entries_p2_dev lstep_update_entries_p2 with n_real / nseg read from lstep_group_by_key's device summary and the
  *                               row-0 decision (models/LSTEP.py:324: 0 is among the unique neighbour ids iff a slot of a live row is
  *                               padding) taken on the device: segment 0 is always reserved for row 0, touched = [0, uniq..., 0 ...],
- *                               counts_out = {nseg, row-0 flag}. */
+ *                               counts_out = {nseg, row-0 flag}.  bn == NULL: ent_row = the row's position in the id list. */
 int lstep_widen_ids(const int32_t* ids32, int64_t capacity, const int32_t* count, int64_t* out, void* stream);
 int lstep_update_entries_p2_dev(const int32_t* order, const int32_t* seg, const int32_t* summary, const int32_t* live_rows, int64_t capacity,
                                 int64_t touched_capacity, const int64_t* bn, const float* nt, const float* now32, int32_t num_neighbors,
@@ -366,7 +376,7 @@ int lstep_scatter_add_rows(float* out, int32_t width, int32_t ld_out, const int3
 /* U2, row 0 -- what the PADDED slots of update_pe's sampled neighbourhoods scatter into row 0 (models/LSTEP.py:317-322):
  *   sum_r (number of zero entries of nbr[r, :]) * table[ids[r], :width]
  * as per-block partial sums partial [lstep_padding_rows_sum_blocks(n), width] (the caller adds them: fixed order, no atomics).
- * nbr int64 [n, num_neighbors] (lstep_sample_recent's output), ids int64 [n] the source rows. */
+ * nbr int64 [n, num_neighbors] (lstep_sample_recent's output), ids int64 [n] the source rows (NULL: row r of the table itself). */
 int64_t lstep_padding_rows_sum_blocks(int64_t n);
 int lstep_padding_rows_sum(const int64_t* nbr, int32_t num_neighbors, const int64_t* ids, int64_t n, const float* table, int32_t width,
                            int32_t ld_table, float* partial, void* stream);

@@ -63,6 +63,45 @@ __device__ __forceinline__ void mma_wx(f32x4 (*acc)[S], const float* wl, int ldw
     }
 }
 
+// mma_wx for an operand X whose rows hold only `kvalid` (a multiple of 4) meaningful columns from xl on: the lanes of the last chunk that
+// would read past them contribute zeros instead (the matching weight columns are zero padding; what lies behind X's columns may be anything,
+// NaN included).  g = lane >> 4.
+template <int T, int S>
+__device__ __forceinline__ void mma_wx_masked(f32x4 (*acc)[S], const float* wl, int ldw, int chunks, const float* const (&xl)[S], int kvalid, int g) {
+    auto load = [&](Chunk<T, S>& o, int c) {
+        const bool ok = 16 * c + 4 * g + 4 <= kvalid;
+#pragma unroll
+        for (int s = 0; s < S; ++s) o.b[s] = ok ? ldv4(xl[s] + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < T; ++t) o.a[t] = ldv4(wl + (size_t)16 * t * ldw + 16 * c);
+    };
+    auto run = [&](const Chunk<T, S>& o) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[t][s] = mfma4(o.a[t][v], o.b[s][v], acc[t][s]);
+            }
+        }
+    };
+    Chunk<T, S> c0, c1;
+    load(c0, 0);
+    for (int c = 0; c < chunks; c += 2) {
+        const bool two = c + 1 < chunks;
+        if (two) load(c1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        run(c0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) {
+            if (c + 2 < chunks) load(c0, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            run(c1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // acc[t][s] += sum over the TK register tiles r[tk][s] (16 features each) of W[16 t + i][16 tk + k] * r
 template <int T, int S, int TK>
 __device__ __forceinline__ void mma_wr(f32x4 (*acc)[S], const float* wl, int ldw, const f32x4 (*r)[S]) {

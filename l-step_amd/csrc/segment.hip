@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void padding_rows_sum_kernel(const int64_t*
         }
         if (zeros == 0) continue;   // wave-uniform
         if (wa) {
-            const float4 v = ld4(table + ids[r] * (int64_t)ld + lane * 4);
+            const float4 v = ld4(table + (ids ? ids[r] : r) * (int64_t)ld + lane * 4);
             const float w = (float)zeros;
             acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
         }
@@ -274,7 +274,7 @@ extern "C" int lstep_padding_rows_sum(const int64_t* nbr, int32_t num_neighbors,
     if (n < 0 || num_neighbors <= 0 || width <= 0 || (width & 3) || width > 4 * kMaxRowVec || ld_table < width || (ld_table & 3))
         return set_error(LSTEP_EINVAL, "lstep_padding_rows_sum: bad sizes");
     if (n == 0) return LSTEP_OK;
-    if (!nbr || !ids || !table || !partial) return set_error(LSTEP_EINVAL, "lstep_padding_rows_sum: NULL pointer");
+    if (!nbr || !table || !partial) return set_error(LSTEP_EINVAL, "lstep_padding_rows_sum: NULL pointer");
     hipLaunchKernelGGL(padding_rows_sum_kernel, dim3((unsigned)lstep_padding_rows_sum_blocks(n)), dim3(kBlock), 0, (hipStream_t)stream, nbr,
                        (int)num_neighbors, ids, n, table, (int)width, (int)ld_table, partial);
     return check_launch("padding_rows_sum_kernel");

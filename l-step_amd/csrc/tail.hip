@@ -588,9 +588,16 @@ struct UpdateParams {
     int64_t ring_stride;
     int64_t n;
     int32_t ld_agg, pe_dim;
+    int32_t time_dim;      // kPre kernels: meaningful columns of the time part
 };
 
-template <int S>
+constexpr int kTd = 112, kTt = kTd / 16;     // padded time width of the pre-multiplied form
+
+// kPre: the first layer arrives half done.  pe_mlp_1 is linear in the message sum, W1 [sum pe rows ; sum time features] = sum (W1a pe row) +
+// W1b sum time features, and every message's pe row is one of the U batch-node rows: the caller multiplies those U rows by W1a once
+// (a [U, 172] x [172, 172] product instead of 172 x 172 multiply-adds for each of the ~9 U touched rows), the segment sums run over the
+// products, and agg = [sum W1a pe (176) | sum time features (time_dim)].  Here: h = relu(agg[:176] + W1b agg[176:] + b1), w1 = W1b [176, 112].
+template <int S, bool kPre = false>
 __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) {
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
@@ -627,7 +634,19 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
             z[t][s] = b2v;
         }
     }
-    mma_wx<kTp, S>(h, wlane(p.w1, kCe), kCe, kTe, agg_l);
+    if constexpr (kPre) {
+#pragma unroll
+        for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) h[t][s] += ldv4(agg_l[s] + 16 * t);      // accumulator layout = row-major float4 at feature 16 t + 4 g
+        }
+        const float* tf_l[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) tf_l[s] = agg_l[s] + kPp;
+        mma_wx_masked<kTp, S>(h, wlane(p.w1, kTd), kTd, kTt, tf_l, p.time_dim, g);
+    } else {
+        mma_wx<kTp, S>(h, wlane(p.w1, kCe), kCe, kTe, agg_l);
+    }
 #pragma unroll
     for (int t = 0; t < kTp; ++t) {
 #pragma unroll
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
         }
     }
     mma_wr<kTp, S, kTp>(z, wlane(p.w2, kPp), kPp, h);
-    if (p.ws != nullptr) {
+    if (!kPre && p.ws != nullptr) {
         // own rows straight from the table: pe_dim = 172 columns, so the last lane group of the last chunk would read past the
         // row.  Those lanes re-read the row start instead: the padded weight columns they meet are zero.
         const int last = (p.pe_dim + 15) / 16 - 1;
@@ -754,7 +773,7 @@ extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t
     if (ring && (!ring->start || ring->slots <= 0 || ring->add < 0 || (ring->slot_stride & 3)))
         return set_error(LSTEP_EINVAL, "lstep_update_rows: bad ring reference");
     UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, mirror, num_live, ring ? ring->start : nullptr, ring ? ring->add : 0,
-                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim};
+                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, 0};
     const int S = tail_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
@@ -763,4 +782,28 @@ extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t
     else if (S == 2) hipLaunchKernelGGL(update_rows_kernel<2>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(update_rows_kernel<3>, grid, block, 0, s, p);
     return check_launch("lstep_update_rows");
+}
+
+// update_pe phase 2 with the first layer pre-multiplied into the messages (see update_rows_kernel<S, true>): agg [>= n, ld_agg] =
+// [sum of W1a pe rows (176 columns, 172 used) | sum of time features (time_dim)], w1b [176, 112] = pe_mlp_1.weight[:, pe_dim:] zero-padded.
+extern "C" int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1b, const float* b1,
+                                     const float* w2, const float* b2, float* table, float* mirror, int32_t pe_dim, int32_t time_dim,
+                                     const int32_t* num_live, const lstep_ring_ref_t* ring, void* stream) {
+    if (n < 0 || ld_agg < kPp + time_dim || (ld_agg & 3) || pe_dim <= 0 || pe_dim > kPp || (pe_dim & 3) || time_dim <= 0 || time_dim > kTd || (time_dim & 3))
+        return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: bad sizes");
+    if (n == 0) return LSTEP_OK;
+    if (!agg || !ids || !w1b || !b1 || !w2 || !b2 || !table) return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: NULL pointer");
+    if (((uintptr_t)mirror) & 15) return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: misaligned mirror table");
+    if (ring && (!ring->start || ring->slots <= 0 || ring->add < 0 || (ring->slot_stride & 3)))
+        return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: bad ring reference");
+    UpdateParams p{agg, ids, w1b, b1, w2, b2, nullptr, nullptr, table, mirror, num_live, ring ? ring->start : nullptr, ring ? ring->add : 0,
+                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, time_dim};
+    const int S = tail_slabs_per_wave(n);
+    const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
+    const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (S == 1) hipLaunchKernelGGL((update_rows_kernel<1, true>), grid, block, 0, s, p);
+    else if (S == 2) hipLaunchKernelGGL((update_rows_kernel<2, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((update_rows_kernel<3, true>), grid, block, 0, s, p);
+    return check_launch("lstep_update_rows_pre");
 }

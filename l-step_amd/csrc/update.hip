@@ -68,7 +68,7 @@ __global__ void update_entries_p2_dev_kernel(const int32_t* __restrict__ order, 
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         if (e < n_real) {
             const int64_t o = order[e];
-            ent_row[e] = (int32_t)bn[o / k];
+            ent_row[e] = bn ? (int32_t)bn[o / k] : (int32_t)(o / k);   // (no id list: the row's position in it, for a table laid out in list order)
             ent_dt[e] = now - nt[o];
             ent_seg[e] = seg[e] + 1;
         }
@@ -123,7 +123,7 @@ extern "C" int lstep_update_entries_p2_dev(const int32_t* order, const int32_t* 
                                            int32_t num_neighbors, const int32_t* uniq, int32_t* ent_row, float* ent_dt, int32_t* ent_seg,
                                            int64_t* touched, int32_t* counts_out, void* stream) {
     if (capacity <= 0 || touched_capacity <= 0 || num_neighbors <= 0) return set_error(LSTEP_EINVAL, "lstep_update_entries_p2_dev: bad sizes");
-    if (!order || !seg || !summary || !live_rows || !bn || !nt || !now32 || !uniq || !ent_row || !ent_dt || !ent_seg || !touched || !counts_out)
+    if (!order || !seg || !summary || !live_rows || !nt || !now32 || !uniq || !ent_row || !ent_dt || !ent_seg || !touched || !counts_out)
         return set_error(LSTEP_EINVAL, "lstep_update_entries_p2_dev: NULL pointer");
     const int64_t total = capacity > touched_capacity ? capacity : touched_capacity;
     hipLaunchKernelGGL(update_entries_p2_dev_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, order, seg, summary, live_rows,

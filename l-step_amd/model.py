@@ -1363,6 +1363,21 @@ class LSTEP(nn.Module):
         return self._padded_cached("update_mlp", (m1.weight, m1.bias, m2.weight, m2.bias), lambda: (
             _pad2(m1.weight.detach(), Pp, Cp).t(), _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).t(), _pad1(m2.bias.detach(), Pp)))
 
+    def _update_weights_pre(self):
+        """Operands of ``lstep_update_rows_pre``: pe_mlp_1.weight split into its PE half (transposed, [172, 176]: the right factor of the
+        batch-node product) and its time half ([176, 112] zero-padded), the biases and pe_mlp_2.weight [176, 176]."""
+        P, D, Pp = self.pe_dim, self.time_dim, self.ld_self
+        m1, m2 = self.pe_mlp_1, self.pe_mlp_2
+
+        def build():
+            w = m1.weight.detach()
+            w1a_t = torch.zeros((P, Pp), dtype=torch.float32, device=w.device)
+            w1a_t[:, :w.shape[0]] = w[:, :P].t()
+            w1b = torch.zeros((Pp, 112), dtype=torch.float32, device=w.device)
+            w1b[:w.shape[0], :D] = w[:, P:P + D]
+            return (w1a_t, w1b, _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).contiguous(), _pad1(m2.bias.detach(), Pp))
+        return self._padded_cached("update_mlp_pre", (m1.weight, m1.bias, m2.weight, m2.bias), build)
+
     def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None, live: torch.Tensor = None, ring=None):
         """``lstep_update_rows``: pe[ids] += tanh(pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(pe[ids])]) in place, one launch."""
         lib = nat.load_library()
@@ -1612,10 +1627,37 @@ class LSTEP(nn.Module):
         ent_seg = torch.empty(n, dtype=torch.int32, device=dev)
         touched = torch.empty(tcap, dtype=torch.int64, device=dev)
         counts = torch.empty(2, dtype=torch.int32, device=dev)    # {touched rows besides row 0, does row 0 take part}
+        # pre-multiplied form (lstep_update_rows_pre): the messages' PE rows are the batch nodes' rows, so pe_mlp_1's PE half is applied to
+        # those cap rows once and the segment sums run over the products
+        premul = (os.environ.get("LSTEP_UPDATE_NO_PREMUL") != "1" and self.ld_pe == P + self.time_dim and self.ld_self == 176
+                  and self.time_dim <= 112 and self.time_dim % 4 == 0)
         with torch.cuda.device(dev):
-            nat.check(lib.lstep_update_entries_p2_dev(nat.ptr(order), nat.ptr(seg), nat.ptr(summary), nat.ptr(n_live), n, tcap, nat.ptr(bn),
-                                                      nat.ptr(nt), nat.ptr(now32), K, nat.ptr(uniq), nat.ptr(ent_row), nat.ptr(ent_dt),
-                                                      nat.ptr(ent_seg), nat.ptr(touched), nat.ptr(counts), nat.current_stream()))
+            nat.check(lib.lstep_update_entries_p2_dev(nat.ptr(order), nat.ptr(seg), nat.ptr(summary), nat.ptr(n_live), n, tcap,
+                                                      None if premul else nat.ptr(bn), nat.ptr(nt), nat.ptr(now32), K, nat.ptr(uniq),
+                                                      nat.ptr(ent_row), nat.ptr(ent_dt), nat.ptr(ent_seg), nat.ptr(touched), nat.ptr(counts),
+                                                      nat.current_stream()))
+        if premul:
+            D, Pp = self.time_dim, self.ld_self
+            w1a_t, w1b, b1, w2, b2 = self._update_weights_pre()
+            y = torch.mm(pe.index_select(0, bn), w1a_t)                       # [cap, 176]; dead rows are node 0: pe[0] = 0 -> 0
+            agg2 = torch.empty((tcap, Pp + D), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_segment_rows_sum(nat.ptr(y), Pp, Pp, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
+                                                     nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), n, nat.ptr(agg2), Pp + D, 2,
+                                                     nat.ptr(summary[1:2]), nat.current_stream()))
+            agg2[0].zero_()
+            part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), Pp), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, None, cap, nat.ptr(y), Pp, Pp, nat.ptr(part), nat.current_stream()))
+            agg2[0, :Pp] = part.sum(dim=0)
+            for ids_, agg_, live_ in ((touched[1:], agg2[1:], counts[0:1]), (touched[:1], agg2[:1], counts[1:2])):
+                with torch.cuda.device(dev):
+                    nat.check(lib.lstep_update_rows_pre(nat.ptr(agg_), int(agg_.stride(0)), nat.ptr(ids_), ids_.numel(), nat.ptr(w1b), nat.ptr(b1),
+                                                        nat.ptr(w2), nat.ptr(b2), nat.ptr(pe), nat.ptr(mirror), P, D, nat.ptr(live_), mirror_ring,
+                                                        nat.current_stream()))
+            if changed is not None:
+                changed(touched, mirror is not None)
+            return pe
         agg2 = self._segment_sum(pe, tcap, ent_seg, ent_row, ent_dt, exact=True, live=summary[1:2])
         # row 0 collects cat[pe[source], 0] from every padded slot: segment 0 has no entries of its own, its aggregate is the sum over
         # the rows of (their number of padded slots) * pe[source row]
