@@ -336,14 +336,31 @@ class DistributedLstep:
             self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)       # every replica applies the same update
         return now32, fused
 
+    def _phase2_replicated(self) -> bool:
+        """How the replicas of the PE table receive phase 2's rows.  ``allgather``: every rank computes the rows it
+        owns and all-gathers them -- U2 x 704 B per step, 72-91 % of the table at the BASELINE shapes: 2.1-3.3 ms of link time.
+        ``replicate``: every rank runs phase 2 for ALL touched rows itself (same inputs on every rank: the batch-node rows were all-gathered
+        by phase 1, the CSR is replicated) and nothing travels; the work grows with the global batch (0.9 / 1.1 / 3.4 ms of update_rows at
+        W = 2 / 4 / 8 on c4 / c4 / c5).  ``auto`` (default) replicates up to W = 4, where it is the cheaper of the two.
+        Replicas stay bit-identical under ``replicate`` as long as no touched row collects more than 128 messages (a segment cut into
+        two 64-entry chunks is a two-operand sum, which commutes; three or more partial sums are added with float atomics in arrival
+        order, 1 ulp apart at most); the history shard always stores the owner's value."""
+        policy = os.environ.get("LSTEP_PHASE2", "auto")
+        if policy not in ("auto", "replicate", "allgather"):
+            raise ValueError("LSTEP_PHASE2 must be auto, replicate or allgather")
+        return self.W > 1 and (policy == "replicate" or (policy == "auto" and self.W <= 4))
+
     def _update_phase2(self, bn, ts, state):
         """update_pe phase 2 up to the all-gather of its rows, which is left in flight."""
         now32, fused = state
         shard = (self.W, self.rank)
         ring = self._ring
         if fused:
-            ids = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard, fused=True)
-            ring.mark(ids, self.W, self.rank)
+            replicate = self._phase2_replicated()
+            ids = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=None if replicate else shard, fused=True)
+            ring.mark(ids, self.W, self.rank)          # (marks the rows of ``ids`` this rank owns)
+            if replicate:
+                return ("rows", None)
             return ("rows", PendingGather(self._rows_with_ids(ids), self.group) if not _skip_single(self.W) else None)
         ids, z = self.bb.update_pe_phase2(self.table, bn, ts, now32, self.K, shard=shard)
         ring.mark(ids, self.W, self.rank)

@@ -146,9 +146,15 @@ def _gpu_worker(rank, world, port, q, backend="gloo"):
 
 
 @pytest.mark.gpu
-def test_distributed_engine_reproduces_golden_trace_2_ranks_one_gpu():
+@pytest.mark.parametrize("world,phase2", [(2, "allgather"), (2, "replicate"), (4, "auto")])
+def test_distributed_engine_reproduces_golden_trace_ranks_on_one_gpu(monkeypatch, world, phase2):
+    """W ranks share the one GPU of the test box (gloo staging the device tensors through the host) and must reproduce the REFERENCE's
+    golden training + evaluation trace: owner-sharded history ring and FFT filter, batch slices through the gather stage, both ways of
+    handing phase 2's rows to the replicas (LSTEP_PHASE2), two ranks and four (17 / 16 / 16 / 16 owned
+    rows, 4 edges of the batch per rank)."""
     assert torch.cuda.is_available()
-    _run(_gpu_worker, 2)
+    monkeypatch.setenv("LSTEP_PHASE2", phase2)      # (inherited by the spawned ranks)
+    _run(_gpu_worker, world)
 
 
 @pytest.mark.gpu
