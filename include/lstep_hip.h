@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 28
+#define LSTEP_ABI_VERSION 29
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -341,8 +341,10 @@ int lstep_head_bwd(const float* d_logits, const float* h, int64_t n, const float
  * -- the batch's history slot, so that appending the snapshot (train_link_prediction.py:301) costs no separate copy. */
 int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
                       const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim, const int32_t* num_live,
-                      const lstep_ring_ref_t* ring, void* stream);
-/* num_live (optional, device): only the first min(*num_live, n) rows are updated; n is then the capacity the launch covers. */
+                      const lstep_ring_ref_t* ring, int32_t mirror_world, int32_t mirror_rank, void* stream);
+/* num_live (optional, device): only the first min(*num_live, n) rows are updated; n is then the capacity the launch covers.
+ * mirror_world > 1: the mirror is a slot of an OWNER-SHARDED history ring (one process per GPU, node id owned by rank id % world): the new
+ * row of node id is mirrored to row id / world, and only if id % world == mirror_rank.  (1, 0): the mirror has the table's shape. */
 
 /* U2 with the first layer pre-multiplied into the messages.  pe_mlp_1 (models/LSTEP.py:327) is linear in the message sum and every
  * message's PE row is one of the U batch-node rows (:319-322), so W1 [sum pe ; sum time] = sum (W1[:, :pe_dim] pe) + W1[:, pe_dim:] sum time:
@@ -352,7 +354,7 @@ int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int6
  * row than lstep_update_rows; the sums are re-associated (differences at the 1e-7 level). */
 int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1b, const float* b1, const float* w2,
                           const float* b2, float* table, float* mirror, int32_t pe_dim, int32_t time_dim, const int32_t* num_live,
-                          const lstep_ring_ref_t* ring, void* stream);
+                          const lstep_ring_ref_t* ring, int32_t mirror_world, int32_t mirror_rank, void* stream);
 
 /* Device-resident counts for the engine's update_pe (no host synchronisation anywhere in models/LSTEP.py:268-340):
  *   lstep_widen_ids             out[i] = i < *count ? ids32[i] : 0 -- lstep_group_by_key's distinct keys as an int64 id list of fixed

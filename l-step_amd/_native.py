@@ -19,7 +19,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 28
+ABI_VERSION = 29
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -115,8 +115,8 @@ SIGNATURES = {
     "lstep_update_entries_p1": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P]),
     "lstep_update_keys_p2": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "lstep_update_entries_p2": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _I64, _P, _P, _P, _P, _P]),
-    "lstep_update_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, C.POINTER(RingRef), _P]),
-    "lstep_update_rows_pre": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, C.POINTER(RingRef), _P]),
+    "lstep_update_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, C.POINTER(RingRef), _I32, _I32, _P]),
+    "lstep_update_rows_pre": (C.c_int, [_P, _I32, _P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, C.POINTER(RingRef), _I32, _I32, _P]),
     "lstep_widen_ids": (C.c_int, [_P, _I64, _P, _P, _P]),
     "lstep_update_entries_p2_dev": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_fwd": (C.c_int, [_P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),

@@ -589,6 +589,7 @@ struct UpdateParams {
     int64_t n;
     int32_t ld_agg, pe_dim;
     int32_t time_dim;      // kPre kernels: meaningful columns of the time part
+    int32_t mirror_world, mirror_rank;   // world > 1: `mirror` is an owner-sharded slot -- row id goes to row id / world, only if id % world == rank
 };
 
 constexpr int kTd = 112, kTt = kTd / 16;     // padded time width of the pre-multiplied form
@@ -622,6 +623,20 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
         own_l[s] = own_row[s] + 4 * g;
     }
     auto wlane = [&](const float* w, int ldw) { return w + i * ldw + 4 * g; };
+    float* mir_row[S];     // where this row goes in the mirror (NULL: nowhere)
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        mir_row[s] = nullptr;
+        if (p.mirror) {
+            const int64_t off = own_row[s] - p.table;
+            if (p.mirror_world > 1) {
+                const int64_t id = off / p.pe_dim;
+                if (id % p.mirror_world == p.mirror_rank) mir_row[s] = p.mirror + (id / p.mirror_world) * p.pe_dim;
+            } else {
+                mir_row[s] = p.mirror + off;
+            }
+        }
+    }
     f32x4 h[kTp][S], z[kTp][S];
 #pragma unroll
     for (int t = 0; t < kTp; ++t) {
@@ -688,7 +703,7 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
 #pragma unroll
                     for (int v = 0; v < 4; ++v) old[v] += tanhf(z[t][s][v]);
                     *reinterpret_cast<f32x4*>(own_row[s] + f) = old;
-                    if (p.mirror) *reinterpret_cast<f32x4*>(p.mirror + (own_row[s] - p.table) + f) = old;
+                    if (mir_row[s]) *reinterpret_cast<f32x4*>(mir_row[s] + f) = old;
                 }
             }
         }
@@ -765,7 +780,8 @@ extern "C" int lstep_tail_bwd(const float* grad_out, const float* cat1, const fl
 
 extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1, const float* b1, const float* w2,
                                  const float* b2, const float* ws, const float* bs, float* table, float* mirror, int32_t pe_dim,
-                                 const int32_t* num_live, const lstep_ring_ref_t* ring, void* stream) {
+                                 const int32_t* num_live, const lstep_ring_ref_t* ring, int32_t mirror_world, int32_t mirror_rank, void* stream) {
+    if (mirror_world < 1 || mirror_rank < 0 || mirror_rank >= mirror_world) return set_error(LSTEP_EINVAL, "lstep_update_rows: bad mirror shard");
     if (n < 0 || ld_agg < kCe || (ld_agg & 3) || pe_dim <= 0 || pe_dim > kPp || (pe_dim & 3)) return set_error(LSTEP_EINVAL, "lstep_update_rows: bad sizes");
     if (n == 0) return LSTEP_OK;
     if (!agg || !ids || !w1 || !b1 || !w2 || !b2 || !table || (ws && !bs)) return set_error(LSTEP_EINVAL, "lstep_update_rows: NULL pointer");
@@ -773,7 +789,7 @@ extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t
     if (ring && (!ring->start || ring->slots <= 0 || ring->add < 0 || (ring->slot_stride & 3)))
         return set_error(LSTEP_EINVAL, "lstep_update_rows: bad ring reference");
     UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, mirror, num_live, ring ? ring->start : nullptr, ring ? ring->add : 0,
-                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, 0};
+                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, 0, mirror_world, mirror_rank};
     const int S = tail_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
@@ -788,7 +804,9 @@ extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t
 // [sum of W1a pe rows (176 columns, 172 used) | sum of time features (time_dim)], w1b [176, 112] = pe_mlp_1.weight[:, pe_dim:] zero-padded.
 extern "C" int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int64_t* ids, int64_t n, const float* w1b, const float* b1,
                                      const float* w2, const float* b2, float* table, float* mirror, int32_t pe_dim, int32_t time_dim,
-                                     const int32_t* num_live, const lstep_ring_ref_t* ring, void* stream) {
+                                     const int32_t* num_live, const lstep_ring_ref_t* ring, int32_t mirror_world, int32_t mirror_rank,
+                                     void* stream) {
+    if (mirror_world < 1 || mirror_rank < 0 || mirror_rank >= mirror_world) return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: bad mirror shard");
     if (n < 0 || ld_agg < kPp + time_dim || (ld_agg & 3) || pe_dim <= 0 || pe_dim > kPp || (pe_dim & 3) || time_dim <= 0 || time_dim > kTd || (time_dim & 3))
         return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: bad sizes");
     if (n == 0) return LSTEP_OK;
@@ -797,7 +815,7 @@ extern "C" int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int
     if (ring && (!ring->start || ring->slots <= 0 || ring->add < 0 || (ring->slot_stride & 3)))
         return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: bad ring reference");
     UpdateParams p{agg, ids, w1b, b1, w2, b2, nullptr, nullptr, table, mirror, num_live, ring ? ring->start : nullptr, ring ? ring->add : 0,
-                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, time_dim};
+                   ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, time_dim, mirror_world, mirror_rank};
     const int S = tail_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);

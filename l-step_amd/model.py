@@ -1378,7 +1378,7 @@ class LSTEP(nn.Module):
             return (w1a_t, w1b, _pad1(m1.bias.detach(), Pp), _pad2(m2.weight.detach(), Pp, Pp).contiguous(), _pad1(m2.bias.detach(), Pp))
         return self._padded_cached("update_mlp_pre", (m1.weight, m1.bias, m2.weight, m2.bias), build)
 
-    def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None, live: torch.Tensor = None, ring=None):
+    def _update_rows(self, pe, ids, agg, with_self: bool, mirror=None, live: torch.Tensor = None, ring=None, mirror_shard=(1, 0)):
         """``lstep_update_rows``: pe[ids] += tanh(pe_mlp_2(relu(pe_mlp_1(agg))) [+ self_update_pe(pe[ids])]) in place, one launch."""
         lib = nat.load_library()
         Pp = self.ld_self
@@ -1394,7 +1394,7 @@ class LSTEP(nn.Module):
         with torch.cuda.device(pe.device):
             nat.check(lib.lstep_update_rows(nat.ptr(agg), int(agg.stride(0)), nat.ptr(ids), ids.numel(), nat.ptr(w1), nat.ptr(b1), nat.ptr(w2),
                                             nat.ptr(b2), nat.ptr(ws), nat.ptr(bs), nat.ptr(pe), nat.ptr(mirror), self.pe_dim, nat.ptr(live),
-                                            ring, nat.current_stream()))
+                                            ring, int(mirror_shard[0]), int(mirror_shard[1]), nat.current_stream()))
 
     @classmethod
     def _bucket_rows(cls, n: int) -> int:
@@ -1584,7 +1584,8 @@ class LSTEP(nn.Module):
         return touched
 
     @torch.no_grad()
-    def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None, mirror_ring=None):
+    def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None, mirror_ring=None,
+                         mirror_shard=(1, 0)):
         """``update_pe`` for the engine, with every data-dependent size left on the device: no host synchronisation, no second host
         thread, a fixed launch sequence.
 
@@ -1610,7 +1611,7 @@ class LSTEP(nn.Module):
             nat.check(lib.lstep_update_entries_p1(nat.ptr(order32), n2, nat.ptr(src), nat.ptr(dst), nat.ptr(t), nat.ptr(now32), src.numel(),
                                                   nat.ptr(ent_row), nat.ptr(ent_dt), nat.current_stream()))
         agg = self._segment_sum(pe, cap, seg32, ent_row, ent_dt, exact=True)
-        self._update_rows(pe, bn, agg, with_self=True, mirror=mirror, live=n_live, ring=mirror_ring)
+        self._update_rows(pe, bn, agg, with_self=True, mirror=mirror, live=n_live, ring=mirror_ring, mirror_shard=mirror_shard)
         if changed is not None:
             changed(bn, mirror is not None)       # (the dead tail marks row 0, which every update_pe rewrites anyway)
         # ---- phase 2 (LSTEP.py:305-339): row i of bn is zipped with the i-th EDGE time, rows >= min(U, B) stay padding
@@ -1654,7 +1655,7 @@ class LSTEP(nn.Module):
                 with torch.cuda.device(dev):
                     nat.check(lib.lstep_update_rows_pre(nat.ptr(agg_), int(agg_.stride(0)), nat.ptr(ids_), ids_.numel(), nat.ptr(w1b), nat.ptr(b1),
                                                         nat.ptr(w2), nat.ptr(b2), nat.ptr(pe), nat.ptr(mirror), P, D, nat.ptr(live_), mirror_ring,
-                                                        nat.current_stream()))
+                                                        int(mirror_shard[0]), int(mirror_shard[1]), nat.current_stream()))
             if changed is not None:
                 changed(touched, mirror is not None)
             return pe
@@ -1667,8 +1668,8 @@ class LSTEP(nn.Module):
             nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, nat.ptr(bn), cap, nat.ptr(pe), P, int(pe.stride(0)), nat.ptr(part),
                                                  nat.current_stream()))
         agg2[0, :P] = part.sum(dim=0)
-        self._update_rows(pe, touched[1:], agg2[1:], with_self=False, mirror=mirror, live=counts[0:1], ring=mirror_ring)
-        self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=counts[1:2], ring=mirror_ring)
+        self._update_rows(pe, touched[1:], agg2[1:], with_self=False, mirror=mirror, live=counts[0:1], ring=mirror_ring, mirror_shard=mirror_shard)
+        self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=counts[1:2], ring=mirror_ring, mirror_shard=mirror_shard)
         if changed is not None:
             changed(touched, mirror is not None)
         return pe

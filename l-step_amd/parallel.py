@@ -188,6 +188,68 @@ def owned_rows(num_rows: int, world: int, rank: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------- engine
+class ShardedSparseRing(HistoryRing):
+    """The sparse change-mask ring of the single-GPU engine (``engine.HistoryRing``, sparse mode) over the rows ONE rank owns: local row
+    id // W for the nodes with id % W == rank.  The current PE is the REPLICATED full table (``full``), updated in place by every rank;
+    a slot receives the rows its batch wrote straight from the update kernels (their ``mirror``, which maps id -> id // W and skips
+    rows of other owners), ``oldest`` follows the window.  No shard-sized copy of the current table, no per-batch clone: per batch a
+    rank appends only the rows it owns among the ~20 % of the table the batch wrote."""
+
+    def __init__(self, full_table: torch.Tensor, world: int, rank: int, num_fft_batches: int):
+        super().__init__(owned_rows(full_table.shape[0], world, rank), full_table.shape[1], num_fft_batches, full_table.device, sparse=True)
+        if not self.sparse:
+            raise RuntimeError("the owner-sharded sparse ring needs the change mask (at most 126 snapshots, no LSTEP_DENSE/CLONE_HISTORY)")
+        self.full, self.world, self.rank = full_table, int(world), int(rank)
+        self.table = None
+
+    def owned(self) -> torch.Tensor:
+        """Strided view of the rows this rank owns, in local order."""
+        return self.full[self.rank::self.world]
+
+    def last(self) -> torch.Tensor:
+        assert self.len > 0
+        return self.owned()
+
+    def spare(self) -> torch.Tensor:
+        return self.full
+
+    base_for_next = spare
+
+    def building(self):
+        return self.buf[(self.start + self.len) % self.S]
+
+    def written(self, ids: torch.Tensor, mirrored: bool = False):
+        self.mark(ids, self.world, self.rank, copy=not mirrored)
+
+    def commit(self):
+        dst = self.buf[(self.start + self.len) % self.S]
+        if self._all_written or self.len == 0:
+            dst.copy_(self.owned())
+        else:
+            for ids in self._written:          # writers without a mirror (none on the device-count path): their owned rows, copied now
+                own = ids[ids % self.world == self.rank]
+                dst.index_copy_(0, own // self.world, self.full[own])
+            # local row 0 carries the always-set change bit (lstep_history_slot_bits: it is the padding row on rank 0): keep it valid
+            dst[0].copy_(self.full[self.rank])
+        if self.len == 0:
+            self.oldest.copy_(self.owned())
+        self._written, self._all_written = [], False
+        if self.len < self.T:
+            self.len += 1
+        else:
+            self.start = (self.start + 1) % self.S
+            assert self._advance is None, "HistoryRing.apply_advance() must follow every commit()"
+            self._advance = self.start
+        self.begin_slot()
+
+    def adopt_full_slots(self):
+        self.recompute_mask()
+        self._written, self._all_written, self._advance, self._advanced = [], False, None, [None, None]
+        if self.len:
+            self.oldest.copy_(self.buf[self.start])
+        self.begin_slot()
+
+
 class DistributedLstep:
     """Drives one ``LstepEngine``'s model over a global batch shared by all ranks of ``group``."""
 
@@ -201,10 +263,21 @@ class DistributedLstep:
         self.device = dev
         rows = self.bb.node_raw_features.shape[0]
         self.num_rows = rows
-        self._ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
         self.table = torch.zeros((rows, self.bb.pe_dim), dtype=torch.float32, device=dev)  # replicated current PE
         self.slot_of = engine.slot_of
         engine.ring = None  # the unsharded ring is not used (and must not be allocated at scale)
+        # Two ways to run update_pe across ranks (``_phase2_replicated``): REPLICATED -- every rank runs the single-GPU engine's
+        # device-count update on the global batch and mirrors the rows it owns into a sparse ring shard: no update collective, no host
+        # wait -- or OWNER-COMPUTES with all-gathers of the new rows into clone slots (the scheme that scales past W = 4).
+        self.replicated = self._phase2_replicated() and self._device_update_ok()
+        if self.replicated:
+            self._ring = ShardedSparseRing(self.table, self.W, self.rank, self.bb.num_fft_batches)
+            engine.ring = self._ring        # (lets the engine's grouping helpers take their device-count branch; its own iterations are not used)
+            if engine.use_aux:
+                from .model import _aux_stream
+                self._ring.advance_stream = _aux_stream(dev)
+        else:
+            self._ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
         self._copy_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
         # update_pe's layers are forward-only (no gradient ever reaches them): they stay out of the bucket
         frozen = {id(p) for m in (self.bb.pe_mlp_1, self.bb.pe_mlp_2, self.bb.self_update_pe) for p in m.parameters()}
@@ -213,9 +286,16 @@ class DistributedLstep:
     # ---- state import/export (tests, checkpoints)
     def load_history(self, history: torch.Tensor):
         """Adopt a reference-shaped ``[N+1, t, P]`` history: this rank keeps its owned rows."""
-        self.ring.load(history[self.rank::self.W])
         if history.shape[1]:
             self.table.copy_(history[:, -1, :])
+        self.ring.load(history[self.rank::self.W])
+
+    def _device_update_ok(self) -> bool:
+        bb = self.bb
+        return (torch.device(self.device).type == "cuda" and bb._fused_tail_ok() and bb.num_fft_batches <= 126
+                and getattr(bb.neighbor_sampler, "sample_neighbor_strategy", "recent") == "recent"
+                and not any(os.environ.get(v) == "1" for v in ("LSTEP_TORCH_UPDATE", "LSTEP_TORCH_ENTRIES", "LSTEP_HOST_COUNTS",
+                                                                 "LSTEP_DENSE_HISTORY", "LSTEP_CLONE_HISTORY")))
 
     def _append_snapshot(self):
         """This rank's rows of the finished table become the newest snapshot of its ring shard.  The strided copy (N / W rows of 688 B)
@@ -248,7 +328,8 @@ class DistributedLstep:
         owner rank to the host behind it, so the next iteration starts without waiting for the GPU."""
         self.eng.prefetch_batch_nodes(*lookahead)
         key, (_, _, uniq, pending) = self.eng._prefetched_group
-        valid = torch.arange(uniq.numel(), device=uniq.device) < pending._keep[0]       # entries past n_unique are uninitialised
+        n_unique = pending[0] if isinstance(pending, torch.Tensor) else pending._keep[0]     # (device summary / pending host count)
+        valid = torch.arange(uniq.numel(), device=uniq.device) < n_unique               # entries past n_unique are uninitialised
         ranks = torch.arange(self.W, device=uniq.device, dtype=uniq.dtype)
         # (not torch.bincount: it reads the largest value back to size its output, a host synchronisation)
         per_owner = ((torch.remainder(uniq, self.W).unsqueeze(1) == ranks) & valid.unsqueeze(1)).sum(dim=0)
@@ -283,7 +364,9 @@ class DistributedLstep:
         owned_idx = order[first:first + counts[self.rank]]             # positions in bn of the nodes this rank owns
         self._owned_idx = owned_idx
         mine = bn[owned_idx]                                           # (sizes known on the host: no boolean-mask compaction)
-        rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx, mask=self.ring.mask)
+        self.ring.wait_window()
+        rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx, mask=self.ring.mask,
+                                           oldest=self.ring.oldest)
         return bn, rows_mine, PendingGather(rows_mine.detach(), self.group, counts=counts), order, counts
 
     def _splice_finish(self, started):
@@ -348,7 +431,7 @@ class DistributedLstep:
         policy = os.environ.get("LSTEP_PHASE2", "auto")
         if policy not in ("auto", "replicate", "allgather"):
             raise ValueError("LSTEP_PHASE2 must be auto, replicate or allgather")
-        return self.W > 1 and (policy == "replicate" or (policy == "auto" and self.W <= 4))
+        return policy == "replicate" or (policy == "auto" and self.W <= 4)
 
     def _update_phase2(self, bn, ts, state):
         """update_pe phase 2 up to the all-gather of its rows, which is left in flight."""
@@ -383,7 +466,118 @@ class DistributedLstep:
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
         with self.eng.aux_streams():
+            if self.replicated:
+                return self._train_iteration_replicated(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
             return self._train_iteration(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
+
+    # ---- the replicated-update form: forward / backward exactly as below, update_pe = the single-GPU engine's, on the global batch
+    def _global_batch_nodes(self, src, dst, batch_idx):
+        """(exact sorted batch nodes, capacity-sized list with its device count, grouping, rows per owner).  The per-owner counts come
+        from the look-ahead of the previous iteration when there was one (no host wait); otherwise the host waits for the grouping."""
+        owner_counts = self._prefetched_owner_counts(src, dst)      # (before the grouping below consumes the engine's prefetch)
+        bn_cap, n_live, presorted = self.eng.batch_nodes_device(src, dst)
+        if owner_counts is None:
+            u = int(n_live.item())
+            owner_counts = torch.bincount(bn_cap[:u] % self.W, minlength=self.W).tolist()
+        u = sum(owner_counts)
+        return bn_cap[:u], bn_cap, n_live, presorted, owner_counts
+
+    def _forward_on_slice(self, bn, batch_idx, owner_counts, src, dst, neg_dst, ts):
+        """FFT splice (owner-sharded filter + all-gather) and this rank's slice through gather, dense tail, predictor and loss."""
+        n_glob = src.numel()
+        b = n_glob // self.W
+        sl = slice(self.rank * b, (self.rank + 1) * b)
+        started = self._splice_start(bn, batch_idx, owner_counts)
+        s_, d_, n_, t_ = src[sl], dst[sl], neg_dst[sl], ts[sl]
+        ids3, t3 = torch.cat([s_, d_, n_]), torch.cat([t_, t_, t_])
+        fused = self.bb._fused_tail_ok()
+        # edge + node channels first: they read no PE row, so their launch overlaps the all-gather of the filtered rows
+        x_edge, x_node, _, _, _ = self.bb._gather(None, ids3, t3, self.K, self.G, nat_branch("edge_node"), wide=fused, row_blocks=3)
+        rows_mine, leaf, (owner_order, owner_counts) = self._splice_finish(started)
+        spliced = SplicedRows(leaf, self.slot_of)
+        _, _, x_pe, own, _ = self.bb._gather(self.table, ids3, t3, self.K, self.G, nat_branch("pe"), spliced, wide=fused, row_blocks=3)
+        emb_p = self.bb._combined_tail(x_edge, x_node, x_pe, own, fused)
+        logits = self.predictor.pair_logits(emb_p, b, (0, b, 0, 2 * b))
+        loss, lp_loss, pe_loss, predicts = _LinkLoss.apply(logits, leaf, self.table, self.slot_of, ids3, self.eng.pe_weight,
+                                                           self.eng.neg_sample_weight)
+        out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
+        return out, loss, rows_mine, leaf, owner_order, owner_counts
+
+    def _train_iteration_replicated(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
+        assert src.numel() % self.W == 0, "global batch must divide by the world size"
+        bb, ring = self.bb, self._ring
+        bb.prepare_step()
+        bn, bn_cap, n_live, presorted, owner_counts = self._global_batch_nodes(src, dst, batch_idx)
+        out, loss = None, None
+        if batch_idx == 0:
+            self.table.copy_(initial_pe)
+            ring.begin_slot(all_changed=True)
+        else:
+            out, loss, rows_mine, leaf, owner_order, owner_counts = self._forward_on_slice(bn, batch_idx, owner_counts, src, dst, neg_dst, ts)
+        if lookahead is not None:
+            self._prefetch(lookahead)
+
+        def update_and_append():
+            # every rank updates ALL rows of its replica (same inputs everywhere) and mirrors the ones it owns into its ring shard
+            bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building(),
+                                mirror_shard=(self.W, self.rank))
+            if batch_idx == 0 and initial_pe is not None:
+                initial_pe.copy_(self.table)
+            ring.commit()
+
+        if loss is None:
+            update_and_append()
+            ring.apply_advance()
+            return out
+        main, side = torch.cuda.current_stream(self.device), self.eng._update_stream
+        overlap = self.eng.overlap_update
+        if overlap:
+            side.wait_stream(main)       # after the forward pass: it reads the table update_pe is about to rewrite
+            with torch.cuda.stream(side):
+                update_and_append()
+        else:
+            update_and_append()
+        optimizer.zero_grad()
+        (loss / self.W).backward()                       # global mean = mean of the rank means
+        g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+        g_mine = reduce_scatter_var(g_rows[owner_order].contiguous(), owner_counts, self.group)
+        if rows_mine.numel():
+            rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
+        bb.join_aux_stream()
+        all_reduce_gradients(self._trainable, self.group)
+        ring.apply_advance()             # the backward pass is enqueued: the window's oldest snapshot may move on behind it
+        if overlap:
+            main.wait_stream(side)       # the optimiser may only step once update_pe has read its weights
+        optimizer.step()
+        self.slot_of.index_fill_(0, bn, -1)
+        v = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
+        all_reduce_sum(v, self.group)
+        out["lp_loss"], out["pe_loss"], out["loss"] = (v / self.W).unbind(0)
+        return out
+
+    def _eval_iteration_replicated(self, batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead):
+        n_glob = src.numel()
+        b = n_glob // self.W
+        sl = slice(self.rank * b, (self.rank + 1) * b)
+        bb, ring = self.bb, self._ring
+        bn, bn_cap, n_live, presorted, owner_counts = self._global_batch_nodes(src, dst, batch_idx)
+        self._splice(bn, batch_idx, owner_counts)
+        self.slot_of.index_fill_(0, bn, -1)
+        ids = torch.cat([src[sl], dst[sl], neg_src[sl], neg_dst[sl]])
+        emb_p = bb.combining_pe_raw_feat(self.table, ids, torch.cat([ts[sl]] * 4), self.K, self.G, padded=True, row_blocks=4)
+        if self.predictor.fused_ok(emb_p):
+            predicts = self.predictor.pair_logits(emb_p, b, (0, b, 2 * b, 3 * b)).sigmoid().clamp(0, 1)
+        else:
+            emb = emb_p[:, :bb.feat_dim]
+            predicts = torch.cat([self._probabilities(emb[:b], emb[b:2 * b]), self._probabilities(emb[2 * b:3 * b], emb[3 * b:])], dim=0)
+        labels = torch.cat([torch.ones(b, device=self.device), torch.zeros(b, device=self.device)])
+        if lookahead is not None:
+            self._prefetch(lookahead)
+        bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building(),
+                            mirror_shard=(self.W, self.rank))
+        ring.commit()
+        ring.apply_advance()
+        return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}
 
     def _train_iteration(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
         n_glob = src.numel()
@@ -481,6 +675,8 @@ class DistributedLstep:
 
     # ---- evaluate_model_utils.py:38-142 on a global batch (call under torch.no_grad())
     def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
+        if self.replicated:
+            return self._eval_iteration_replicated(batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead)
         n_glob = src.numel()
         b = n_glob // self.W
         sl = slice(self.rank * b, (self.rank + 1) * b)

@@ -19,7 +19,7 @@ for n, with_self in ((45000, True), (213000, False), (262144, False), (65536, Fa
     def run():
         nat.check(lib.lstep_update_rows(nat.ptr(agg), 272, nat.ptr(ids), n, nat.ptr(w1), nat.ptr(b1), nat.ptr(w2), nat.ptr(b2),
                                         nat.ptr(ws) if with_self else None, nat.ptr(bs) if with_self else None, nat.ptr(table), None, 172,
-                                        None, None, nat.current_stream()))
+                                        None, None, 1, 0, nat.current_stream()))
     for _ in range(3):
         run()
     torch.cuda.synchronize()

@@ -33,7 +33,7 @@ for live_n, cap in ((290_000, 290_000), (290_000, 655_361), (32_500, 32_768), (1
 
     def run(use_live):
         nat.check(lib.lstep_update_rows(nat.ptr(agg), 272, nat.ptr(ids), cap if use_live else live_n, nat.ptr(w1), nat.ptr(b1), nat.ptr(w2), nat.ptr(b2),
-                                        None, None, nat.ptr(table), None, 172, nat.ptr(live) if use_live else None, None, nat.current_stream()))
+                                        None, None, nat.ptr(table), None, 172, nat.ptr(live) if use_live else None, None, 1, 0, nat.current_stream()))
     a, b = timeit(lambda: run(False)), timeit(lambda: run(True))
     fl = live_n * 158e3
     print(f"live {live_n:7d} capacity {cap:7d}: exact launch {a:8.1f} us ({fl / a / 1e6:5.1f} TF/s) | capacity launch + device count {b:8.1f} us")
