@@ -312,9 +312,11 @@ def main():
                        "history": (f"evolved: {prerolled} pre-roll batches through the engine's own eval iteration + {prime} through its training iteration"
                                    if args.history == "evolved" else f"random: T independent snapshots (+ {prime} training iterations of set-up)"),
                        "step_graph": bool(getattr(runner, "use_step_graph", False)),
-                       "parallelism": (f"x{world}: PE history, FFT filter and update_pe sharded by node owner (id % {world}); gather / dense tail / loss "
-                                       f"on each rank's {B}-edge slice of the global batch; RCCL all-gather of updated PE rows") if use_dist
-                                      else "single GPU"},
+                       "parallelism": ((f"x{world}: PE history ring and FFT filter sharded by node owner (id % {world}), RCCL all-gather of the "
+                                        f"filtered rows / reduce-scatter of their gradient; gather, dense tail and loss on each rank's {B}-edge "
+                                        f"slice of the global batch; update_pe " +
+                                        ("replicated on the global batch (no update collective)" if getattr(runner, "replicated", False)
+                                         else "sharded by owner with RCCL all-gather of the updated PE rows")) if use_dist else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": GATHER_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "launch_timing": timing_note, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),

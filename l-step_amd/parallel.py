@@ -420,18 +420,21 @@ class DistributedLstep:
         return now32, fused
 
     def _phase2_replicated(self) -> bool:
-        """How the replicas of the PE table receive phase 2's rows.  ``allgather``: every rank computes the rows it
-        owns and all-gathers them -- U2 x 704 B per step, 72-91 % of the table at the BASELINE shapes: 2.1-3.3 ms of link time.
-        ``replicate``: every rank runs phase 2 for ALL touched rows itself (same inputs on every rank: the batch-node rows were all-gathered
-        by phase 1, the CSR is replicated) and nothing travels; the work grows with the global batch (0.9 / 1.1 / 3.4 ms of update_rows at
-        W = 2 / 4 / 8 on c4 / c4 / c5).  ``auto`` (default) replicates up to W = 4, where it is the cheaper of the two.
-        Replicas stay bit-identical under ``replicate`` as long as no touched row collects more than 128 messages (a segment cut into
-        two 64-entry chunks is a two-operand sum, which commutes; three or more partial sums are added with float atomics in arrival
-        order, 1 ulp apart at most); the history shard always stores the owner's value."""
+        """How the replicas of the PE table receive update_pe's rows.
+        ``replicate`` (default, ``auto``): every rank runs update_pe for ALL rows itself -- same inputs on every rank (the spliced rows
+        were all-gathered, the CSR and the edge stream are replicated) -- and nothing travels; the work grows with the global batch
+        (phase 2 touches 0.72 / 0.91 / 2.9 M rows at W = 2 / 4 / 8 on c4 / c4 / c5: ~0.8 / 1.0 / 3 ms of matrix-core time on the side
+        stream), but it is the single-GPU engine's host-free device-count path (``_train_iteration_replicated``).
+        ``allgather``: every rank computes the rows it owns and all-gathers them -- U2 x 704 B per step, 72-91 % of the table at the
+        BASELINE shapes: 2.1-3.3 ms of link time, plus host waits for the data-dependent sizes of the exchange.  Measured at W = 1 on RCCL
+        with the collectives forced: 3.92 ms/step replicated, 5.84 owner-computes.
+        Replicas stay bit-identical under ``replicate`` as long as no touched row collects more than 128 messages in one batch (a
+        segment cut into two 64-entry chunks is a two-operand sum, which commutes; three or more partial sums are added with float
+        atomics in arrival order, 1 ulp apart at most); the history shard always stores the owner's value."""
         policy = os.environ.get("LSTEP_PHASE2", "auto")
         if policy not in ("auto", "replicate", "allgather"):
             raise ValueError("LSTEP_PHASE2 must be auto, replicate or allgather")
-        return policy == "replicate" or (policy == "auto" and self.W <= 4)
+        return policy != "allgather"
 
     def _update_phase2(self, bn, ts, state):
         """update_pe phase 2 up to the all-gather of its rows, which is left in flight."""
