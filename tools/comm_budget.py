@@ -46,6 +46,13 @@ def budget(name, N, B, K, W):
     print(f"    -- destination-owner sharding of the gather stage instead of batch slices: + all-gather of the embeddings {emb * frac / 1e6:7.1f} MB in "
           f"per rank forward and the same again for their gradient, both on the critical path ({2 * emb * frac / bw * 1e3:.2f} ms), to save "
           f"{(1 - 2 / W) * 100:.0f} % of the edge table per rank")
+    # the replicated-update form (DistributedLstep's default): no update collective, but every rank runs update_pe for the whole global batch.
+    # Matrix-core time from the one-GPU measurement (lstep_update_rows_pre: 0.46 ms per 290 k touched rows, 0.09 ms per 32 k phase-1 rows),
+    # segment sums 0.1 ms and sorting 0.08 ms per 0.65 M messages
+    msgs = U * K
+    rep_ms = U2 / 290e3 * 0.46 + U / 32e3 * 0.09 + msgs / 0.65e6 * (0.10 + 0.08)
+    print(f"    -- replicated update_pe instead of the two update all-gathers: 0 MB, ~{rep_ms:.1f} ms of kernels on the side stream (single GPU: ~0.9 ms), "
+          f"against ~2 ms of backward pass to hide under")
     pull = need * P_ROW * frac
     print(f"    -- owner-sharded PE table with a pull of the rows the next gather reads: {pull / 1e6:7.1f} MB in per rank "
           f"({pull / bw * 1e3:.2f} ms) instead of the phase-2 all-gather's {rows['phase-2 rows all-gather (side stream, under the backward pass)'] * frac / 1e6:.1f} MB, "
