@@ -176,9 +176,9 @@ constexpr int kRunsFwdBlocks = 256 * 4;   // persistent grid of the forward kern
 
 
 // persistent waves: wave w handles nodes w, w + waves, ...; the next node's id and mask are fetched while the current node's rows travel.
-// IN_LDS: the workgroup (16 waves, one per CU) first builds the float64 prefix table of coef in LDS ((t_len + 1) * P * 8 bytes, 139 KB for
-// T = 100, P = 172) and reads the run weights from there: with the table in L2 every run costs 1376 B of L1 fills next to its 688-B row,
-// and the kernel was bound by that (245 us against 155 us with the weights faked).  Otherwise cpre is the table coef_prefix_kernel made.
+// cpre = the float64 prefix table of coef (coef_prefix_kernel).  IN_LDS: the workgroup (16 waves, one per CU) first copies it into LDS
+// ((t_len + 1) * P * 8 bytes, 139 KB for T = 100, P = 172) and reads the run weights from there: with the table in L2 every run costs
+// 1376 B of L1 fills next to its 688-B row, and the kernel was bound by that (245 us against 155 us with the weights faked).
 template <bool IN_LDS>
 __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fwd_kernel(HistView h, int t_len, int P, const uint32_t* __restrict__ mask,
                                                                                          int words, const int64_t* __restrict__ ids, int64_t num_ids,
@@ -194,14 +194,12 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fw
     const int lane = lane_id();
     const int waves_per_block = (int)(blockDim.x >> 6);
     if (IN_LDS) {
-        for (int p = threadIdx.x; p < P; p += blockDim.x) {
-            double run = 0.0;
-            cpre_lds[p] = 0.0;
-            for (int s = 0; s < t_len; ++s) {
-                run += (double)coef[(int64_t)s * P + p];
-                cpre_lds[(s + 1) * P + p] = run;
-            }
-        }
+        // copy the prefix table coef_prefix_kernel made (139 KB, L2-resident) with all 1024 threads, 16 bytes each: a few microseconds,
+        // where building it here kept 172 threads busy with 100 dependent steps each (~30 us of every launch, whatever the batch size)
+        const int n2 = ((t_len + 1) * P) >> 1;               // (P is a multiple of 4: the table is a whole number of double2)
+        const double2_* src = reinterpret_cast<const double2_*>(cpre);
+        double2_* dst = reinterpret_cast<double2_*>(cpre_lds);
+        for (int k = threadIdx.x; k < n2; k += blockDim.x) dst[k] = src[k];
         __syncthreads();
     }
     const int64_t waves = (int64_t)gridDim.x * waves_per_block;
@@ -533,8 +531,10 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
         // one 16-wave workgroup per CU, prefix table in LDS
         int64_t blocks = (num_ids + 15) / 16;
         if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(coef_prefix_kernel, dim3((unsigned)((pe_dim + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                           coef, (int)t_len, (int)pe_dim, cpre);
         hipLaunchKernelGGL(history_filter_runs_fwd_kernel<true>, dim3((unsigned)blocks), dim3(1024), lds_bytes, (hipStream_t)stream, h, (int)t_len,
-                           (int)pe_dim, mask, (int)mask_words, node_ids, num_ids, coef, (const double*)nullptr, out, table_out, slot_of, num_live);
+                           (int)pe_dim, mask, (int)mask_words, node_ids, num_ids, coef, (const double*)cpre, out, table_out, slot_of, num_live);
         return check_launch("history_filter_runs_fwd_kernel<lds>");
     }
     hipLaunchKernelGGL(coef_prefix_kernel, dim3((unsigned)((pe_dim + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, (hipStream_t)stream,
