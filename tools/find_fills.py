@@ -59,10 +59,23 @@ print("---- Python-level calls in one iteration")
 for (op, where), n in sorted(calls.items(), key=lambda kv: (kv[0][0], -kv[1])):
     print(f"{n:3d} x {op:12s} {where}")
 
-# (2) every aten op of one iteration (names and counts), autograd-internal ones included
-with profile(activities=[ProfilerActivity.CPU]) as prof:
+# (2) every aten op of one iteration (names and counts), autograd-internal ones included; for the fill / zero / copy family the innermost
+#     Python frames (C++-internal calls show the frame of the Python call that led into them)
+try:
+    cfg = torch._C._profiler._ExperimentalConfig(verbose=True)
+except Exception:  # noqa: BLE001
+    cfg = None
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, experimental_config=cfg) as prof:
     step(5)
 torch.cuda.synchronize()
 ops = collections.Counter(ev.name for ev in prof.events() if ev.name.startswith("aten::"))
 print("---- aten ops in one iteration")
 print(", ".join(f"{n} x {k[6:]}" for k, n in ops.most_common(60)))
+print("---- stacks of the fill / zero / copy family")
+where = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::zeros", "aten::zero_", "aten::fill_", "aten::copy_", "aten::zeros_like", "aten::cat", "aten::mul", "aten::add_", "aten::add"):
+        st = [f for f in (ev.stack or []) if "l-step_amd" in f or "lstep_amd" in f or "torch/autograd" in f or "optim" in f]
+        where[(ev.name, " <- ".join(f.strip().split("/")[-1][:60] for f in st[:3]) or "(no Python frame: autograd engine / C++)")] += 1
+for (op, w), n in sorted(where.items(), key=lambda kv: (kv[0][0], -kv[1])):
+    print(f"{n:3d} x {op:14s} {w}")
