@@ -419,7 +419,20 @@ class _LinkLoss(torch.autograd.Function):
         if g_loss is None:
             return (None,) * 7
         d_logits, d_rows = ctx.saved_tensors
+        if _LinkLoss.unit_gradient:      # the engine's own ``loss.backward()``: the incoming gradient is the scalar 1 (two launches less)
+            return d_logits, d_rows, None, None, None, None, None
         return g_loss * d_logits, g_loss * d_rows, None, None, None, None, None
+
+    unit_gradient = False     # set by LstepEngine around its own backward call (a plain ``loss.backward()``)
+
+
+def _backward_unit(loss):
+    """``loss.backward()`` of the engine's own iteration: the seed gradient is 1, ``_LinkLoss.backward`` hands its saved gradients on as they are."""
+    _LinkLoss.unit_gradient = True
+    try:
+        loss.backward()
+    finally:
+        _LinkLoss.unit_gradient = False
 
 
 class GraphedTrainStep:
@@ -684,7 +697,7 @@ class LstepEngine:
             update_and_append()
             if loss is not None:
                 optimizer.zero_grad()
-                loss.backward()
+                _backward_unit(loss)
                 bb.join_aux_stream()
                 optimizer.step()
                 self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
@@ -704,7 +717,7 @@ class LstepEngine:
             with torch.cuda.stream(side):
                 update_and_append()
             optimizer.zero_grad()
-            loss.backward()
+            _backward_unit(loss)
             bb.join_aux_stream()
             ring.apply_advance()  # the backward pass is enqueued: the window's oldest snapshot may move on behind it
             main.wait_stream(side)
@@ -727,7 +740,7 @@ class LstepEngine:
         th.start()
         try:
             optimizer.zero_grad()
-            loss.backward()
+            _backward_unit(loss)
             bb.join_aux_stream()
         finally:
             # whatever happened above, the worker must not be left mutating the table / mask / commit state behind our back, and the

@@ -1006,7 +1006,8 @@ class _HistoryFilter(torch.autograd.Function):
         hist_base, mask = ctx.hist, ctx.mask
         node_stride, time_stride, slots, rot, t_len, P = ctx.geom
         U = ids.numel()
-        g_coef = torch.zeros(ctx.coef_shape, dtype=torch.float32, device=ids.device)
+        full = ctx.needs_input_grad[0] and U > 0 and t_len == ctx.coef_shape[0] and mask is not None      # every row is written below
+        g_coef = (torch.empty if full else torch.zeros)(ctx.coef_shape, dtype=torch.float32, device=ids.device)
         if ctx.needs_input_grad[0] and t_len > 0 and U > 0:
             chunks = int(lib.lstep_history_filter_bwd_chunks(U) if mask is None else lib.lstep_history_filter_runs_bwd_chunks(U, t_len))
             partial = torch.empty((chunks, t_len, P), dtype=torch.float32, device=ids.device)
