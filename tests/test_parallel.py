@@ -203,6 +203,36 @@ def test_bench_starts_its_own_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["config"]["per_gpu_batch"] == 256 and line["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_single_gpu_line_keeps_the_contract():
+    """`python bench.py` on one GPU (tiny workload, the graphed step like the default run): ONE JSON line with the driver's keys, BASELINE.json's
+    metric, the roofline object of the gather kernel and the workload named in `config` -- and the timed steps must really have been graph replays."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LSTEP_FORCE_DIST")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--workload", "tiny", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):      # (cpu_baseline is left out by --no-cpu-baseline: it takes 10-30 s of host time)
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 2 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["unit"] == "edges/s" and line["dtype"] == "f32" and line["data"] == "synthetic" and line["scaling"] == "weak"
+    assert abs(line["value"] - line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert line["config"]["workload_name"] == "tiny" and "model" not in line["config"] and line["config"]["step_graph"] is True
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "algorithmic_bytes_per_launch"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and roof["launch_ms"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 1e-6 * roof["achieved"]
+
+
 def test_bench_default_workload_by_gpu_count():
     import importlib.util
     root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
