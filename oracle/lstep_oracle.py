@@ -184,7 +184,7 @@ class OracleLSTEP(nn.Module):
             mask = torch.zeros_like(x)
             mask[:, :batch_idx, :] = 1.0  # keyed on batch_idx, not on the stored length (:113)
         _unused = torch.clone(x)  # the reference keeps an (unused) copy here (:115); kept so the CPU baseline pays for it too
-        z = torch.fft.fftn(x.to(self.fft_filter.weight.dtype), dim=1)                  # complex64 (:116)
+        z = torch.fft.fftn(x.to(torch.complex64), dim=1)                               # complex64, whatever the parameters' width (:116)
         if mask is not None:
             z = z * mask
         z = self.fft_filter.weight.unsqueeze(0) * z
@@ -193,8 +193,9 @@ class OracleLSTEP(nn.Module):
         z = torch.fft.ifftn(z, dim=1)
         if mask is not None:
             z = z * mask
-        y = z.real.to(self.fft_agg.weight.dtype)  # float32; imaginary part dropped (:129)
-        return self.fft_agg(y.permute(0, 2, 1)).squeeze()
+        y = z.real.to(torch.float32)  # float32; imaginary part dropped (:129)
+        # (the widening is a no-op in the fp32 model; ``float64_yardstick`` keeps the reference's explicit complex64 / float32 casts)
+        return self.fft_agg(y.permute(0, 2, 1).to(self.fft_agg.weight.dtype)).squeeze()
 
     # ---- A + N: edge/time channel and node channel (LSTEP.py:139-220)
     def aggregated_node_embeddings(self, node_ids, node_interact_times, num_neighbors=20, time_gap=2000, testing=False):

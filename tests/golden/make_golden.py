@@ -306,6 +306,102 @@ def gen_traces():
     print("traces.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------- long training trace (graph-replay parity)
+LONG_BATCHES = 16     # T = 4: the window is full after batch 3, batches 4 and 5 prime the capture, batch 6 is captured, 7..15 are replays
+LONG_GRAD_STRIDE = 32
+
+
+def gen_traces_long():
+    """The training loop body of train_LSTEP_link_prediction.py:204-311 over 16 consecutive batches of the trace graph (same graph, weights
+    and first 7 batches as ``gen_traces``), with EVERY step's losses, probabilities, snapshot and parameter gradients: the fixture the
+    graph-replayed engine iteration (engine.GraphedTrainStep) is held to."""
+    g = synth.make_temporal_graph(**TRACE_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=31)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=32)
+    sampler = ref_sampler(g)
+    out = {}
+    model = ref_model(node_raw, edge_raw, sampler, TRACE_K, TRACE_T)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    state = protocol.ProtocolState(history=torch.zeros(g["num_nodes"] + 1, 0, synth.PE_DIM), initial_pe=torch.from_numpy(pe0.copy()))
+    for b in range(LONG_BATCHES):
+        sl = slice(TRACE_START + b * TRACE_B, TRACE_START + (b + 1) * TRACE_B)
+        neg = synth.make_negatives(g["num_nodes"], TRACE_B, seed=500 + b)
+        res = protocol.train_iteration(model[0], model[1], opt, state, b, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], neg,
+                                       TRACE_K, TRACE_G, TRACE_T)
+        out[f"b{b}/snapshot"] = state.history[:, -1, :].numpy().copy()
+        if res is None:
+            continue
+        out[f"b{b}/losses"] = np.asarray([res["lp_loss"], res["pe_loss"], res["loss"]])
+        out[f"b{b}/predicts"] = res["predicts"]
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            a = p.grad.detach().numpy()
+            a = np.stack([a.real, a.imag], -1) if np.iscomplexobj(a) else a.copy()
+            out[f"b{b}/grads/{k}/digest"] = np.asarray([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+            out[f"b{b}/grads/{k}"] = a[::LONG_GRAD_STRIDE] if a.size > 20000 else a
+    out["final_history"] = state.history[:, -TRACE_T:, :].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "traces_long.npz"), **out)
+    print("traces_long.npz", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------------------- the reference in float64 (pins oracle.float64_yardstick)
+F64_GRAPH = dict(num_nodes=64, num_edges=2000, seed=40, time_span=4096.0, tie_quantum=0.125)    # every time and time difference is exact in float32
+F64_K, F64_T = 5, 6
+
+
+def gen_float64():
+    """The reference CLASSES evaluated in float64: parameters and feature tables widened, every nn.Linear input widened by a forward
+    pre-hook (the reference casts time differences to float32 explicitly, models/LSTEP.py:153,228,277,314; the float32 VALUES stay,
+    only the arithmetic after them is double), torch's default dtype float64 while it runs (the dense scatter targets of :282,319 are
+    ``torch.zeros`` of the default dtype).  ``torch.Tensor([current_time])`` (:277) follows the default dtype too, so the graph's
+    timestamps are multiples of 1/8 below 4096: every timestamp and every difference is exact in float32 and the reference's float32
+    roundings are the identity either way."""
+    g = synth.make_temporal_graph(**F64_GRAPH)
+    assert np.array_equal(g["ts"], g["ts"].astype(np.float32).astype(np.float64))
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=41)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=42).astype(np.float64)
+    sampler = ref_sampler(g)
+    model = ref_model(node_raw, edge_raw, sampler, F64_K, F64_T).double()
+    bb = model[0]
+    bb.fft_filter.weight = torch.nn.Parameter(bb.fft_filter.weight.detach().to(torch.complex128))
+    bb.node_raw_features, bb.edge_raw_features = bb.node_raw_features.double(), bb.edge_raw_features.double()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.register_forward_pre_hook(lambda mod, inp: (inp[0].to(mod.weight.dtype),))
+    out = {}
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.no_grad():
+            pe = torch.from_numpy(pe0.copy())
+            sl = slice(40, 56)        # one early update_pe makes the padding row live (as ``live_pe``)
+            bn = protocol.unique_batch_nodes(g["src"][sl], g["dst"][sl])
+            bb.update_pe(pe, bn, g["eid"][sl], g["src"][sl], g["dst"][sl], g["ts"][sl], g["ts"][sl].max(), num_neighbors=F64_K)
+            out["pe_live"] = pe.numpy().copy()
+            for tag, sl in {"mid": slice(1200, 1216), "early": slice(3, 19)}.items():
+                src, dst, t = g["src"][sl], g["dst"][sl], g["ts"][sl]
+                out[f"{tag}/out_src"] = bb.combining_pe_raw_feat(pe, src, t, F64_K, 2000).numpy()
+                out[f"{tag}/out_dst"] = bb.combining_pe_raw_feat(pe, dst, t, F64_K, 8).numpy()
+            sl = slice(1200, 1216)
+            src, dst, t, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+            bn = protocol.unique_batch_nodes(src, dst)
+            pe_in = pe.clone()
+            bb.update_pe(pe_in, bn, eid, src, dst, t, t.max(), num_neighbors=F64_K)
+            out["update/pe_out"] = pe_in.numpy().copy()
+            rng = np.random.RandomState(43)
+            hist = 0.1 * rng.standard_normal((g["num_nodes"] + 1, F64_T, synth.PE_DIM))
+            ids = np.asarray([1, 2, 5, 9, 17, 33, 64, 0], dtype=np.int64)
+            out["fft/ids"] = ids
+            for stored, bidx in ((3, 3), (F64_T, 9)):
+                out[f"fft/stored{stored}_b{bidx}"] = bb.fourier_transform_pe(ids, torch.from_numpy(hist[:, :stored, :].copy()), bidx).numpy()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert all(v.dtype == np.float64 for k, v in out.items() if k != "fft/ids"), {k: v.dtype for k, v in out.items()}
+    np.savez_compressed(os.path.join(HERE, "float64.npz"), **out)
+    print("float64.npz", len(out), "arrays")
+
+
 # ----------------------------------------------------------------------------------------------- row P pinned by the reference's own loop
 EVAL_LOOP = dict(first=1200, edges=6 * 16 + 5, batch=16, stored=2)      # a ragged tail batch of 5 edges (drop_last=False)
 
@@ -474,7 +570,7 @@ def gen_loader():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop", "variants"]
+    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop", "variants", "traces_long", "float64"]
     if "sampler" in which:
         gen_sampler()
     if "time" in which:
@@ -491,3 +587,7 @@ if __name__ == "__main__":
         gen_eval_loop()
     if "variants" in which:
         gen_variants()
+    if "traces_long" in which:
+        gen_traces_long()
+    if "float64" in which:
+        gen_float64()

@@ -23,6 +23,9 @@ TRACE_GRAPH = dict(num_nodes=64, num_edges=2000, seed=30)
 TRACE_K, TRACE_T, TRACE_B, TRACE_G = 5, 4, 16, 2000
 TRACE_START, TRACE_BATCHES, GRAD_ROW_STRIDE = 640, 7, 4
 EVAL_LOOP = dict(first=1200, edges=6 * 16 + 5, batch=16, stored=2)
+LONG_BATCHES, LONG_GRAD_STRIDE = 16, 32          # tests/golden/traces_long.npz
+F64_GRAPH = dict(num_nodes=64, num_edges=2000, seed=40, time_span=4096.0, tie_quantum=0.125)   # tests/golden/float64.npz
+F64_K, F64_T = 5, 6
 WS_GRAPH = dict(num_nodes=40, num_edges=1200, seed=90, time_span=60.0, tie_quantum=0.25)
 WS_K, WS_T = 5, 4
 
@@ -47,6 +50,35 @@ def trace_batches(g):
         sl = slice(TRACE_START + b * TRACE_B, TRACE_START + (b + 1) * TRACE_B)
         out.append((g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], synth.make_negatives(g["num_nodes"], TRACE_B, seed=500 + b)))
     return out
+
+
+def long_trace_batches(g):
+    """The 16 consecutive batches of tests/golden/traces_long.npz (the first 7 are ``trace_batches``)."""
+    out = []
+    for b in range(LONG_BATCHES):
+        sl = slice(TRACE_START + b * TRACE_B, TRACE_START + (b + 1) * TRACE_B)
+        out.append((g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], synth.make_negatives(g["num_nodes"], TRACE_B, seed=500 + b)))
+    return out
+
+
+def check_long_trace_gradients(model, z, b, atol, digest_atol):
+    """Parameter gradients of step b against tests/golden/traces_long.npz (big matrices: every 32nd row + a digest of all of it)."""
+    for k, p in model.named_parameters():
+        if f"b{b}/grads/{k}" not in z.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        a = p.grad.detach().cpu().numpy()
+        a = np.stack([a.real, a.imag], -1) if np.iscomplexobj(a) else a
+        got = a[::LONG_GRAD_STRIDE] if a.size > 20000 else a
+        np.testing.assert_allclose(got, z[f"b{b}/grads/{k}"], rtol=0, atol=atol, err_msg=f"b{b} {k}")
+        np.testing.assert_allclose(a.astype(np.float64).sum(), z[f"b{b}/grads/{k}/digest"][0], rtol=0, atol=digest_atol, err_msg=f"b{b} {k}")
+
+
+def float64_inputs():
+    g = synth.make_temporal_graph(**F64_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=41)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=42).astype(np.float64)
+    return g, node_raw, edge_raw, pe0
 
 
 def eval_batches(g):
