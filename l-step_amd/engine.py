@@ -96,6 +96,7 @@ class HistoryRing:
         # the ring rotates -- the precondition for replaying a captured iteration (``GraphedTrainStep``).
         self.dev_start = None
         self._dev_mirror = 0     # the value the host knows ``dev_start`` to hold (it trails ``start`` between a commit and the tick)
+        self.generation = 0      # bumped whenever the window is replaced from outside (``load`` / ``adopt_full_slots``): captured iterations are stale then
 
     def position_on_device(self):
         """Keep the ring position on the device from now on (sparse rings whose window is full)."""
@@ -289,12 +290,26 @@ class HistoryRing:
         """The window's slots were filled with FULL snapshots from outside (``load``, a synthetic pre-fill): derive the change bits from
         them and, for a sparse ring, the ``oldest`` / current tables."""
         self.recompute_mask()
+        self._reposition()
         if self.sparse:
             self._written, self._all_written, self._advance, self._advanced = [], False, None, [None, None]
             if self.len:
                 self.oldest.copy_(self.buf[self.start])
                 self.table.copy_(self.buf[(self.start + self.len - 1) % self.S])
             self.begin_slot()
+
+    def _reposition(self):
+        """The window was replaced from outside (checkpoint reload, ``EarlyStopping.load_pe``-style best-PE reload, a pre-fill): the
+        device-resident position follows the host's when the window is full; a shorter window goes back to host positions (the
+        device word only ever serves full, rotating windows: ``tick`` moves it by exactly one slot per iteration).  Whoever replays
+        captured iterations compares ``generation`` and captures again."""
+        self.generation += 1
+        if self.dev_start is not None:
+            if self.sparse and self.len == self.T:
+                self.dev_start.fill_(self.start)
+                self._dev_mirror = self.start
+            else:
+                self.dev_start, self._dev_mirror = None, 0
 
     def recompute_mask(self):
         """Change bits of the whole window from the stored rows; only meaningful while every slot of the window holds a full snapshot
@@ -453,16 +468,35 @@ class GraphedTrainStep:
         self.src, self.dst, self.eid, self.neg = i64(), i64(), i64(), i64()
         self.ts = torch.zeros(self.B, dtype=torch.float64, device=dev)
         self.graph, self.out = None, None
+        self.replays = 0          # graph launches that stood for an iteration, the capture's own first replay not counted
+        self.hyper = None         # the optimiser's scalars as they were baked into the captured Adam launch
+
+    def _hyper(self):
+        o = self.optimizer
+        return (o.lr, o.weight_decay, tuple(o.betas), o.eps)
+
+    def close(self):
+        """Give the captured graph back (destroyed at the next safe point); the next ``step`` captures again."""
+        from .model import drain_dead_graphs, retire_graph
+        if self.graph is not None:
+            retire_graph(self.graph)
+        self.graph, self.out = None, None
+        drain_dead_graphs()
 
     def step(self, batch_idx: int, src, dst, ts, eid, neg_dst):
         torch._foreach_copy_([self.src, self.dst, self.eid, self.neg], [src, dst, eid, neg_dst])
         self.ts.copy_(ts)
         eng = self.eng
         eng.__dict__.pop("_prefetched_group", None)        # the captured iteration groups its own batch
+        if self.graph is not None and self.hyper != self._hyper():
+            # lr / betas / eps / weight decay are launch constants of the captured Adam kernel: a schedule or a load_state_dict that changes
+            # them makes the captured iteration stale
+            self.close()
         if self.graph is None:
             self._capture(batch_idx)
         else:
             self.graph.replay()
+            self.replays += 1
             eng.ring.replay_tick()
         return self.out
 
@@ -473,8 +507,9 @@ class GraphedTrainStep:
         ring._advanced = [None, None]          # events of eager iterations must not be waited for inside the capture
         if ring.dev_start is None:
             ring.position_on_device()
-        from .model import _no_gc
-        graph = torch.cuda.CUDAGraph()
+        from .model import _no_gc, new_graph
+        graph = new_graph(self)
+        self.hyper = self._hyper()
         with _no_gc(), torch.cuda.graph(graph):
             with eng.aux_streams():
                 self.out = eng._train_iteration(self.optimizer, batch_idx, self.src, self.dst, self.ts, self.eid, self.neg, None, None)
@@ -513,6 +548,7 @@ class LstepEngine:
         self.use_step_graph = os.environ.get("LSTEP_STEP_GRAPH") == "1"
         self._graphed = {}                 # batch size -> GraphedTrainStep
         self._steady_eager_steps = 0       # eager training iterations run with a full window (they prime the capture)
+        self._ring_generation = 0          # ``HistoryRing.generation`` the captured iterations belong to
         # the engine joins the auxiliary stream before every optimiser step, so INSIDE its training iteration (``aux_streams``) the model
         # may put its weight-gradient products there; outside of it every backward() is self-contained on the caller's stream
         self.use_aux = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_AUX_STREAM") != "1"
@@ -520,6 +556,19 @@ class LstepEngine:
         if self.ring is not None and self.ring.sparse and self.use_aux:
             from .model import _aux_stream
             self.ring.advance_stream = _aux_stream(dev)    # idle between the weight gradients and the next weight composition
+
+    def close(self):
+        """Release every captured graph of this engine and of its model now (explicit graph lifetime, ``model.new_graph``): call it when
+        the engine is dropped while other models keep capturing, e.g. between test cases or when a trainer rebuilds its model.  The
+        engine stays usable: it captures again after two steady-state eager iterations."""
+        self.drop_captured_iterations()
+        self.backbone.close()
+
+    def drop_captured_iterations(self):
+        for gs in self._graphed.values():
+            gs.close()
+        self._graphed = {}
+        self._steady_eager_steps = 0
 
     @contextlib.contextmanager
     def aux_streams(self):
@@ -615,9 +664,17 @@ class LstepEngine:
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
         """``lookahead = (src, dst)`` of the next batch (optional): see ``prefetch_batch_nodes``.  The grouping made from them is used by
         the next call only if it receives the same (unmodified) tensors; otherwise it is recomputed."""
+        from .model import drain_dead_graphs
+        drain_dead_graphs()          # a safe point: nothing is capturing here (graphs of dropped models / closed engines die now)
+        if self.ring is not None and self._ring_generation != self.ring.generation:
+            # the history window was replaced from outside (``HistoryRing.load``): captured iterations belong to the old one
+            self.drop_captured_iterations()
+            self._ring_generation = self.ring.generation
         if self._graph_ready(optimizer, batch_idx):
             gs = self._graphed.get(src.numel())
             if gs is None or gs.optimizer is not optimizer:
+                if gs is not None:
+                    gs.close()
                 gs = self._graphed[src.numel()] = GraphedTrainStep(self, optimizer, src.numel())
             return gs.step(batch_idx, src, dst, ts, eid, neg_dst)
         if self.ring is not None and self.ring.sparse and self.ring.len == self.ring.T and batch_idx > 0:
@@ -675,7 +732,9 @@ class LstepEngine:
                 e_src = e_all[:n]
                 pe_loss = F.mse_loss(e_src, e_all[n:2 * n]) - self.neg_sample_weight * F.mse_loss(e_src, e_all[2 * n:])
                 loss = (1.0 - self.pe_weight) * lp_loss + self.pe_weight * pe_loss
-            out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
+            # ("embeddings": the [3 B, 176] rows of cat[src, dst, negative] the predictor read, columns >= 172 zero -- a view, for parity tests)
+            out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach(),
+                   "embeddings": emb_p.detach()}
         if lookahead is not None:
             self.prefetch_batch_nodes(*lookahead)
 

@@ -242,6 +242,15 @@ class _TailWeightsGraph:
     def _detached(self):
         return [p.detach() for p in self.params]
 
+    def close(self):
+        """Give the two captured graphs back (destroyed at the next safe point, ``drain_dead_graphs``); the object re-captures on its next use."""
+        for g in (self.g_fwd, self.g_bwd):
+            if g is not None:
+                retire_graph(g)
+        self.g_fwd = self.g_bwd = self.ptrs = self.prepared = None
+        self.__dict__.pop("outs", None), self.__dict__.pop("transposed", None), self.__dict__.pop("saved", None), self.__dict__.pop("pgrads", None)
+        drain_dead_graphs()
+
     def forward(self):
         if torch.cuda.is_current_stream_capturing():
             # the whole iteration is being captured (engine.GraphedTrainStep): no graph inside a graph, the ~25 launches are recorded
@@ -256,11 +265,15 @@ class _TailWeightsGraph:
             return outs, transposed
         ptrs = tuple(p.data_ptr() for p in self.params)
         if self.g_fwd is None or ptrs != self.ptrs:     # first use, or a parameter's storage was replaced: (re)capture
+            if self.g_bwd is not None:
+                retire_graph(self.g_bwd)
             self.ptrs, self.g_bwd = ptrs, None
             with torch.no_grad():
                 _tail_weights_forward(self.dims, *self._detached())   # warm-up outside the capture (library handles, workspaces)
                 torch.cuda.current_stream().synchronize()
-                self.g_fwd = torch.cuda.CUDAGraph()
+                if self.g_fwd is not None:
+                    retire_graph(self.g_fwd)
+                self.g_fwd = new_graph(self)
                 with _no_gc(), torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
                     self.outs, self.transposed, self.saved = _tail_weights_forward(self.dims, *self._detached())
         if self.prepared is not None:        # replayed ahead of time on the auxiliary stream (LSTEP.prepare_step): just wait for it
@@ -307,7 +320,7 @@ class _TailWeightsGraph:
                 keep = [g.clone() for g in self.gin]
                 _tail_weights_backward(*args)
                 torch.cuda.current_stream().synchronize()
-                self.g_bwd = torch.cuda.CUDAGraph()
+                self.g_bwd = new_graph(self)
                 with _no_gc(), torch.cuda.graph(self.g_bwd, capture_error_mode="thread_local"):
                     self.pgrads = _tail_weights_backward(*args)
                 for g, k in zip(self.gin, keep):
@@ -318,9 +331,8 @@ class _TailWeightsGraph:
 
 @contextlib.contextmanager
 def _no_gc():
-    """No cyclic garbage collection while a stream is capturing: a collection that happens to run inside the capture may destroy an
-    unrelated ``torch.cuda.CUDAGraph`` (an earlier model's) on the capturing thread, which the runtime refuses mid-capture and the
-    destructor turns into an abort (seen once in a long test session, in the autograd thread)."""
+    """No cyclic garbage collection while a stream is capturing (second line of defence; the first is ``new_graph`` below: no
+    ``torch.cuda.CUDAGraph`` of this package is ever destroyed by the collector or by a reference count reaching zero)."""
     was = gc.isenabled()
     gc.disable()
     try:
@@ -328,6 +340,48 @@ def _no_gc():
     finally:
         if was:
             gc.enable()
+
+
+# ---- explicit lifetime of captured graphs.  Destroying a ``torch.cuda.CUDAGraph`` is a HIP call the runtime refuses while a stream of the
+# calling thread is capturing, and its destructor turns the refusal into an abort.  Left to Python, the destruction happens wherever the
+# last reference dies: a dead model's graphs used to die inside whatever code the cyclic collector interrupted -- once, inside another
+# model's capture on the autograd thread (round 2, gpurun_out/t3.log).  So every graph this package captures is OWNED by the registry below;
+# its user only borrows it.  A graph is destroyed (``reset()``) in ``drain_dead_graphs`` alone, which runs at the package's safe points
+# (before a capture starts, at the start of an engine iteration, in ``close()``) and never while a stream is capturing.
+_GRAPH_REGISTRY = []      # [weak reference to the owner, graph, retired?]
+
+
+def new_graph(owner) -> "torch.cuda.CUDAGraph":
+    """A ``CUDAGraph`` whose lifetime is explicit: it lives until ``retire_graph`` / the death of ``owner`` AND the next drain."""
+    import weakref
+    drain_dead_graphs()
+    g = torch.cuda.CUDAGraph()
+    _GRAPH_REGISTRY.append([weakref.ref(owner), g, False])
+    return g
+
+
+def retire_graph(g):
+    """The owner is done with ``g`` (close(), re-capture): it is destroyed at the next safe point."""
+    for entry in _GRAPH_REGISTRY:
+        if entry[1] is g:
+            entry[2] = True
+
+
+def drain_dead_graphs() -> int:
+    """Destroy the graphs that were retired or whose owner is gone -- unless a capture is under way.  Returns how many were destroyed."""
+    if not _GRAPH_REGISTRY or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return 0
+    keep, dead = [], []
+    for entry in _GRAPH_REGISTRY:
+        (dead if (entry[2] or entry[0]() is None) else keep).append(entry)
+    _GRAPH_REGISTRY[:] = keep
+    for entry in dead:
+        entry[1].reset()
+    return len(dead)
+
+
+def live_graph_count() -> int:
+    return len(_GRAPH_REGISTRY)
 
 
 class _LiveToken:
@@ -1079,6 +1133,13 @@ class LSTEP(nn.Module):
         self.pe_neighbor_mlp_2 = nn.Linear(pe_dim, pe_dim)
         self.out_node_emb = nn.Linear(pe_dim + node_feat_dim, node_feat_dim)
         self.to(self.device)
+
+    def close(self):
+        """Release the captured weight-composition graphs now (they are re-captured on the next use).  Optional: a model that is simply
+        dropped gives them back at the package's next safe point (``drain_dead_graphs``)."""
+        tw = self.__dict__.pop("_tail_weight_graph", None)
+        if tw is not None:
+            tw.close()
 
     # ---- sampler handling (models/LSTEP.py:76-85)
     def set_neighbor_sampler(self, neighbor_sampler):

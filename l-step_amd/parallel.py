@@ -244,6 +244,7 @@ class ShardedSparseRing(HistoryRing):
 
     def adopt_full_slots(self):
         self.recompute_mask()
+        self._reposition()
         self._written, self._all_written, self._advance, self._advanced = [], False, None, [None, None]
         if self.len:
             self.oldest.copy_(self.buf[self.start])

@@ -324,9 +324,18 @@ def gen_traces_long():
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     state = protocol.ProtocolState(history=torch.zeros(g["num_nodes"] + 1, 0, synth.PE_DIM), initial_pe=torch.from_numpy(pe0.copy()))
+    # distance of the step's pre-activations from the relu kinks (edge channel models/LSTEP.py:164-166, neighbourhood PE :241-242, predictor
+    # models/modules.py:66): a value within float32 rounding of 0 makes the reference's OWN gradient a coin toss (relu'(0-) = 0, relu'(0+) = 1),
+    # and the whole contribution of that row to the layers in front of the relu flips with it.  The tests hold a step's gradients to the
+    # tight bar only when the reference is not sitting on a kink.
+    kink = []
+    hook = lambda mod, inp, out: kink.append(float(out.detach().abs().min()))  # noqa: E731
+    for m in (model[0].edge_agg, model[0].pe_neighbor_mlp_1, model[1].fc1):
+        m.register_forward_hook(hook)
     for b in range(LONG_BATCHES):
         sl = slice(TRACE_START + b * TRACE_B, TRACE_START + (b + 1) * TRACE_B)
         neg = synth.make_negatives(g["num_nodes"], TRACE_B, seed=500 + b)
+        kink.clear()
         res = protocol.train_iteration(model[0], model[1], opt, state, b, g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl], neg,
                                        TRACE_K, TRACE_G, TRACE_T)
         out[f"b{b}/snapshot"] = state.history[:, -1, :].numpy().copy()
@@ -334,6 +343,7 @@ def gen_traces_long():
             continue
         out[f"b{b}/losses"] = np.asarray([res["lp_loss"], res["pe_loss"], res["loss"]])
         out[f"b{b}/predicts"] = res["predicts"]
+        out[f"b{b}/kink_distance"] = np.asarray([min(kink)])
         for k, p in model.named_parameters():
             if p.grad is None:
                 continue

@@ -379,3 +379,183 @@ def test_c4_bench_workload_vs_oracle(hip, monkeypatch):
     _parity(got_t, ref_t, 5e-5, "c4 update_pe", f64)
     changed = float((np.abs(got_t - pe_cpu.numpy()).max(axis=1) > 0).mean())
     assert 0.1 < changed < 0.6, f"update_pe should touch roughly a quarter of the table at this shape, got {changed:.2f}"
+
+
+# ------------------------------------------------------------------------------------------------ the ENGINE at c3 / c4, step by step
+def _engine_state(eng, bn_dev):
+    """What one training iteration reads of the engine's state, on the CPU: the history window of the batch nodes [U, T, P] (all the
+    FFT splice touches) and the newest snapshot [N+1, P]."""
+    torch.cuda.synchronize()
+    rows = torch.stack([snap[bn_dev] for snap in eng.ring.snapshots()], dim=1)
+    return rows.cpu(), eng.ring.last().cpu()
+
+
+def _engine_steps_vs_oracle(hip_model, eng, om, stream, arrays, first, B, K, G, N, steps, full_steps, sample_edges, tag, min_padded,
+                            yardstick_every_step=True):
+    """``steps`` CONSECUTIVE ``eng.train_iteration`` calls (look-ahead grouping, three streams, fused loss, update_pe_device, one-launch
+    Adam; with ``eng.use_step_graph`` the first two run launch by launch, the third is captured, the rest are replays of the captured
+    HIP graph), each held to the oracle ONE STEP AT A TIME: before every iteration the oracle is handed what the engine itself holds
+    (the history window of the batch nodes, the newest snapshot, the current weights), then both run the batch
+    (train_LSTEP_link_prediction.py:204-311) and are compared: the embeddings and link probabilities of a sample of edges (every edge
+    in ``full_steps``, where the oracle affords the whole batch in row chunks and the three losses and every parameter gradient are
+    compared too) and the WHOLE table update_pe left behind -- every node row at 5e-5, the padding row 0 by the float64 yardstick
+    (``_parity``).  One-step parity from the engine's own state for k consecutive steps covers its state evolution without letting the
+    ill-conditioned row 0 (or Adam's amplification of rounding noise) decide the comparison two steps later.
+
+    What the padding row does downstream: the sample contains at least ``min_padded`` rows with padded neighbour slots, which read the
+    live row 0 (models/LSTEP.py:233, ``gather.hip``); their embeddings must meet the same 5e-5 (the oracle reads the engine's row 0),
+    and the effect of row 0's own uncertainty is measured: the same rows re-evaluated by the oracle with row 0 replaced by the
+    fp32 oracle's and by the float64 value of the previous step (``yardstick_every_step``; otherwise the float64 update -- two dense
+    [N+1, 272] float64 scatters, ~10 s at N = 1 M -- only runs when row 0 misses the fp32 bar).  Returns the printed numbers."""
+    import time
+    from helpers import oracle_train_step_chunked
+    from lstep_amd.optim import FusedAdam
+    from oracle.lstep_oracle import float64_yardstick
+    src_a, dst_a, ts_a, eid_a = arrays
+    opt = FusedAdam(hip_model.parameters(), lr=1e-4)
+    hip_model.train(), om.train()
+    scale, report = {}, []
+    prev_row0 = None       # (fp32 oracle's, float64) padding row produced by the previous step's update_pe
+    for k in range(steps):
+        lo = first + k * B
+        sl = slice(lo, lo + B)
+        src, dst, ts, eid = src_a[sl], dst_a[sl], ts_a[sl], eid_a[sl]
+        neg = synth.make_negatives(N, B, seed=7000 + k)
+        bn = protocol.unique_batch_nodes(src, dst)
+        om.load_state_dict({kk: v.detach().cpu() for kk, v in hip_model.state_dict().items()})
+        window_rows, last = _engine_state(eng, torch.from_numpy(bn).to(DEV))
+        nxt = stream.batch(lo + B, lo + 2 * B)[:2]
+        rh = eng.train_iteration(opt, 1000 + k, *stream.batch(lo, lo + B), torch.from_numpy(neg).to(DEV), lookahead=nxt)
+        torch.cuda.synchronize()
+        gs = eng._graphed.get(B)
+        mode = "launch by launch" if gs is None else ("captured" if gs.replays == 0 or k == 2 else "graph replay")
+        full = k in full_steps
+        # the sample: ``sample_edges`` edges, those whose rows have padded slots first
+        cnt = np.stack([eng.backbone.neighbor_sampler.get_historical_neighbors(ids, ts, K)[0] for ids in (src, dst, neg)])      # [3, B, K]
+        padded_rows = (cnt == 0).any(axis=2)                                                                                # [3, B]
+        pad_edges = np.nonzero(padded_rows.any(axis=0))[0]
+        rng = np.random.RandomState(8000 + k)
+        take = list(rng.permutation(pad_edges)[:sample_edges // 2])
+        rest = np.setdiff1d(np.arange(B), np.asarray(take, dtype=np.int64))
+        take += list(rng.permutation(rest)[:sample_edges - len(take)])
+        take = np.sort(np.asarray(take, dtype=np.int64))
+        want = np.concatenate([take, B + take, 2 * B + take])
+        t_or = time.perf_counter()
+        ro = oracle_train_step_chunked(om, window_rows, last, bn, 1000 + k, src, dst, ts, eid, neg, K, G, chunk=256, want_emb=want,
+                                       edges=None if full else take)
+        t_or = time.perf_counter() - t_or
+        # embeddings and link probabilities of the sample
+        emb_h = rh["embeddings"][:, :synth.FEAT_DIM][torch.from_numpy(want).to(DEV)].cpu().numpy()
+        emb_o = np.stack([ro["emb"][int(i)] for i in want])
+        d_emb = np.abs(emb_h - emb_o).max(axis=1)
+        is_pad = padded_rows.reshape(-1)[want]
+        n_pad = int(is_pad.sum())
+        assert n_pad >= min_padded, f"{tag} step {k}: only {n_pad} sampled rows have padded neighbour slots"
+        assert d_emb.max() <= 5e-5, f"{tag} step {k} ({mode}): embeddings differ by {d_emb.max():.3e} (rows with padded slots: {d_emb[is_pad].max():.3e})"
+        ph = rh["predicts"].cpu().numpy()
+        sel = np.concatenate([take, B + take]) if not full else np.arange(2 * B)
+        np.testing.assert_allclose(ph[sel], ro["predicts"][sel], err_msg=f"{tag} step {k} ({mode}): link probabilities", **TOL)
+        line = f"{tag} step {k} ({mode}{', full batch' if full else ''}): embeddings {d_emb.max():.2e} ({n_pad} rows with padded slots: {d_emb[is_pad].max():.2e})"
+        if full:
+            got_l = [float(rh["lp_loss"]), float(rh["pe_loss"]), float(rh["loss"])]
+            np.testing.assert_allclose(got_l, [ro["lp_loss"], ro["pe_loss"], ro["loss"]], rtol=0, atol=2e-5, err_msg=f"{tag} step {k} ({mode}): losses")
+            _compare_grads(om, hip_model, 3e-5, f"{tag} step {k} ({mode})")
+            line += ", losses + every parameter gradient checked"
+        # the state transition: the whole table; row 0 by the float64 yardstick (the same update applied to the same spliced table)
+        got_t = eng.ring.last().cpu().numpy()
+        ref_t = ro["table"].numpy()
+        row0_64 = None
+        if yardstick_every_step or float(np.abs(got_t[0] - ref_t[0]).max()) > 5e-5:
+            with torch.no_grad():
+                row0_64 = float64_yardstick(om, tables=False)[0].update_pe(ro["spliced"].double(), bn, eid, src, dst, ts, ts.max(), num_neighbors=K,
+                                                                           time_gap=G)[0].numpy().copy()
+        _parity(got_t, ref_t, 5e-5, f"{tag} step {k} ({mode}): table after update_pe", row0_64, scale)
+        d_rows = float(np.abs(got_t[1:] - ref_t[1:]).max())
+        line += f"; table rows {d_rows:.2e}; row 0 vs fp32 oracle {float(np.abs(got_t[0] - ref_t[0]).max()):.2e}"
+        if row0_64 is not None:
+            line += f", vs float64: hip {float(np.abs(got_t[0] - row0_64).max()):.2e}, fp32 oracle {float(np.abs(ref_t[0] - row0_64).max()):.2e}"
+        line += f" [oracle {t_or:.0f} s]"
+        # what row 0's uncertainty does to the embeddings of the rows that read it
+        if prev_row0 is not None and prev_row0[1] is not None and n_pad:
+            rows_pad = want[is_pad][:48]
+            ids_all, ts_all = np.concatenate([src, dst, neg]), np.concatenate([ts, ts, ts])
+            outs = []
+            with torch.no_grad():
+                for r0 in (None, prev_row0[0], prev_row0[1]):
+                    tab = ro["spliced"].clone()
+                    if r0 is not None:
+                        tab[0] = torch.from_numpy(np.asarray(r0, dtype=np.float32))
+                    outs.append(om[0].combining_pe_raw_feat(tab, ids_all[rows_pad], ts_all[rows_pad], K, G).numpy())
+            hip_gap = float(np.abs(emb_h[is_pad][:48] - outs[2]).max())        # engine's embeddings vs the oracle reading the float64 row 0
+            ref_gap = float(np.abs(outs[1] - outs[2]).max())                   # the fp32 oracle reading ITS OWN row 0 vs the float64 row 0
+            assert hip_gap <= 2 * ref_gap + 1e-4, \
+                f"{tag} step {k}: rows with padded slots are {hip_gap:.3e} from the float64-row-0 embeddings, the fp32 reference order only {ref_gap:.3e}"
+            line += f"; embeddings of padded rows vs float64 row 0: hip {hip_gap:.2e}, fp32 reference order {ref_gap:.2e}"
+        prev_row0 = (ref_t[0].copy(), row0_64)
+        report.append(line)
+        print(line)
+    return report
+
+
+def test_c3_engine_training_iterations_step_by_step_vs_oracle(hip):
+    """Reddit-shaped c3 (10 984 nodes / 672 447 edges, B = 4096, K = 32, time_gap 2000, T = 100): the device ENGINE, eager and graph-replayed,
+    against the oracle over five consecutive training iterations a quarter into the stream (mean degree ~ K: thousands of rows with padded
+    slots reading the live padding row).  Window: T random snapshots, slid by three evaluation batches first (rotated ring, lagging
+    ``oldest`` table, sparse change mask).  See ``_engine_steps_vs_oracle``."""
+    N, E, B, K, T, G = 10_984, 672_447, 4096, 32, 100, 2000
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=403)
+    node_raw, edge_raw = synth.make_features(N, E, seed=404)
+    sd = synth.make_state_dict(K, T, seed=406)
+    om, _ = _oracle(g, node_raw, edge_raw, K, T, sd)
+    hm = hip.build(node_raw, edge_raw, hip.NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N, device=DEV), K, T, sd, DEV)
+    eng = hip.LstepEngine(hm[0], hm[1], K, G)
+    eng.use_step_graph = True
+    stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(407)
+    eng.ring.load(0.1 * torch.randn((N + 1, T, synth.PE_DIM), generator=gen, device=DEV))
+    first = E // 4
+    hm.eval()
+    with torch.no_grad():
+        for j in range(3):
+            lo = first + j * B
+            neg = synth.make_negatives(N, 2 * B, seed=j)
+            eng.eval_iteration(j + 1, *stream.batch(lo, lo + B), torch.from_numpy(neg[:B]).to(DEV), torch.from_numpy(neg[B:]).to(DEV))
+    assert eng.ring.start == 3 and eng.ring.len == T
+    report = _engine_steps_vs_oracle(hm, eng, om, stream, (g["src"], g["dst"], g["ts"], g["eid"]), first + 3 * B, B, K, G, N, steps=5,
+                                     full_steps=(1, 3), sample_edges=96, tag="c3 engine", min_padded=32)
+    gs = eng._graphed.get(B)
+    assert gs is not None and gs.replays == 2, "steps 0-1 launch by launch, step 2 captured, steps 3-4 replayed"
+    assert len(report) == 5
+    eng.close()
+
+
+def test_c4_engine_training_iterations_step_by_step_vs_oracle(hip):
+    """The bench workload (1 M nodes / 20 M edges, B = 16384, K = 20, time_gap 2000, T = 100; history evolved by bench.py's own pre-roll):
+    four consecutive ``eng.train_iteration`` calls exactly as bench.py issues them (look-ahead grouping, FusedAdam, ``use_step_graph``:
+    two launch by launch, one captured, one replayed) against the oracle, one step at a time from the engine's own state.  Every step: a
+    sample of 64 edges (192 embedding rows, half of them with padded slots -- mid-stream the mean degree equals K), their link
+    probabilities, and all 1 000 001 rows of the table update_pe left behind; the replayed step also the three losses and every
+    parameter gradient of the whole 16 384-edge batch (the oracle in 64 row chunks)."""
+    from lstep_amd.workload import build_workload, evolve_history
+    from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * 2 ** 30:
+        pytest.skip("needs ~100 GB of HBM (the 70 GB history ring + the 13.8 GB edge table)")
+    wl = build_workload("synth-1M-20M", DEV, seed=0)
+    N, E, B, K, G, T = wl.num_nodes, wl.num_edges, wl.batch, wl.K, wl.G, wl.T
+    eng, hm = wl.engine, wl.model
+    eng.use_step_graph = True
+    start = E // 2
+    hm.eval()
+    assert evolve_history(eng, wl.stream, start, B, N) == T
+    arrays = tuple(a.cpu().numpy() for a in (wl.stream.src, wl.stream.dst, wl.stream.ts, wl.stream.eid))
+    osamp = OracleNeighborSampler(*(arrays[i] for i in (0, 1, 3, 2)), num_nodes=N)
+    sd = {k: v.detach().cpu().numpy() for k, v in hm.state_dict().items()}
+    om = build_oracle_model(hm[0].node_raw_features.cpu().numpy(), hm[0].edge_raw_features.cpu().numpy(), osamp, K, T, sd)
+    report = _engine_steps_vs_oracle(hm, eng, om, wl.stream, arrays, start, B, K, G, N, steps=4, full_steps=(3,), sample_edges=64,
+                                     tag="c4 engine", min_padded=32, yardstick_every_step=False)
+    gs = eng._graphed.get(B)
+    assert gs is not None and gs.replays == 1
+    assert len(report) == 4
+    eng.close()

@@ -248,3 +248,50 @@ def test_initial_positional_encodings_properties():
         q = q @ p
         assert np.allclose(rw[:, i].numpy(), np.diag(q), atol=1e-6)
     assert rw.dtype == torch.float32 and float(rw[deg == 0].abs().max()) == 0.0
+
+
+def test_chunked_oracle_training_step_equals_the_protocol_iteration():
+    """tests/helpers.py::oracle_train_step_chunked (the form in which the -m gpu tests afford the oracle's full-batch losses and
+    gradients at B = 4096 / 16384) against ``protocol.train_iteration`` (the reference's loop body) on the same state: losses,
+    probabilities, every parameter gradient and the table update_pe leaves behind, for a chunk size that does not divide the batch."""
+    from helpers import oracle_train_step_chunked
+    from lstep_amd import protocol
+    N, E, B, K, T, G = 50, 1500, 40, 5, 4, 2000
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=61)
+    node_raw, edge_raw = synth.make_features(N, E, seed=62)
+    sd = synth.make_state_dict(K, T, seed=63)
+    hist = torch.from_numpy((0.1 * np.random.RandomState(64).standard_normal((N + 1, T, synth.PE_DIM))).astype(np.float32))
+    hist[0, -1] = 0.01                  # a live padding row
+    sl = slice(300, 300 + B)            # early: many padded neighbour slots
+    src, dst, ts, eid = g["src"][sl], g["dst"][sl], g["ts"][sl], g["eid"][sl]
+    neg = synth.make_negatives(N, B, seed=65)
+    out = []
+    for chunked in (False, True):
+        om = build_oracle_model(node_raw, edge_raw, OracleNeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N), K, T, sd)
+        om.train()
+        if not chunked:
+            opt = torch.optim.SGD(om.parameters(), lr=0.0)       # the iteration steps its optimiser: keep the weights where they are
+            st = protocol.ProtocolState(history=hist.clone())
+            res = protocol.train_iteration(om[0], om[1], opt, st, 9, src, dst, ts, eid, neg, K, G, T)
+            res["table"] = st.history[:, -1, :]
+        else:
+            bn = protocol.unique_batch_nodes(src, dst)
+            res = oracle_train_step_chunked(om, hist[torch.from_numpy(bn)], hist[:, -1, :].clone(), bn, 9, src, dst, ts, eid, neg, K, G, chunk=16,
+                                            want_emb=[0, B + 3, 2 * B + 39])
+            assert sorted(res["emb"]) == [0, B + 3, 2 * B + 39]
+            with torch.no_grad():
+                e = om[0].combining_pe_raw_feat(res["spliced"], dst[3:5], ts[3:5], K, G)[0].numpy()     # (two rows: the reference's squeeze() breaks B == 1)
+            np.testing.assert_allclose(res["emb"][B + 3], e, rtol=0, atol=1e-6)
+        out.append((res, {k: (None if p.grad is None else p.grad.clone()) for k, p in om.named_parameters()}))
+    (ra, ga), (rb, gb) = out
+    for k in ("lp_loss", "pe_loss", "loss"):
+        assert abs(ra[k] - rb[k]) < 2e-6, k
+    np.testing.assert_allclose(rb["predicts"], ra["predicts"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rb["table"].numpy(), ra["table"].numpy(), rtol=0, atol=1e-6)
+    for k in ga:
+        if ga[k] is None:
+            assert gb[k] is None or float(gb[k].abs().max()) == 0.0, k
+            continue
+        a, b = ga[k], gb[k]
+        d = float((torch.view_as_real(a - b) if a.is_complex() else (a - b)).abs().max())
+        assert d <= 2e-6 * max(1.0, float(a.abs().max())), (k, d)
