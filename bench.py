@@ -204,15 +204,29 @@ def main():
         from lstep_amd.workload import evolve_history
         prerolled = evolve_history(runner, wl.stream, start - prime * B * world, B * world, wl.num_nodes)
 
+    negatives = {}
+
+    def draw(i):
+        """Negative destinations (and sources, evaluation) of step i, drawn in step order from ONE generator -- one step ahead of their
+        use, so that the multi-GPU engine can request the rows of the next gather while the current step runs (``parallel.RowPull``)."""
+        if i not in negatives:
+            assert not negatives or i == max(negatives) + 1
+            neg = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
+            neg_src = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev) if args.mode == "eval" else None
+            negatives[i] = (neg, neg_src)
+        return negatives[i]
+
     def step(i):
         lo = start + i * B * world
         src, dst, ts, eid = wl.stream.batch(lo, lo + B * world)
-        neg = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
+        neg, neg_src = draw(i)
+        negatives.pop(i - 1, None)
         nxt = None
         if lo + 2 * B * world <= wl.num_edges:     # the edge stream is known ahead: let the engine group the next batch's endpoints early
-            nxt = wl.stream.batch(lo + B * world, lo + 2 * B * world)[:2]
+            s2, d2, t2, _ = wl.stream.batch(lo + B * world, lo + 2 * B * world)
+            n2, ns2 = draw(i + 1)
+            nxt = (s2, d2, t2, ns2, n2) if args.mode == "eval" else (s2, d2, t2, n2)
         if args.mode == "eval":
-            neg_src = torch.randint(1, wl.num_nodes + 1, (B * world,), generator=gen, device=dev)
             with torch.no_grad():
                 return runner.eval_iteration(1000 + i, src, dst, ts, eid, neg_src, neg, lookahead=nxt)
         return runner.train_iteration(opt, 1000 + i, src, dst, ts, eid, neg, lookahead=nxt)
@@ -315,8 +329,12 @@ def main():
                        "parallelism": ((f"x{world}: PE history ring and FFT filter sharded by node owner (id % {world}), RCCL all-gather of the "
                                         f"filtered rows / reduce-scatter of their gradient; gather, dense tail and loss on each rank's {B}-edge "
                                         f"slice of the global batch; update_pe " +
-                                        ("replicated on the global batch (no update collective)" if getattr(runner, "replicated", False)
-                                         else "sharded by owner with RCCL all-gather of the updated PE rows")) if use_dist else "single GPU")},
+                                        {"replicate": "replicated on the global batch (no update collective)",
+                                         "allgather": "sharded by owner with RCCL all-gather of every updated PE row into replicated tables",
+                                         "pull": "and the PE table sharded by owner: RCCL all-gather of the batch nodes' updated rows, all-to-all pull of the "
+                                                 "rows the next gather reads (requested one step ahead)"}[getattr(runner, "form", "replicate")])
+                                       if use_dist else "single GPU"),
+                       "update_form": getattr(runner, "form", None)},
             "roofline": {"bound": "hbm", "kernel": GATHER_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": avg_ms, "launch_timing": timing_note, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),

@@ -662,7 +662,7 @@ class LstepEngine:
 
     # ---- train:204-311
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
-        """``lookahead = (src, dst)`` of the next batch (optional): see ``prefetch_batch_nodes``.  The grouping made from them is used by
+        """``lookahead = (src, dst[, ts, neg_dst])`` of the next batch (optional): see ``prefetch_batch_nodes``.  The grouping made from them is used by
         the next call only if it receives the same (unmodified) tensors; otherwise it is recomputed."""
         from .model import drain_dead_graphs
         drain_dead_graphs()          # a safe point: nothing is capturing here (graphs of dropped models / closed engines die now)
@@ -736,7 +736,7 @@ class LstepEngine:
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach(),
                    "embeddings": emb_p.detach()}
         if lookahead is not None:
-            self.prefetch_batch_nodes(*lookahead)
+            self.prefetch_batch_nodes(*lookahead[:2])      # (a longer tuple also names the next batch's times / negatives: lstep_amd.parallel)
 
         def update_and_append():
             if on_device:
@@ -838,7 +838,7 @@ class LstepEngine:
             predicts = torch.cat([self._probabilities(emb[:n], emb[n:2 * n]), self._probabilities(emb[2 * n:3 * n], emb[3 * n:])], dim=0)
         labels = self._labels(n)
         if lookahead is not None:
-            self.prefetch_batch_nodes(*lookahead)
+            self.prefetch_batch_nodes(*lookahead[:2])      # (a longer tuple also names the next batch's times / negatives: lstep_amd.parallel)
         if on_device:
             base, ref = ring.building_ref()
             bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written,

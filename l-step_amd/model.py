@@ -1662,7 +1662,7 @@ class LSTEP(nn.Module):
 
     @torch.no_grad()
     def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None, mirror_ring=None,
-                         mirror_shard=(1, 0)):
+                         mirror_shard=(1, 0), owner=None, owned_idx=None, after_phase1=None):
         """``update_pe`` for the engine, with every data-dependent size left on the device: no host synchronisation, no second host
         thread, a fixed launch sequence.
 
@@ -1673,11 +1673,19 @@ class LSTEP(nn.Module):
         K * pe[0] = 0 (pe[0] is zeroed first, models/LSTEP.py:317).  What does depend on the exact count reads it on the device:
         ``lstep_update_rows`` (which rows to write), ``lstep_segment_rows_sum`` (how many grouped slots are real) and the decision
         whether row 0 takes part in phase 2 at all (``lstep_update_entries_p2_dev``).  ``mirror_ring`` (``lstep_ring_ref_t*``): ``mirror``
-        is the base of the history ring and the slot that receives the new rows is picked on the device."""
+        is the base of the history ring and the slot that receives the new rows is picked on the device.
+
+        OWNER-COMPUTES form (``lstep_amd.parallel``, one process per GPU): ``owner = (W, r)`` -- this rank computes only the rows with
+        id % W == r.  Phase 1: the message sums of all batch nodes are formed (two rows per batch edge, every rank has the inputs), the MLP
+        and the write run for the batch nodes at positions ``owned_idx`` of ``bn`` (int64, sized on the host by the caller);
+        ``after_phase1(ids)`` then exchanges the new rows so that ``pe[bn]`` holds every batch node's phase-1 value on every rank
+        (phase 2's messages carry them).  Phase 2: the sampled slots whose NEIGHBOUR this rank owns are grouped and summed, only those
+        rows go through the MLP; row 0 belongs to rank 0.  Everything stays device-sized."""
         lib = nat.load_library()
         dev, P, K = pe.device, self.pe_dim, int(num_neighbors)
         cap = bn.numel()
         rows = pe.shape[0]
+        world, rank = (int(owner[0]), int(owner[1])) if owner is not None else (1, 0)
         now32 = t.max().to(torch.float32).reshape(1)          # torch.Tensor([current_time]) of models/LSTEP.py:277: float32-rounded
         order32, seg32 = presorted
         n2 = order32.numel()
@@ -1688,16 +1696,25 @@ class LSTEP(nn.Module):
             nat.check(lib.lstep_update_entries_p1(nat.ptr(order32), n2, nat.ptr(src), nat.ptr(dst), nat.ptr(t), nat.ptr(now32), src.numel(),
                                                   nat.ptr(ent_row), nat.ptr(ent_dt), nat.current_stream()))
         agg = self._segment_sum(pe, cap, seg32, ent_row, ent_dt, exact=True)
-        self._update_rows(pe, bn, agg, with_self=True, mirror=mirror, live=n_live, ring=mirror_ring, mirror_shard=mirror_shard)
-        if changed is not None:
-            changed(bn, mirror is not None)       # (the dead tail marks row 0, which every update_pe rewrites anyway)
+        if owner is None:
+            self._update_rows(pe, bn, agg, with_self=True, mirror=mirror, live=n_live, ring=mirror_ring, mirror_shard=mirror_shard)
+            if changed is not None:
+                changed(bn, mirror is not None)       # (the dead tail marks row 0, which every update_pe rewrites anyway)
+        else:
+            ids1 = bn.index_select(0, owned_idx)
+            if ids1.numel():
+                self._update_rows(pe, ids1, agg.index_select(0, owned_idx), with_self=True, mirror=mirror, ring=mirror_ring, mirror_shard=mirror_shard)
+            if changed is not None:
+                changed(ids1, mirror is not None)
+            if after_phase1 is not None:
+                after_phase1(ids1)
         # ---- phase 2 (LSTEP.py:305-339): row i of bn is zipped with the i-th EDGE time, rows >= min(U, B) stay padding
         nbr, _, nt = self.neighbor_sampler.sample_device(bn, t, K)
         n = nbr.numel()
         pe[0].zero_()
         keys32 = torch.empty(n, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            nat.check(lib.lstep_update_keys_p2(nat.ptr(nbr), n, rows, 1, 0, nat.ptr(keys32), nat.current_stream()))
+            nat.check(lib.lstep_update_keys_p2(nat.ptr(nbr), n, rows, world, rank, nat.ptr(keys32), nat.current_stream()))
         _, order, seg, uniq, summary = nat.group_by_key(keys32, max(1, int(rows + 1).bit_length()), rows, wait=None)
         tcap = min(n, rows) + 1                                # row 0's reserved segment + at most one per slot / per table row
         ent_row = torch.empty(n, dtype=torch.int32, device=dev)
@@ -1710,10 +1727,19 @@ class LSTEP(nn.Module):
         premul = (os.environ.get("LSTEP_UPDATE_NO_PREMUL") != "1" and self.ld_pe == P + self.time_dim and self.ld_self == 176
                   and self.time_dim <= 112 and self.time_dim % 4 == 0)
         with torch.cuda.device(dev):
+            # (owner-computes: the row-0 flag compares live_rows * K with the number of REAL slots; with the other owners' slots dropped
+            # from the grouping it would always read "padding present" -- rank 0 takes the flag from a second, unfiltered count below)
             nat.check(lib.lstep_update_entries_p2_dev(nat.ptr(order), nat.ptr(seg), nat.ptr(summary), nat.ptr(n_live), n, tcap,
                                                       None if premul else nat.ptr(bn), nat.ptr(nt), nat.ptr(now32), K, nat.ptr(uniq),
                                                       nat.ptr(ent_row), nat.ptr(ent_dt), nat.ptr(ent_seg), nat.ptr(touched), nat.ptr(counts),
                                                       nat.current_stream()))
+        row0_live = counts[1:2]
+        if owner is not None:
+            if rank != 0:
+                row0_live = torch.zeros(1, dtype=torch.int32, device=dev)          # row 0 belongs to rank 0
+            else:       # does any slot of a LIVE row hold the padding id?  (models/LSTEP.py:324: 0 in unique(neighbour ids))
+                live_slots = (torch.arange(cap, device=dev) < n_live).unsqueeze(1) & (nbr == 0)
+                row0_live = live_slots.any().to(torch.int32).reshape(1)
         if premul:
             D, Pp = self.time_dim, self.ld_self
             w1a_t, w1b, b1, w2, b2 = self._update_weights_pre()
@@ -1724,11 +1750,12 @@ class LSTEP(nn.Module):
                                                      nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), n, nat.ptr(agg2), Pp + D, 2,
                                                      nat.ptr(summary[1:2]), nat.current_stream()))
             agg2[0].zero_()
-            part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), Pp), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, None, cap, nat.ptr(y), Pp, Pp, nat.ptr(part), nat.current_stream()))
-            agg2[0, :Pp] = part.sum(dim=0)
-            for ids_, agg_, live_ in ((touched[1:], agg2[1:], counts[0:1]), (touched[:1], agg2[:1], counts[1:2])):
+            if rank == 0:
+                part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), Pp), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, None, cap, nat.ptr(y), Pp, Pp, nat.ptr(part), nat.current_stream()))
+                agg2[0, :Pp] = part.sum(dim=0)
+            for ids_, agg_, live_ in ((touched[1:], agg2[1:], counts[0:1]), (touched[:1], agg2[:1], row0_live)):
                 with torch.cuda.device(dev):
                     nat.check(lib.lstep_update_rows_pre(nat.ptr(agg_), int(agg_.stride(0)), nat.ptr(ids_), ids_.numel(), nat.ptr(w1b), nat.ptr(b1),
                                                         nat.ptr(w2), nat.ptr(b2), nat.ptr(pe), nat.ptr(mirror), P, D, nat.ptr(live_), mirror_ring,
@@ -1740,13 +1767,14 @@ class LSTEP(nn.Module):
         # row 0 collects cat[pe[source], 0] from every padded slot: segment 0 has no entries of its own, its aggregate is the sum over
         # the rows of (their number of padded slots) * pe[source row]
         agg2[0].zero_()
-        part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), P), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, nat.ptr(bn), cap, nat.ptr(pe), P, int(pe.stride(0)), nat.ptr(part),
-                                                 nat.current_stream()))
-        agg2[0, :P] = part.sum(dim=0)
+        if rank == 0:
+            part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), P), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, nat.ptr(bn), cap, nat.ptr(pe), P, int(pe.stride(0)), nat.ptr(part),
+                                                     nat.current_stream()))
+            agg2[0, :P] = part.sum(dim=0)
         self._update_rows(pe, touched[1:], agg2[1:], with_self=False, mirror=mirror, live=counts[0:1], ring=mirror_ring, mirror_shard=mirror_shard)
-        self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=counts[1:2], ring=mirror_ring, mirror_shard=mirror_shard)
+        self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=row0_live, ring=mirror_ring, mirror_shard=mirror_shard)
         if changed is not None:
             changed(touched, mirror is not None)
         return pe

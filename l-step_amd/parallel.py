@@ -13,10 +13,18 @@ cooperate on ONE global batch of ``W * B`` edges at a time (weak scaling: B per 
               global batch, i.e. the mean of the rank means.
   backward    gradients w.r.t. the spliced rows are REDUCE-SCATTERED by owner, each rank back-propagates its owned rows through its
               history shard into the filter coefficients; parameter gradients are ALL-REDUCED (one flat bucket, 2.3 MB).
-  update_pe   both phases are sharded by the owner of the UPDATED row (phase 1: batch nodes; phase 2: touched
-              neighbours); the new rows are ALL-GATHERED ("updated positional encodings at snapshot boundaries",
-              BASELINE.json north_star) and applied on every replica; each rank appends its owned rows to its ring.
-              The phase-2 gather (the largest message) is asynchronous and overlaps the backward pass.
+  update_pe   three forms (``DistributedLstep.form``, LSTEP_PHASE2):
+              "pull"      OWNER-SHARDED PE TABLE.  A rank is authoritative for the rows it owns only; both phases are computed by the
+                          owner of the UPDATED row (phase 1: batch nodes, their new rows ALL-GATHERED -- "updated positional encodings
+                          at snapshot boundaries", BASELINE.json north_star -- because phase 2's messages carry them; phase 2: touched
+                          neighbours, nothing sent).  Before its next gather a rank PULLS the rows that gather will read and it does
+                          not own (its 3 B rows, their K most recent neighbours, row 0: ~23 % of a 4 M-node table) from their owners:
+                          an all-to-all-v whose requests are computed one step ahead from the look-ahead batch, so the rows travel
+                          underneath the backward pass on a communicator of their own (``RowPull``).  Per-rank bytes and update
+                          FLOPs are flat in W: the form for W = 8.  The full-size table of a rank is a CACHE outside its owned rows.
+              "replicate" every rank recomputes update_pe for the whole global batch on a replicated table: no update collective, but
+                          work that grows with W (default up to W = 4).
+              "allgather" owner-computes with an all-gather of ALL updated rows into replicated tables (round 1's form; kept for A/B).
 
 All collectives are small-to-medium one-shot gathers/reductions (no ring-pipelined bulk transfer is needed); the data
 path itself (gathers, GEMMs) has no collective inside.  Results equal the single-GPU engine on the same global batch up
@@ -24,6 +32,7 @@ to fp32 summation order (``tests/test_parallel.py``).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import numpy as np
@@ -187,6 +196,164 @@ def owned_rows(num_rows: int, world: int, rank: int) -> int:
     return (num_rows - rank + world - 1) // world if num_rows > rank else 0
 
 
+def exchange_rows(send: torch.Tensor, send_counts, recv_counts, group=None, async_op: bool = False):
+    """All-to-all-v of row blocks: ``send`` holds ``send_counts[p]`` rows for rank p, in rank order; returns the rows this rank receives,
+    ``recv_counts[p]`` from rank p, in rank order (``async_op``: an object whose ``wait()`` returns them).  RCCL: one
+    ``all_to_all_single`` with split sizes; gloo (the CPU / one-GPU rehearsals -- it has no all-to-all): point-to-point sends and
+    receives of the same blocks, device tensors staged through the host."""
+    w, r = dist.get_world_size(group), dist.get_rank(group)
+    assert len(send_counts) == w and len(recv_counts) == w and sum(send_counts) == send.shape[0]
+    send = send.contiguous()
+
+    class _Done:
+        def __init__(self, t):
+            self.t = t
+
+        def wait(self):
+            return self.t
+
+    if _skip_single(w):
+        return _Done(send) if async_op else send
+    out_shape = (sum(recv_counts),) + tuple(send.shape[1:])
+    if dist.get_backend(group) != "gloo":
+        out = torch.empty(out_shape, dtype=send.dtype, device=send.device)
+        work = dist.all_to_all_single(out, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group,
+                                      async_op=True)
+
+        class _Pending:
+            def wait(self_inner):
+                work.wait()
+                return out
+        pend = _Pending()
+        pend._keep = send
+        return pend if async_op else pend.wait()
+    dev = send.device
+    s = send.cpu() if send.is_cuda else send
+    o = torch.empty(out_shape, dtype=send.dtype)
+    ops, so, ro = [], 0, 0
+    for p in range(w):
+        sb, rb = s[so:so + send_counts[p]], o[ro:ro + recv_counts[p]]
+        so, ro = so + send_counts[p], ro + recv_counts[p]
+        if p == r:
+            rb.copy_(sb)
+            continue
+        if send_counts[p]:
+            ops.append(dist.P2POp(dist.isend, sb, p, group))
+        if recv_counts[p]:
+            ops.append(dist.P2POp(dist.irecv, rb, p, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    res = o.to(dev) if dev.type == "cuda" else o
+    return _Done(res) if async_op else res
+
+
+class TensorsKey:
+    """Identity of a tuple of tensors (address, length, layout, version) -- like ``engine.BatchKey``, for any number of tensors; holds
+    them, so an equal address means the same buffer."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.sig = self._sig(tensors)
+
+    @staticmethod
+    def _sig(tensors):
+        return tuple((t.data_ptr(), t.numel(), t.stride(), t.dtype, t._version) for t in tensors)
+
+    def matches(self, *tensors) -> bool:
+        return self.sig == self._sig(tensors) and self.sig == self._sig(self.tensors)
+
+
+class RowPull:
+    """The rows of the owner-sharded PE table one gather will read and this rank does not own, fetched from their owners.
+
+    ``request`` (any time after the batch's ids are known -- one step ahead with a look-ahead): sample the K most recent neighbours of
+    the rows, take the distinct ids (neighbours, the rows themselves, the padding row 0) this rank does not own, group them by owner
+    and send every owner its list in a fixed-capacity block (ids are 4 bytes: the padding is noise), together with the counts, which
+    travel to the host asynchronously.  ``fetch`` (once the owners' rows are final: after the previous update_pe): every rank gathers
+    the rows it was asked for, one all-to-all-v moves them (exact sizes: the counts have long arrived), the receiver scatters them
+    into its full-size table.  ``wait``: the current stream waits for that scatter.  All on the caller's current stream / the
+    communicator ``group`` (a second communicator, so the transfer is not queued behind the backward pass's collectives)."""
+
+    def __init__(self, dl: "DistributedLstep", ids: torch.Tensor, times: torch.Tensor, key: TensorsKey = None):
+        from . import _native as nat
+        self.dl, self.key = dl, key
+        W, rank, dev, rows = dl.W, dl.rank, dl.device, dl.num_rows
+        nbr = dl.bb.neighbor_sampler.sample_device(ids, times, dl.K)[0]
+        every = torch.cat([nbr.reshape(-1), ids, torch.zeros(1, dtype=torch.int64, device=dev)])
+        owner = torch.remainder(every, W)
+        sentinel = W * rows
+        keys = torch.where(owner == rank, torch.full_like(every, sentinel), owner * rows + every).to(torch.int32)
+        _, _, _, uniq, summary = nat.group_by_key(keys, max(1, int(sentinel + 1).bit_length()), sentinel, wait=None)
+        n = uniq.numel()
+        pos = torch.arange(n, device=dev)
+        u = torch.where(pos < summary[2], uniq, torch.full_like(uniq, 2 ** 31 - 1))        # sorted by (owner, id); the tail is uninitialised
+        bounds = torch.arange(W + 1, device=dev, dtype=torch.int32) * rows
+        off = torch.searchsorted(u, bounds)                                                   # [W + 1]
+        cnt = (off[1:] - off[:-1]).to(torch.int32)                                            # ids requested from every owner
+        self._parts = (u, off, cnt, n)
+        self._send_requests(dl._pull_capacity(n))
+        self.done = None
+
+    def _send_requests(self, C: int):
+        """Every owner receives its block of ``C`` id slots (-1 = unused) and every rank the whole count matrix; nothing here waits for the GPU."""
+        dl = self.dl
+        W, dev, rows = dl.W, dl.device, dl.num_rows
+        u, off, cnt, n = self._parts
+        col = torch.arange(C, device=dev)
+        idx = (off[:W].unsqueeze(1) + col.unsqueeze(0)).clamp(max=n - 1)
+        valid = col.unsqueeze(0) < cnt.unsqueeze(1)
+        base = (torch.arange(W, device=dev, dtype=torch.int32) * rows).unsqueeze(1)
+        self.req = torch.where(valid, u[idx] - base, torch.full((1, 1), -1, dtype=torch.int32, device=dev))       # [W, C] global ids
+        self.C = C
+        group = dl.pull_group
+        self.asked = exchange_rows(self.req.reshape(W * C), [C] * W, [C] * W, group, async_op=True)       # [W * C]: block p = what rank p wants from me
+        cm = all_gather_var(cnt.reshape(1, W), group, counts=[1] * W)[0]                                      # [W, W]: cm[p, q] = rows p wants from q
+        if cm.is_cuda:
+            self.cm_host = torch.empty((W, W), dtype=torch.int32, pin_memory=True)
+            self.cm_host.copy_(cm, non_blocking=True)
+            self.cm_event = torch.cuda.Event()
+            self.cm_event.record()
+        else:
+            self.cm_host, self.cm_event = cm.clone(), None
+
+    def fetch(self):
+        """Serve and receive (call when the owned rows are final on the current stream)."""
+        dl = self.dl
+        W, rank, C = dl.W, dl.rank, self.C
+        if self.cm_event is not None:
+            self.cm_event.synchronize()
+        cm = self.cm_host.tolist()
+        mine = [int(cm[rank][q]) for q in range(W)]            # rows I receive from q
+        serve = [int(cm[p][rank]) for p in range(W)]           # rows I send to p
+        if max(max(max(row) for row in cm), 0) > C:
+            # some owner was asked for more ids than a block holds (ids concentrated on one owner: every rank sees the same matrix and
+            # takes this branch together): send the lists again in blocks that hold any list, then go on
+            self.asked.wait()
+            self._send_requests(self._parts[3])
+            dl._pull_min_capacity = max(dl._pull_min_capacity, max(max(row) for row in cm))
+            C = self.C
+            if self.cm_event is not None:
+                self.cm_event.synchronize()
+        asked = self.asked.wait().reshape(W, C)
+        serve_ids = torch.cat([asked[p, :serve[p]] for p in range(W)]).long()
+        rows_out = dl.table.index_select(0, serve_ids)
+        pend = exchange_rows(rows_out, serve, mine, dl.pull_group, async_op=True)
+        my_ids = torch.cat([self.req[q, :mine[q]] for q in range(W)]).long()
+        rows_in = pend.wait()
+        if my_ids.numel():
+            dl.table.index_copy_(0, my_ids, rows_in)
+        self.rows_pulled = int(my_ids.numel())
+        if dl.table.is_cuda:
+            self.done = torch.cuda.Event()
+            self.done.record()
+        self.req = self.asked = self._parts = None
+
+    def wait(self):
+        if self.done is not None:
+            torch.cuda.current_stream(self.dl.device).wait_event(self.done)
+
+
 # ---------------------------------------------------------------------------------------------- engine
 class ShardedSparseRing(HistoryRing):
     """The sparse change-mask ring of the single-GPU engine (``engine.HistoryRing``, sparse mode) over the rows ONE rank owns: local row
@@ -267,16 +434,23 @@ class DistributedLstep:
         self.table = torch.zeros((rows, self.bb.pe_dim), dtype=torch.float32, device=dev)  # replicated current PE
         self.slot_of = engine.slot_of
         engine.ring = None  # the unsharded ring is not used (and must not be allocated at scale)
-        # Two ways to run update_pe across ranks (``_phase2_replicated``): REPLICATED -- every rank runs the single-GPU engine's
-        # device-count update on the global batch and mirrors the rows it owns into a sparse ring shard: no update collective, no host
-        # wait -- or OWNER-COMPUTES with all-gathers of the new rows into clone slots (the scheme that scales past W = 4).
-        self.replicated = self._phase2_replicated() and self._device_update_ok()
-        if self.replicated:
+        # Three ways to run update_pe across ranks (``_choose_form``; module docstring): "pull" -- owner-sharded table, owner-computes,
+        # pulled gather rows; "replicate" -- every rank recomputes the whole update on a replicated table; "allgather" -- owner-computes with
+        # all-gathers of every new row into replicated tables (clone ring shards, host-sized).
+        self.form = self._choose_form()
+        self.replicated = self.form == "replicate"
+        self.pull_group = None
+        self._pending_pull, self._pull_min_capacity = None, 0
+        if self.form in ("replicate", "pull"):
             self._ring = ShardedSparseRing(self.table, self.W, self.rank, self.bb.num_fft_batches)
             engine.ring = self._ring        # (lets the engine's grouping helpers take their device-count branch; its own iterations are not used)
             if engine.use_aux:
                 from .model import _aux_stream
                 self._ring.advance_stream = _aux_stream(dev)
+            if self.form == "pull":
+                # the pulled rows travel on a communicator of their own: on the main one they would queue behind the backward pass's
+                # reduce-scatter / all-reduce (a communicator runs its collectives in issue order) instead of underneath them
+                self.pull_group = dist.new_group(backend=dist.get_backend(group)) if not _skip_single(self.W) else group
         else:
             self._ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
         self._copy_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
@@ -420,22 +594,27 @@ class DistributedLstep:
             self.bb.apply_residual_tanh(self.table, unpack_ids(z_all, P), z_all)       # every replica applies the same update
         return now32, fused
 
-    def _phase2_replicated(self) -> bool:
-        """How the replicas of the PE table receive update_pe's rows.
-        ``replicate`` (default, ``auto``): every rank runs update_pe for ALL rows itself -- same inputs on every rank (the spliced rows
-        were all-gathered, the CSR and the edge stream are replicated) -- and nothing travels; the work grows with the global batch
-        (phase 2 touches 0.72 / 0.91 / 2.9 M rows at W = 2 / 4 / 8 on c4 / c4 / c5: ~0.8 / 1.0 / 3 ms of matrix-core time on the side
-        stream), but it is the single-GPU engine's host-free device-count path (``_train_iteration_replicated``).
-        ``allgather``: every rank computes the rows it owns and all-gathers them -- U2 x 704 B per step, 72-91 % of the table at the
-        BASELINE shapes: 2.1-3.3 ms of link time, plus host waits for the data-dependent sizes of the exchange.  Measured at W = 1 on RCCL
-        with the collectives forced: 3.92 ms/step replicated, 5.84 owner-computes.
-        Replicas stay bit-identical under ``replicate`` as long as no touched row collects more than 128 messages in one batch (a
-        segment cut into two 64-entry chunks is a two-operand sum, which commutes; three or more partial sums are added with float
-        atomics in arrival order, 1 ulp apart at most); the history shard always stores the owner's value."""
+    def _choose_form(self) -> str:
+        """LSTEP_PHASE2 = auto | replicate | allgather | pull (module docstring).
+        ``auto``: "replicate" up to W = 4 -- zero update bytes and the single-GPU engine's host-free path; the redundant work (phase 2
+        touches 0.72 / 0.91 M rows at W = 2 / 4 on c4) still fits under the backward pass -- and "pull" beyond: at W = 8 on c5 the
+        replicated update would touch 2.9 M rows per step (~6.7 ms of update kernels against a ~3.4 ms step) and an all-gather of them
+        would move 1.77 GB per rank, while the pull moves the ~0.55 GB a rank's next gather reads and keeps the update at 1 / W of the
+        rows.  Configurations the device-count update does not cover (non-default widths, RNG-defined sampling, T > 126) take
+        "allgather", the host-sized owner-computes form."""
         policy = os.environ.get("LSTEP_PHASE2", "auto")
-        if policy not in ("auto", "replicate", "allgather"):
-            raise ValueError("LSTEP_PHASE2 must be auto, replicate or allgather")
-        return policy != "allgather"
+        if policy not in ("auto", "replicate", "allgather", "pull"):
+            raise ValueError("LSTEP_PHASE2 must be auto, replicate, allgather or pull")
+        if not self._device_update_ok():
+            if policy in ("replicate", "pull"):
+                raise RuntimeError(f"LSTEP_PHASE2={policy} needs the device-count update path (default widths, 'recent' sampling, T <= 126, a GPU)")
+            return "allgather"
+        if policy == "auto":
+            return "replicate" if self.W <= 4 else "pull"
+        return policy
+
+    def _phase2_replicated(self) -> bool:
+        return self.form == "replicate"
 
     def _update_phase2(self, bn, ts, state):
         """update_pe phase 2 up to the all-gather of its rows, which is left in flight."""
@@ -470,6 +649,8 @@ class DistributedLstep:
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
         with self.eng.aux_streams():
+            if self.form == "pull":
+                return self._train_iteration_pull(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
             if self.replicated:
                 return self._train_iteration_replicated(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
             return self._train_iteration(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
@@ -486,8 +667,9 @@ class DistributedLstep:
         u = sum(owner_counts)
         return bn_cap[:u], bn_cap, n_live, presorted, owner_counts
 
-    def _forward_on_slice(self, bn, batch_idx, owner_counts, src, dst, neg_dst, ts):
-        """FFT splice (owner-sharded filter + all-gather) and this rank's slice through gather, dense tail, predictor and loss."""
+    def _forward_on_slice(self, bn, batch_idx, owner_counts, src, dst, neg_dst, ts, pull=None):
+        """FFT splice (owner-sharded filter + all-gather) and this rank's slice through gather, dense tail, predictor and loss.
+        ``pull`` (owner-sharded table): the fetched rows this gather reads; their scatter must precede the write of the spliced rows."""
         n_glob = src.numel()
         b = n_glob // self.W
         sl = slice(self.rank * b, (self.rank + 1) * b)
@@ -497,6 +679,8 @@ class DistributedLstep:
         fused = self.bb._fused_tail_ok()
         # edge + node channels first: they read no PE row, so their launch overlaps the all-gather of the filtered rows
         x_edge, x_node, _, _, _ = self.bb._gather(None, ids3, t3, self.K, self.G, nat_branch("edge_node"), wide=fused, row_blocks=3)
+        if pull is not None:
+            pull.wait()      # (rows of this batch's nodes were fetched BEFORE their splice: the all-gathered spliced rows overwrite them next)
         rows_mine, leaf, (owner_order, owner_counts) = self._splice_finish(started)
         spliced = SplicedRows(leaf, self.slot_of)
         _, _, x_pe, own, _ = self.bb._gather(self.table, ids3, t3, self.K, self.G, nat_branch("pe"), spliced, wide=fused, row_blocks=3)
@@ -506,6 +690,182 @@ class DistributedLstep:
                                                            self.eng.neg_sample_weight)
         out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
         return out, loss, rows_mine, leaf, owner_order, owner_counts
+
+    # ---- the owner-sharded form ("pull"): module docstring, ``RowPull``
+    def _slice_rows(self, blocks, ts):
+        """This rank's gather rows of a global batch: cat of its B-edge slice of every id block, with the slice's times repeated."""
+        b = ts.numel() // self.W
+        sl = slice(self.rank * b, (self.rank + 1) * b)
+        return torch.cat([x[sl] for x in blocks]), torch.cat([ts[sl]] * len(blocks))
+
+    def _pull_capacity(self, n: int) -> int:
+        """Id slots per owner in the request exchange: 1.5 x an even split of the n candidate ids (or 1.25 x the longest list seen),
+        never more than n; a list that does not fit makes every rank resend in blocks of n (``RowPull.fetch``)."""
+        even = -(-n // self.W)
+        want = max(even + even // 2, self._pull_min_capacity + self._pull_min_capacity // 4, 1024)
+        return min(n, -(-want // 1024) * 1024)
+
+    def _pull_now(self, blocks, ts):
+        """No look-ahead had the rows fetched: request and fetch on the current stream (two host waits)."""
+        pull = RowPull(self, *self._slice_rows(blocks, ts))
+        self._poison_foreign_rows()
+        pull.fetch()
+        return pull
+
+    def _take_pull(self, *tensors):
+        pend, self._pending_pull = self._pending_pull, None
+        return pend if (pend is not None and pend.key is not None and pend.key.matches(*tensors)) else None
+
+    def _owned_positions(self, bn, owner_counts):
+        order = torch.argsort(bn % self.W, stable=True)
+        first = sum(owner_counts[:self.rank])
+        return order[first:first + owner_counts[self.rank]]
+
+    def _share_phase1_rows(self, owner_counts):
+        """``update_pe_device(after_phase1=...)``: phase 2's messages carry the phase-1 rows of ALL batch nodes (models/LSTEP.py:311-320),
+        so every owner hands out the ones it just computed -- the "all-gather of updated positional encodings" of north_star: U x 692 B."""
+        def share(ids1):
+            if not _skip_single(self.W):
+                self._write_rows(all_gather_var(self._rows_with_ids(ids1), self.group, counts=owner_counts)[0])
+        return share
+
+    def full_table(self) -> torch.Tensor:
+        """The whole current PE table assembled from its owners (all-gather of the owned rows) -- a new tensor; this rank's own table,
+        a cache outside its owned rows, is left as it is."""
+        if _skip_single(self.W):
+            return self.table.clone()
+        mx = owned_rows(self.num_rows, self.W, 0)
+        cat, _ = all_gather_var(_pad_rows(self.table[self.rank::self.W].contiguous(), mx), self.group, counts=[mx] * self.W)
+        out = torch.empty_like(self.table)
+        for r in range(self.W):
+            out[r::self.W] = cat[r * mx:r * mx + owned_rows(self.num_rows, self.W, r)]
+        return out
+
+    def sync_full_table(self):
+        """Make every row of this rank's table valid: checkpoints, and batch 0, where the reference hands the updated table back through
+        ``initial_positional_encoding`` (train:281,286)."""
+        if not _skip_single(self.W):
+            self.table.copy_(self.full_table())
+
+    def _poison_foreign_rows(self):
+        """LSTEP_PULL_POISON=1 (tests): every row this rank does not own becomes NaN right before the rows of the next gather are
+        fetched -- whatever the next iteration reads must then have arrived through the pull or one of the two all-gathers."""
+        if os.environ.get("LSTEP_PULL_POISON") != "1":
+            return
+        if getattr(self, "_foreign", None) is None:
+            self._foreign = (torch.remainder(torch.arange(self.num_rows, device=self.device), self.W) != self.rank).unsqueeze(1)
+        self.table.masked_fill_(self._foreign, float("nan"))
+
+    def _train_iteration_pull(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
+        assert src.numel() % self.W == 0, "global batch must divide by the world size"
+        bb, ring = self.bb, self._ring
+        bb.prepare_step()
+        bn, bn_cap, n_live, presorted, owner_counts = self._global_batch_nodes(src, dst, batch_idx)
+        out, loss = None, None
+        if batch_idx == 0:
+            self.table.copy_(initial_pe)         # every row valid on every rank
+            self._pending_pull = None
+            ring.begin_slot(all_changed=True)
+            owned_idx = self._owned_positions(bn, owner_counts)
+        else:
+            pull = self._take_pull(src, dst, ts, neg_dst) or self._pull_now((src, dst, neg_dst), ts)
+            out, loss, rows_mine, leaf, owner_order, owner_counts = self._forward_on_slice(bn, batch_idx, owner_counts, src, dst, neg_dst, ts, pull=pull)
+            owned_idx = self._owned_idx
+        if lookahead is not None:
+            self._prefetch(lookahead[:2])
+        ahead = lookahead if (lookahead is not None and len(lookahead) >= 4) else None
+        nxt = None
+
+        def update_and_append():
+            nonlocal nxt
+            if ahead is not None:       # the next batch's requests: independent of this update, issued first so the counts reach the host early
+                nxt = RowPull(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]))
+            bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building(),
+                                mirror_shard=(self.W, self.rank), owner=(self.W, self.rank), owned_idx=owned_idx,
+                                after_phase1=self._share_phase1_rows(owner_counts))
+            if batch_idx == 0 and initial_pe is not None:
+                self.sync_full_table()
+                initial_pe.copy_(self.table)
+            ring.commit()
+
+        if loss is None:
+            update_and_append()
+            ring.apply_advance()
+            if nxt is not None:
+                self._poison_foreign_rows()
+                nxt.fetch()
+                self._pending_pull = nxt
+            return out
+        main, side = torch.cuda.current_stream(self.device), self.eng._update_stream
+        overlap = self.eng.overlap_update
+        updated = None
+        if overlap:
+            side.wait_stream(main)       # after the forward pass: it reads the table update_pe is about to rewrite
+            with torch.cuda.stream(side):
+                update_and_append()
+                updated = torch.cuda.Event()
+                updated.record()
+        else:
+            update_and_append()
+        optimizer.zero_grad()
+        (loss / self.W).backward()                       # global mean = mean of the rank means
+        g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+        g_mine = reduce_scatter_var(g_rows[owner_order].contiguous(), owner_counts, self.group)
+        if rows_mine.numel():
+            rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
+        bb.join_aux_stream()
+        all_reduce_gradients(self._trainable, self.group)
+        ring.apply_advance()             # the backward pass is enqueued: the window's oldest snapshot may move on behind it
+        if nxt is not None:
+            # the rows of the NEXT gather: behind update_pe on its stream (the owners' rows are final there), underneath the backward pass
+            # on the GPU; the host only reads counts that arrived while it was enqueueing the backward pass
+            with torch.cuda.stream(side) if overlap else contextlib.nullcontext():
+                self._poison_foreign_rows()
+                nxt.fetch()
+            self._pending_pull = nxt
+        if updated is not None:
+            main.wait_event(updated)     # the optimiser may only step once update_pe has read its weights; the ring shard is appended
+        optimizer.step()
+        self.slot_of.index_fill_(0, bn, -1)
+        v = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
+        all_reduce_sum(v, self.group)
+        out["lp_loss"], out["pe_loss"], out["loss"] = (v / self.W).unbind(0)
+        return out
+
+    def _eval_iteration_pull(self, batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead):
+        n_glob = src.numel()
+        b = n_glob // self.W
+        bb, ring = self.bb, self._ring
+        bn, bn_cap, n_live, presorted, owner_counts = self._global_batch_nodes(src, dst, batch_idx)
+        pull = self._take_pull(src, dst, ts, neg_src, neg_dst) or self._pull_now((src, dst, neg_src, neg_dst), ts)
+        started = self._splice_start(bn, batch_idx, owner_counts)
+        pull.wait()
+        self._splice_finish(started)
+        owned_idx = self._owned_idx
+        self.slot_of.index_fill_(0, bn, -1)
+        ids, t4 = self._slice_rows((src, dst, neg_src, neg_dst), ts)
+        emb_p = bb.combining_pe_raw_feat(self.table, ids, t4, self.K, self.G, padded=True, row_blocks=4)
+        if self.predictor.fused_ok(emb_p):
+            predicts = self.predictor.pair_logits(emb_p, b, (0, b, 2 * b, 3 * b)).sigmoid().clamp(0, 1)
+        else:
+            emb = emb_p[:, :bb.feat_dim]
+            predicts = torch.cat([self._probabilities(emb[:b], emb[b:2 * b]), self._probabilities(emb[2 * b:3 * b], emb[3 * b:])], dim=0)
+        labels = torch.cat([torch.ones(b, device=self.device), torch.zeros(b, device=self.device)])
+        if lookahead is not None:
+            self._prefetch(lookahead[:2])
+        nxt = None
+        if lookahead is not None and len(lookahead) >= 5:
+            nxt = RowPull(self, *self._slice_rows((lookahead[0], lookahead[1], lookahead[3], lookahead[4]), lookahead[2]), key=TensorsKey(*lookahead[:5]))
+        bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building(),
+                            mirror_shard=(self.W, self.rank), owner=(self.W, self.rank), owned_idx=owned_idx,
+                            after_phase1=self._share_phase1_rows(owner_counts))
+        ring.commit()
+        ring.apply_advance()
+        if nxt is not None:
+            self._poison_foreign_rows()
+            nxt.fetch()
+            self._pending_pull = nxt
+        return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}
 
     def _train_iteration_replicated(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
         assert src.numel() % self.W == 0, "global batch must divide by the world size"
@@ -519,7 +879,7 @@ class DistributedLstep:
         else:
             out, loss, rows_mine, leaf, owner_order, owner_counts = self._forward_on_slice(bn, batch_idx, owner_counts, src, dst, neg_dst, ts)
         if lookahead is not None:
-            self._prefetch(lookahead)
+            self._prefetch(lookahead[:2])
 
         def update_and_append():
             # every rank updates ALL rows of its replica (same inputs everywhere) and mirrors the ones it owns into its ring shard
@@ -576,7 +936,7 @@ class DistributedLstep:
             predicts = torch.cat([self._probabilities(emb[:b], emb[b:2 * b]), self._probabilities(emb[2 * b:3 * b], emb[3 * b:])], dim=0)
         labels = torch.cat([torch.ones(b, device=self.device), torch.zeros(b, device=self.device)])
         if lookahead is not None:
-            self._prefetch(lookahead)
+            self._prefetch(lookahead[:2])
         bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building(),
                             mirror_shard=(self.W, self.rank))
         ring.commit()
@@ -628,7 +988,7 @@ class DistributedLstep:
                 loss = (1.0 - self.eng.pe_weight) * lp_loss + self.eng.pe_weight * pe_loss
             out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
         if lookahead is not None:
-            self._prefetch(lookahead)                      # the next global batch's endpoints, grouped while this one runs
+            self._prefetch(lookahead[:2])                  # the next global batch's endpoints, grouped while this one runs
         # update_pe: the all-gather of the phase-2 rows (the largest collective, ~0.7 KB per touched node) stays in flight
         # while the backward pass runs; neither reads what the other writes
         # With a loss to differentiate, update_pe's kernels go to a side stream, issued from this same thread (so every rank still posts
@@ -679,6 +1039,8 @@ class DistributedLstep:
 
     # ---- evaluate_model_utils.py:38-142 on a global batch (call under torch.no_grad())
     def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
+        if self.form == "pull":
+            return self._eval_iteration_pull(batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead)
         if self.replicated:
             return self._eval_iteration_replicated(batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead)
         n_glob = src.numel()
