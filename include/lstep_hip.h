@@ -211,17 +211,23 @@ int lstep_history_filter_runs_finish(const float* partial_sum, int32_t t_len, in
  * adjacent (ent_seg grouped, e.g. sorted); for every segment s that occurs
  *   out[s, :W]    = sum_e table[ent_row[e], :W]                       (table row stride ld_table floats)
  *   out[s, W:W+D] = sum_e cos(ent_dt[e] * time_w + time_b)            (time_dim D may be 0: no time part, ent_dt unused)
- * `out` (row stride ld_out) MUST be zero-initialised by the caller: rows that own no entry stay zero, and a segment that
- * straddles a 64-entry chunk boundary is accumulated with float atomics (long segments = hub nodes); all other
- * segments are plain stores summed in entry order (deterministic).  accumulate = 1: the sums are ADDED to what `out`
- * already holds (a second reduction into the same rows, e.g. neighbour + self gradients).  accumulate = 2: `out` is UNINITIALISED
- * memory and (width + time_dim) a multiple of 4 -- a pre-pass zeroes just the straddling segments' rows, every other row that owns
- * entries is written whole, rows without entries stay undefined (update_pe: every row owns entries; saves a 356 MB memset).  Uses:
+ * `out` (row stride ld_out) MUST be zero-initialised by the caller (accumulate = 0): rows that own no entry stay zero.  Segments inside one
+ * 64-entry chunk are plain stores summed in entry order.  A segment that straddles chunk boundaries (long segments = hub nodes):
+ *   with `workspace` (lstep_segment_rows_sum_workspace bytes, 16-byte aligned): every chunk parks its partial sum there and a second
+ *     pass adds a segment's partials in chunk order -- the result is a function of the inputs alone (replicas of a table that run the
+ *     same update on different GPUs stay bit-identical, two runs of one process too);
+ *   with workspace = NULL: float atomics into the row, in arrival order (exact up to the order of three or more partial sums).
+ * accumulate = 1: the sums are ADDED to what `out` already holds (a second reduction into the same rows, e.g. neighbour + self
+ * gradients).  accumulate = 2: `out` is UNINITIALISED memory and (width + time_dim) a multiple of 4 -- every row that owns entries is
+ * written whole (without a workspace a pre-pass zeroes the straddling segments' rows first), rows without entries stay undefined
+ * (update_pe: every row owns entries; saves a 356 MB memset).  Uses:
  *   update_pe U1/U2 (models/LSTEP.py:282-290, 319-322) with table = pe, D = time dim: replaces both dense [N+1, P+D]
  *   torch_scatter targets;  gather backward: table = grad of the PE aggregate, D = 0, segment = spliced PE row. */
+int64_t lstep_segment_rows_sum_workspace(int64_t num_entries, int32_t width, int32_t time_dim);
 int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
                            int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
-                           int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, const int32_t* num_live, void* stream);
+                           int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, const int32_t* num_live, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 /* num_live (optional, device): only the first min(*num_live, num_entries) entries count (a capacity-sized entry list whose length
  * lstep_group_by_key left on the device). */
 
@@ -297,7 +303,8 @@ int lstep_sort_live_bounded(const int32_t* keys, int64_t n, int32_t key_bits, in
                             int64_t workspace_bytes, int32_t* sorted_keys, int32_t* order, int32_t* live_index, int32_t* count, void* stream);
 /* lstep_segment_rows_sum (no time part, accumulate 0 / 1) over such a padded list: only the first min(*num_live, num_entries) entries count. */
 int lstep_segment_rows_sum_live(const float* table, int32_t width, int32_t ld_table, const int32_t* ent_seg, const int32_t* ent_row,
-                                int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate, void* stream);
+                                int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 /* out[keys[e], :width] += table[e / div, :width] for e = live_index[i], i in [capacity, *count). */
 int lstep_scatter_add_overflow(float* out, int32_t width, int32_t ld_out, const int32_t* keys, const int32_t* live_index, const int32_t* count,
                                int64_t capacity, int32_t div, const float* table, int32_t ld_table, void* stream);

@@ -98,10 +98,11 @@ SIGNATURES = {
     "lstep_copy_rows": (C.c_int, [_P, _P, _I32, _I64, _P, _I64, _I64, C.POINTER(RingRef), _P]),
     "lstep_history_advance_oldest": (C.c_int, [_P, _P, _I32, _I64, _P, _I32, _I32, _I64, C.POINTER(RingRef), _P]),
     "lstep_history_filter_runs_finish": (C.c_int, [_P, _I32, _I32, _P, _P]),
-    "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _I32, _P, _P]),
+    "lstep_segment_rows_sum_workspace": (C.c_int64, [_I64, _I32, _I32]),
+    "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _P]),
     "lstep_sort_live_bounded_workspace": (_I64, [_I64, _I64, _I32]),
     "lstep_sort_live_bounded": (C.c_int, [_P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P]),
-    "lstep_segment_rows_sum_live": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _P, _I32, _I32, _P]),
+    "lstep_segment_rows_sum_live": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P]),
     "lstep_scatter_add_overflow": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
@@ -208,6 +209,18 @@ def _workspace(dev, need: int):
     if ws is None or ws.numel() < need:
         ws = _WORKSPACES[wkey] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
     return ws
+
+
+def segment_workspace(dev, num_entries: int, width: int, time_dim: int = 0):
+    """(pointer, bytes) of the scratch that makes ``lstep_segment_rows_sum`` independent of the order in which its waves finish (hub
+    segments are joined in chunk order); (None, 0) with LSTEP_SEGMENT_ATOMICS=1, the A/B switch back to float atomics."""
+    if os.environ.get("LSTEP_SEGMENT_ATOMICS") == "1":
+        return None, 0
+    need = int(load_library().lstep_segment_rows_sum_workspace(int(num_entries), int(width), int(time_dim)))
+    if need == 0:
+        return None, 0
+    ws = _workspace(dev, need)
+    return ws, ws.numel()
 
 
 def sort_live(keys, key_bits: int):

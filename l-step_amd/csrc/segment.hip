@@ -9,10 +9,12 @@ namespace lstep {
 constexpr int kSegInFlight = 8;
 constexpr int kChunk = 64;   // entries per wave: bounds the work of one wave whatever the segment-length distribution is
 
-// flush one run of a segment: plain store when this chunk holds the whole segment, float atomics (contiguous dwords
-// per wave-instruction) when the segment is split over several chunks (long segments = hub nodes)
+// flush one run of a segment: plain store when this chunk holds the whole segment.  A segment split over several chunks (long segments =
+// hub nodes): with a scratch buffer (`part`, this run's slot) the partial sum is parked there and segment_join_split_rows_kernel adds the
+// partials of a segment in chunk order -- deterministic whatever the scheduling; without one, float atomics (contiguous dwords per
+// wave-instruction) into the zeroed row, in arrival order.
 __device__ __forceinline__ void flush_run(float* __restrict__ o, const float4& acc, float t0, float t1, int W, int D, bool whole,
-                                          bool accumulate, int lane) {
+                                          bool accumulate, int lane, float* __restrict__ part) {
     const bool wa = lane < (W >> 2);
     if (whole && accumulate) {   // this wave is the only writer of the row: plain read-modify-write
         if (wa) {
@@ -25,6 +27,10 @@ __device__ __forceinline__ void flush_run(float* __restrict__ o, const float4& a
         if (wa) st4(o + lane * 4, acc);
         if (lane < D) o[W + lane] = t0;
         if (lane + kWave < D) o[W + lane + kWave] = t1;
+    } else if (part) {
+        if (wa) st4(part + lane * 4, acc);
+        if (lane < D) part[W + lane] = t0;
+        if (lane + kWave < D) part[W + lane + kWave] = t1;
     } else {
         if (wa) {
             atomicAdd(o + lane * 4 + 0, acc.x);
@@ -46,10 +52,13 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                                                                    const int32_t* __restrict__ ent_seg, const int32_t* __restrict__ ent_row,
                                                                    const float* __restrict__ ent_dt, int64_t num_entries,
                                                                    float* __restrict__ out, int ld_out, bool accumulate,
-                                                                   const int32_t* __restrict__ num_live) {
+                                                                   const int32_t* __restrict__ num_live, float* __restrict__ parts) {
     const int lane = lane_id();
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t e0 = chunk * kChunk;
+    // partial sums of split runs: two slots of W + D floats per chunk -- [0] the run that continues FROM the previous chunk, [1] the run that
+    // starts here and continues INTO the next one
+    float* const part0 = parts ? parts + (chunk * 2) * (int64_t)(W + D) : nullptr;
     if (num_live) {      // the entry list is padded: only its first min(*num_live, num_entries) entries count (lstep_sort_live_bounded)
         const int64_t live = *num_live;
         if (live < num_entries) num_entries = live;
@@ -88,7 +97,9 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                 if ((j + u) >= m) break;
                 const int sj = bcast_i32(sg, j + u);
                 if (sj != cur) {
-                    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane);
+                    if (cur >= 0)
+                        flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane,
+                                  part0 ? part0 + (cur == seg_prev ? 0 : W + D) : nullptr);
                     cur = sj;
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     t0 = t1 = 0.f;
@@ -102,7 +113,50 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
             }
         }
     }
-    if (cur >= 0) flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane);
+    if (cur >= 0)
+        flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane,
+                  part0 ? part0 + (cur == seg_prev ? 0 : W + D) : nullptr);
+}
+
+// Second pass of the deterministic form: one wave per chunk boundary.  The wave at the boundary behind the chunk in which a split segment
+// STARTS adds that segment's parked partials in chunk order and writes (or, `accumulate`, adds to) its row: the only writer of the row.
+__global__ __launch_bounds__(kBlock) void segment_join_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t num_entries, int W, int D,
+                                                                         const float* __restrict__ parts, float* __restrict__ out, int ld_out,
+                                                                         bool accumulate, const int32_t* __restrict__ num_live) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block() + 1;   // boundary between chunk c - 1 and chunk c
+    const int64_t e = c * kChunk;
+    if (num_live) {
+        const int64_t live = *num_live;
+        if (live < num_entries) num_entries = live;
+    }
+    if (e >= num_entries) return;
+    const int sg = ent_seg[e];
+    if (ent_seg[e - 1] != sg) return;                                               // nothing continues across this boundary
+    if (c > 1 && ent_seg[(c - 1) * kChunk - 1] == sg) return;                      // the segment started earlier: that boundary's wave joins it
+    const int ldp = W + D;
+    const bool wa = lane < (W >> 2);
+    const float* p = parts + ((c - 1) * 2 + 1) * (int64_t)ldp;                      // the start chunk's last run
+    float4 acc = wa ? ld4(p + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float t0 = lane < D ? p[W + lane] : 0.f, t1 = lane + kWave < D ? p[W + lane + kWave] : 0.f;
+    for (int64_t j = c;; ++j) {
+        p = parts + (j * 2) * (int64_t)ldp;                                         // chunk j's first run continues the segment
+        if (wa) { const float4 v = ld4(p + lane * 4); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        if (lane < D) t0 += p[W + lane];
+        if (lane + kWave < D) t1 += p[W + lane + kWave];
+        const int64_t nx = (j + 1) * kChunk;
+        if (nx >= num_entries || ent_seg[nx] != sg) break;
+    }
+    float* o = out + (int64_t)sg * ld_out;
+    if (accumulate) {
+        if (wa) { const float4 old = ld4(o + lane * 4); st4(o + lane * 4, make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w)); }
+        if (lane < D) o[W + lane] += t0;
+        if (lane + kWave < D) o[W + lane + kWave] += t1;
+    } else {
+        if (wa) st4(o + lane * 4, acc);
+        if (lane < D) o[W + lane] = t0;
+        if (lane + kWave < D) o[W + lane + kWave] = t1;
+    }
 }
 
 // Pre-pass for an UNINITIALISED output: only the rows of segments that straddle a chunk boundary are accumulated with atomics and need
@@ -198,10 +252,15 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
 
 using namespace lstep;
 
+extern "C" int64_t lstep_segment_rows_sum_workspace(int64_t num_entries, int32_t width, int32_t time_dim) {
+    if (num_entries <= kChunk) return 0;       // one chunk: nothing can be split
+    return ((num_entries + kChunk - 1) / kChunk) * 2 * (int64_t)(width + time_dim) * (int64_t)sizeof(float);
+}
+
 extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
                                       int32_t time_dim, const int32_t* ent_seg, const int32_t* ent_row, const float* ent_dt,
                                       int64_t num_entries, float* out, int32_t ld_out, int32_t accumulate, const int32_t* num_live,
-                                      void* stream) {
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
     if (num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: negative count");
     if (num_entries == 0) return LSTEP_OK;
     if (ld_table == 0) ld_table = width;
@@ -213,18 +272,29 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
         return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: NULL pointer");
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (accumulate == 2 && chunks > 1)   // uninitialised output: zero just the rows the atomics will add to
-        hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3((unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                           (hipStream_t)stream, ent_seg, num_entries, out, (int)ld_out, (int)(width + time_dim), num_live);
+    const unsigned bgrid = (unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock);
+    float* parts = nullptr;
+    if (workspace && chunks > 1) {       // deterministic form: split segments are joined in chunk order by a second pass
+        if (((uintptr_t)workspace & 15) || workspace_bytes < lstep_segment_rows_sum_workspace(num_entries, width, time_dim))
+            return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: workspace too small or misaligned (need %lld bytes, 16-byte aligned)",
+                             (long long)lstep_segment_rows_sum_workspace(num_entries, width, time_dim));
+        parts = (float*)workspace;
+    }
+    if (!parts && accumulate == 2 && chunks > 1)   // uninitialised output, atomic form: zero just the rows the atomics will add to
+        hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3(bgrid), dim3(kBlock), 0, (hipStream_t)stream, ent_seg, num_entries, out,
+                           (int)ld_out, (int)(width + time_dim), num_live);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts);
+    if (parts)
+        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3(bgrid), dim3(kBlock), 0, (hipStream_t)stream, ent_seg, num_entries, (int)width,
+                           (int)time_dim, parts, out, (int)ld_out, accumulate == 1, num_live);
     return check_launch("segment_rows_sum_kernel");
 }
 
 // lstep_segment_rows_sum (no time part, accumulate 0 / 1) over a PADDED entry list: only the first min(*num_live, num_entries) entries count
 extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, int32_t ld_table, const int32_t* ent_seg, const int32_t* ent_row,
                                            int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate,
-                                           void* stream) {
+                                           void* workspace, int64_t workspace_bytes, void* stream) {
     if (num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: negative count");
     if (num_entries == 0) return LSTEP_OK;
     if (ld_table == 0) ld_table = width;
@@ -235,9 +305,18 @@ extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, in
     if (!table || !ent_seg || !ent_row || !out || !num_live) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: NULL pointer");
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    float* parts = nullptr;
+    if (workspace && chunks > 1) {
+        if (((uintptr_t)workspace & 15) || workspace_bytes < lstep_segment_rows_sum_workspace(num_entries, width, 0))
+            return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: workspace too small or misaligned");
+        parts = (float*)workspace;
+    }
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table,
                        (const float*)nullptr, (const float*)nullptr, 0, ent_seg, ent_row, (const float*)nullptr, num_entries, out, (int)ld_out,
-                       accumulate == 1, num_live);
+                       accumulate == 1, num_live, parts);
+    if (parts)
+        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, ent_seg, num_entries, (int)width, 0, parts, out, (int)ld_out, accumulate == 1, num_live);
     return check_launch("segment_rows_sum_kernel<live>");
 }
 

@@ -755,8 +755,10 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
         sorted_keys, order, live_index, count = nat.sort_live_bounded(keys, key_bits, int(out.shape[0]), capacity)
         ent_row = torch.div(order, div, rounding_mode="floor") if div > 1 else order
         with torch.cuda.device(dev):
+            ws, ws_bytes = nat.segment_workspace(dev, capacity, P)
             nat.check(lib.lstep_segment_rows_sum_live(nat.ptr(table), P, int(table.stride(0)), nat.ptr(sorted_keys), nat.ptr(ent_row), capacity,
-                                                      nat.ptr(count), nat.ptr(out), P, 1 if accumulate else 0, nat.current_stream()))
+                                                      nat.ptr(count), nat.ptr(out), P, 1 if accumulate else 0, nat.ptr(ws), ws_bytes,
+                                                      nat.current_stream()))
             if capacity < n:
                 nat.check(lib.lstep_scatter_add_overflow(nat.ptr(out), P, P, nat.ptr(keys), nat.ptr(live_index), nat.ptr(count), capacity,
                                                          max(div, 1), nat.ptr(table), int(table.stride(0)), nat.current_stream()))
@@ -773,8 +775,9 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
     ent_seg = sorted_keys[:n_hit]
     ent_row = src_row_of(order[:n_hit])
     with torch.cuda.device(dev):
+        ws, ws_bytes = nat.segment_workspace(dev, n_hit, P)
         nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, int(table.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
-                                             n_hit, nat.ptr(out), P, 1 if accumulate else 0, None, nat.current_stream()))
+                                             n_hit, nat.ptr(out), P, 1 if accumulate else 0, None, nat.ptr(ws), ws_bytes, nat.current_stream()))
 
 
 def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, self_groups=None):
@@ -798,8 +801,9 @@ def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, 
     ent_seg, ent_row = self_groups
     n_known = ent_row.numel()
     with torch.cuda.device(hits.device):
+        ws, ws_bytes = nat.segment_workspace(hits.device, n_known, P)
         nat.check(lib.lstep_segment_rows_sum(nat.ptr(g_self), P, int(g_self.stride(0)), None, None, 0, nat.ptr(ent_seg), nat.ptr(ent_row), None,
-                                             n_known, nat.ptr(total), P, 1, None, nat.current_stream()))
+                                             n_known, nat.ptr(total), P, 1, None, nat.ptr(ws), ws_bytes, nat.current_stream()))
         rest = self_slot[n_known:].to(torch.int32).contiguous()
         if rest.numel():
             g_rest = g_self[n_known:]
@@ -1404,9 +1408,10 @@ class LSTEP(nn.Module):
         else:
             out = torch.zeros((self._bucket_rows(nseg), self.ld_pe), dtype=torch.float32, device=pe.device)
         with torch.cuda.device(pe.device):
+            ws, ws_bytes = nat.segment_workspace(pe.device, ent_row.numel(), P, D)
             nat.check(lib.lstep_segment_rows_sum(nat.ptr(pe), P, P, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
                                                  nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), ent_row.numel(), nat.ptr(out), self.ld_pe,
-                                                 2 if exact else 0, nat.ptr(live), nat.current_stream()))
+                                                 2 if exact else 0, nat.ptr(live), nat.ptr(ws), ws_bytes, nat.current_stream()))
         return out
 
     MLP_ROW_BLOCK = 65536   # hipBLASLt's fp32 rate for these skinny GEMMs swings 50-115 TFLOP/s with M; 65536-row blocks sit at ~100 (tools/gemm_m.py)
@@ -1746,9 +1751,10 @@ class LSTEP(nn.Module):
             y = torch.mm(pe.index_select(0, bn), w1a_t)                       # [cap, 176]; dead rows are node 0: pe[0] = 0 -> 0
             agg2 = torch.empty((tcap, Pp + D), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
+                ws, ws_bytes = nat.segment_workspace(dev, n, Pp, D)
                 nat.check(lib.lstep_segment_rows_sum(nat.ptr(y), Pp, Pp, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
                                                      nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), n, nat.ptr(agg2), Pp + D, 2,
-                                                     nat.ptr(summary[1:2]), nat.current_stream()))
+                                                     nat.ptr(summary[1:2]), nat.ptr(ws), ws_bytes, nat.current_stream()))
             agg2[0].zero_()
             if rank == 0:
                 part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), Pp), dtype=torch.float32, device=dev)

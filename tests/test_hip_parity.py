@@ -379,6 +379,69 @@ def test_segment_rows_sum_vs_index_add(hip):
         assert float((out.double() - 2 * ref).abs().max()) <= 2 * tol
 
 
+def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch):
+    """Segments far longer than a 64-entry chunk (hub nodes) are cut into per-chunk partial sums; with the scratch buffer the library joins
+    them in chunk order (``segment_join_split_rows_kernel``), so the result is a function of the inputs alone: bit-identical from run to
+    run and whatever else keeps the GPU busy (replicas of the PE table that run the same update_pe on different GPUs must not drift
+    apart: ADVICE r2).  With time features (update_pe's form), plain, accumulating, and with a device-resident entry count; and equal,
+    up to the order of summation, to the float-atomic form (LSTEP_SEGMENT_ATOMICS=1) and to float64."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    torch.manual_seed(5)
+    n_rows, n_ent, nsrc, P, D = 9, 40000, 5000, 172, 100
+    table = torch.randn(nsrc, P, device=DEV)
+    seg = torch.sort(torch.randint(0, n_rows, (n_ent,), device=DEV)).values.to(torch.int32)          # ~4400 entries = 70 chunks per segment
+    row = torch.randint(0, nsrc, (n_ent,), device=DEV, dtype=torch.int32)
+    dt = torch.rand(n_ent, device=DEV) * 1e4
+    tw = torch.from_numpy(1.0 / 10 ** np.linspace(0, 9, D, dtype=np.float32)).to(DEV)
+    tb = torch.zeros(D, device=DEV)
+    live = torch.tensor([n_ent - 777], dtype=torch.int32, device=DEV)
+    noise = torch.randn(4096, 4096, device=DEV)
+    side = torch.cuda.Stream()
+
+    def run(mode, with_live, busy):
+        out = (torch.full if mode == 2 else torch.zeros)((n_rows, P + D), *((float("nan"),) if mode == 2 else ()), device=DEV)
+        if mode == 1:
+            out.fill_(0.5)
+        if busy:        # another stream saturates the GPU: the arrival order of the chunks' waves changes
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    noise @ noise
+        ws, wb = nat.segment_workspace(torch.device(DEV), n_ent, P, D)
+        nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(seg), nat.ptr(row), nat.ptr(dt), n_ent,
+                                             nat.ptr(out), P + D, mode, nat.ptr(live) if with_live else None, nat.ptr(ws), wb, nat.current_stream()))
+        torch.cuda.current_stream().wait_stream(side)
+        return out
+
+    for mode in (0, 1, 2):
+        for with_live in (False, True):
+            first = run(mode, with_live, False)
+            assert ws_used(nat, n_ent, P, D)
+            for rep in range(4):
+                again = run(mode, with_live, rep % 2 == 1)
+                assert torch.equal(first, again), f"accumulate={mode} live={with_live}: run {rep} differs by {float((first - again).abs().max()):.3e}"
+            m = n_ent - 777 if with_live else n_ent
+            ref = torch.zeros(n_rows, P + D, dtype=torch.float64, device=DEV)
+            ref[:, :P].index_add_(0, seg[:m].long(), table[row[:m].long()].double())
+            # (the argument dt * w is formed in float32, as the reference's Linear(1 -> D) forms it: models/modules.py:35)
+            ref[:, P:].index_add_(0, seg[:m].long(), torch.cos((dt[:m].unsqueeze(1) * tw + tb).double()))
+            if mode == 1:
+                ref += 0.5
+            err = float(((first.double() - ref).abs() / ref.abs().clamp(min=1.0)).max())
+            assert err <= 1e-4, err             # ~4400 fp32 terms per sum; entries whose sum nearly cancels are judged on the absolute scale 1
+    monkeypatch.setenv("LSTEP_SEGMENT_ATOMICS", "1")
+    assert nat.segment_workspace(torch.device(DEV), n_ent, P, D) == (None, 0)
+    out = torch.zeros((n_rows, P + D), device=DEV)
+    nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(seg), nat.ptr(row), nat.ptr(dt), n_ent,
+                                         nat.ptr(out), P + D, 0, None, None, 0, nat.current_stream()))
+    assert float(((out - run(0, False, False)).abs() / out.abs().clamp(min=1.0)).max()) <= 1e-4
+
+
+def ws_used(nat, n_ent, P, D):
+    return int(nat.load_library().lstep_segment_rows_sum_workspace(n_ent, P, D)) == ((n_ent + 63) // 64) * 2 * (P + D) * 4
+
+
 def test_large_tables_64bit_addressing_vs_oracle(hip):
     """4 M edges x 172 floats = 2.75 GB edge table: row offsets exceed 2^31 bytes, CSR built on the GPU.  A sample of rows of
     combining_pe_raw_feat (time_gap = 2000) is checked against the CPU oracle, sampled neighbourhoods bit-exact."""

@@ -212,6 +212,85 @@ def test_distributed_engine_on_rccl_world_size_1_reproduces_golden_trace(monkeyp
     _run(_gpu_worker, 1, "nccl", phase2 == "pull")
 
 
+def _hub_worker(rank, world, port, q):
+    """Power-law graph whose hub rows collect hundreds of update_pe messages per global batch (segments of many 64-entry chunks): the
+    single-GPU engine, the replicated form and the owner-sharded form on the same global batches."""
+    try:
+        torch.cuda.set_device(0)
+        _init(rank, world, port, "gloo")
+        dev = "cuda:0"
+        from lstep_amd.engine import EdgeStream, LstepEngine
+        from lstep_amd.optim import FusedAdam
+        from lstep_amd.parallel import DistributedLstep, all_gather_var
+        from lstep_amd.sampler import NeighborSampler
+        from lstep_amd.workload import build_hip_model
+        N, E, K, T, B, G, steps, first = 300, 40000, 16, 5, 256, 2000, 9, 30000
+        g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=131, zipf=1.3)
+        node_raw, edge_raw = synth.make_features(N, E, seed=132)
+        sd = synth.make_state_dict(K, T, seed=134)
+        stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], dev)
+        # the premise: some row receives far more than two chunks of messages in one batch (phase 1: its incident batch edges)
+        busiest = max(int(np.bincount(np.concatenate([g["src"][first + b * B:first + (b + 1) * B], g["dst"][first + b * B:first + (b + 1) * B]])).max())
+                      for b in range(steps))
+        assert busiest > 128, busiest        # more than two 64-entry chunks: three or more partial sums per row
+        results = {}
+        for form in ("single", "replicate", "pull"):
+            os.environ["LSTEP_PHASE2"] = form if form != "single" else "auto"
+            sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N, device=dev)
+            model = build_hip_model(node_raw, edge_raw, sampler, K, T, sd, dev)
+            model.train()
+            opt = FusedAdam(model.parameters(), lr=1e-4)
+            init = torch.from_numpy(synth.make_initial_pe(N, seed=133)).to(dev)
+            if form == "single":
+                run = LstepEngine(model[0], model[1], K, G)
+            else:
+                run = DistributedLstep(LstepEngine(model[0], model[1], K, G, make_ring=False), opt)
+                assert run.form == form
+            tables, losses = [], []
+            negs = [torch.from_numpy(synth.make_negatives(N, B, seed=140 + b)).to(dev) for b in range(steps)]
+            for b in range(steps):
+                lo = first + b * B
+                nxt = None
+                if b + 1 < steps:
+                    s2, d2, t2, _ = stream.batch(lo + B, lo + 2 * B)
+                    nxt = (s2, d2, t2, negs[b + 1])
+                out = run.train_iteration(opt, b, *stream.batch(lo, lo + B), negs[b], initial_pe=init, lookahead=nxt)
+                if form == "single":
+                    tables.append(run.ring.last().clone())
+                elif form == "replicate":
+                    tables.append(run.table.clone())
+                    # replicas: every rank ran the whole update on its own copy -- they must be BIT-identical (deterministic segment sums)
+                    cat, _ = all_gather_var(run.table.reshape(1, -1))
+                    assert torch.equal(cat[0], cat[-1]), f"replicas differ after batch {b}: {float((cat[0] - cat[-1]).abs().max()):.3e}"
+                else:
+                    tables.append(run.full_table())
+                    assert torch.equal(run.table[rank::world], tables[-1][rank::world])
+                if out is not None:
+                    losses.append(float(out["loss"]))
+            results[form] = (torch.stack(tables), np.asarray(losses))
+        (t1, l1), (t2, l2), (t3, l3) = results["single"], results["replicate"], results["pull"]
+        for name, (tt, ll) in (("replicate", (t2, l2)), ("pull", (t3, l3))):
+            d = float((tt - t1).abs().max())
+            assert d <= 5e-5, f"{name} vs single GPU: tables differ by {d:.3e}"
+            np.testing.assert_allclose(ll, l1, rtol=0, atol=2e-5, err_msg=name)
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+def test_hub_graph_two_ranks_replicas_and_shards_agree():
+    """Zipf-1.3 graph, global batch 256 over two ranks: hub rows receive > 128 messages per batch, i.e. segment sums of three or more
+    chunk partials -- the case in which float atomics made the replicas of the "replicate" form drift apart by ulps per step.
+    Nine training iterations each: the two replicas stay BIT-identical; the owner-sharded table ("pull", rows requested one step ahead),
+    assembled from its owners, and the replicated one both match the single-GPU engine on the same global batches (tables 5e-5,
+    losses 2e-5)."""
+    assert torch.cuda.is_available()
+    _run(_hub_worker, 2)
+
+
 @pytest.mark.gpu
 def test_bench_multi_rank_plumbing_gloo_two_ranks_one_gpu():
     """`bench.py --gpus 2` under torch.distributed.run (the driver's launch line), rehearsed on one GPU with gloo: the JSON
