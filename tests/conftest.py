@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is dense fp32 work on [rows, time_gap, 172] blocks.  A GPU box shows all of the host's cores (hundreds) but gives one
+    # GPU's share of them (16): torch's default of one thread per visible core ran the oracle 10-20x slower than 16 threads do
+    # (bench.py's cpu_baseline found the same).
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")

@@ -539,6 +539,9 @@ def test_c4_engine_training_iterations_step_by_step_vs_oracle(hip):
     parameter gradient of the whole 16 384-edge batch (the oracle in 64 row chunks)."""
     from lstep_amd.workload import build_workload, evolve_history
     from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 120 * 2 ** 30:
         pytest.skip("needs ~100 GB of HBM (the 70 GB history ring + the 13.8 GB edge table)")
@@ -582,8 +585,11 @@ def test_c5_rank0_of_8_footprint_and_kernels_vs_oracle(hip):
     from lstep_amd.parallel import ShardedSparseRing
     from lstep_amd.workload import build_workload
     from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model, float64_yardstick
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()          # (earlier tests of this process leave ~100 GB in the caching allocator)
     free, _ = torch.cuda.mem_get_info()
-    if free < 200 * 2 ** 30:
+    if free < 160 * 2 ** 30:
         pytest.skip("needs ~125 GB of HBM (68.8 GB edge table, 35 GB ring shard, CSR, tables) and a large-memory host")
     W, rank = 8, 0
     wl = build_workload("synth-4M-100M", DEV, seed=0, sharded=True)
