@@ -43,38 +43,77 @@ __device__ __forceinline__ void flush_run(float* __restrict__ o, const float4& a
     }
 }
 
-// Entries are sorted by segment; wave c owns entries [c * kChunk, (c + 1) * kChunk).  Rows are fetched 8 at a time
-// regardless of segment boundaries (memory-level parallelism does not depend on the run lengths); the accumulation
-// walks the entries in order and flushes a run whenever the segment id changes.  Only the first / last run of a chunk
-// can belong to a segment that continues in a neighbouring chunk: those are the runs flushed with atomics.
+// How many of the entries ent_seg[at .. at + 64) (forward) / ent_seg[at - 64 .. at) (backward) next to position `at` carry segment `sg`
+// without a gap: 0 .. 64, where 64 means "at least 64".  One wave-wide load.
+__device__ __forceinline__ int run_forward(const int32_t* __restrict__ ent_seg, int64_t at, int64_t n, int sg, int lane) {
+    const bool same = (at + lane < n) && ent_seg[at + lane] == sg;
+    const unsigned long long diff = ~__ballot(same);
+    return diff ? __builtin_ctzll(diff) : kWave;
+}
+__device__ __forceinline__ int run_backward(const int32_t* __restrict__ ent_seg, int64_t at, int sg, int lane) {
+    const bool same = (at - 1 - lane >= 0) && ent_seg[at - 1 - lane] == sg;
+    const unsigned long long diff = ~__ballot(same);
+    return diff ? __builtin_ctzll(diff) : kWave;
+}
+
+// Entries are sorted by segment; wave c is responsible for the 64-entry chunk [c * kChunk, (c + 1) * kChunk).  A segment of at most 64
+// entries that straddles a chunk boundary belongs WHOLLY to the chunk it starts in: that wave reads on past its chunk (up to 63 more
+// entries), the next wave skips them -- so ordinary segments are summed by one wave, in entry order, and stored with plain stores.  Only
+// segments of more than 64 entries (hub nodes) are cut at the chunk boundaries; their per-chunk partial sums are parked in `parts`
+// (deterministic form) or added with float atomics (`parts` == NULL).  Rows are fetched 8 at a time regardless of segment boundaries
+// (memory-level parallelism does not depend on the run lengths); the accumulation walks the entries in order and flushes a run whenever
+// the segment id changes.  chunk_flags[c] (with `parts`): bit 0 = slot 0 holds a partial that continues a cut segment, bit 1 = slot 1
+// holds the partial that STARTS a cut segment, bit 2 = the slot-0 run fills the chunk and the segment goes on.
 __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* __restrict__ table, int W, int ld_table,
                                                                    const float* __restrict__ tw, const float* __restrict__ tb, int D,
                                                                    const int32_t* __restrict__ ent_seg, const int32_t* __restrict__ ent_row,
                                                                    const float* __restrict__ ent_dt, int64_t num_entries,
                                                                    float* __restrict__ out, int ld_out, bool accumulate,
-                                                                   const int32_t* __restrict__ num_live, float* __restrict__ parts) {
+                                                                   const int32_t* __restrict__ num_live, float* __restrict__ parts,
+                                                                   int32_t* __restrict__ chunk_flags) {
     const int lane = lane_id();
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t e0 = chunk * kChunk;
-    // partial sums of split runs: two slots of W + D floats per chunk -- [0] the run that continues FROM the previous chunk, [1] the run that
-    // starts here and continues INTO the next one
+    // partial sums of cut segments: two slots of W + D floats per chunk
     float* const part0 = parts ? parts + (chunk * 2) * (int64_t)(W + D) : nullptr;
     if (num_live) {      // the entry list is padded: only its first min(*num_live, num_entries) entries count (lstep_sort_live_bounded)
         const int64_t live = *num_live;
         if (live < num_entries) num_entries = live;
     }
-    if (e0 >= num_entries) return;
+    if (e0 >= num_entries) {
+        if (chunk_flags && lane == 0) chunk_flags[chunk] = 0;
+        return;
+    }
     const int64_t e1 = (e0 + kChunk < num_entries) ? e0 + kChunk : num_entries;
-    const int seg_prev = e0 > 0 ? ent_seg[e0 - 1] : -1;            // segment that may spill in from the previous chunk
-    const int seg_next = e1 < num_entries ? ent_seg[e1] : -1;      // segment that may spill over into the next chunk
+    const int seg_first = ent_seg[e0], seg_last = ent_seg[e1 - 1];
+    // head: a segment that began in an earlier chunk.  Short (<= 64 entries in all): the earlier wave sums it, skip it here; long: cut.
+    int64_t b0 = e0;
+    bool head_cut = false;
+    if (e0 > 0 && ent_seg[e0 - 1] == seg_first) {
+        const int back = run_backward(ent_seg, e0, seg_first, lane);
+        const int lead = run_forward(ent_seg, e0, num_entries, seg_first, lane);
+        if (back + lead <= kChunk) b0 = e0 + lead; else head_cut = true;
+    }
+    // tail: a segment that goes on into the next chunk.  Short and begun here: read on to its end; long: cut.
+    int64_t b1 = e1;
+    bool tail_cut = false;
+    if (e1 < num_entries && ent_seg[e1] == seg_last) {
+        const int tail = run_backward(ent_seg, e1, seg_last, lane);
+        const int fwd = run_forward(ent_seg, e1, num_entries, seg_last, lane);
+        if (tail + fwd <= kChunk) b1 = e1 + fwd; else tail_cut = true;
+    }
+    if (chunk_flags && lane == 0)
+        chunk_flags[chunk] = (head_cut ? 1 : 0) | ((tail_cut && !(head_cut && seg_first == seg_last)) ? 2 : 0) |
+                             ((head_cut && tail_cut && seg_first == seg_last) ? 4 : 0);
+    if (b0 >= b1) return;      // (every entry of the chunk belongs to a short segment of the previous chunk)
     const bool wa = lane < (W >> 2);
-    const float w0 = lane < D ? tw[lane] : 0.f, b0 = lane < D ? tb[lane] : 0.f;
-    const float w1 = lane + kWave < D ? tw[lane + kWave] : 0.f, b1 = lane + kWave < D ? tb[lane + kWave] : 0.f;
+    const float w0 = lane < D ? tw[lane] : 0.f, b0f = lane < D ? tb[lane] : 0.f;
+    const float w1 = lane + kWave < D ? tw[lane + kWave] : 0.f, b1f = lane + kWave < D ? tb[lane + kWave] : 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float t0 = 0.f, t1 = 0.f;
     int cur = -1;  // segment of the open run
-    for (int64_t c0 = e0; c0 < e1; c0 += kWave) {
-        const int m = (int)((e1 - c0) < kWave ? (e1 - c0) : kWave);
+    for (int64_t c0 = b0; c0 < b1; c0 += kWave) {
+        const int m = (int)((b1 - c0) < kWave ? (b1 - c0) : kWave);
         int sg = 0, r = 0;
         float dt = 0.f;
         if (lane < m) {
@@ -97,9 +136,11 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                 if ((j + u) >= m) break;
                 const int sj = bcast_i32(sg, j + u);
                 if (sj != cur) {
-                    if (cur >= 0)
-                        flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane,
-                                  part0 ? part0 + (cur == seg_prev ? 0 : W + D) : nullptr);
+                    if (cur >= 0) {
+                        const bool cut_head = head_cut && cur == seg_first, cut = cut_head || (tail_cut && cur == seg_last);
+                        flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, !cut, accumulate, lane,
+                                  part0 ? part0 + (cut_head ? 0 : W + D) : nullptr);
+                    }
                     cur = sj;
                     acc = make_float4(0.f, 0.f, 0.f, 0.f);
                     t0 = t1 = 0.f;
@@ -107,60 +148,60 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                 if (wa) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
                 if (D > 0) {
                     const float dj = bcast_f32(dt, j + u);
-                    if (lane < D) t0 += time_feat(dj, w0, b0);
-                    if (lane + kWave < D) t1 += time_feat(dj, w1, b1);
+                    if (lane < D) t0 += time_feat(dj, w0, b0f);
+                    if (lane + kWave < D) t1 += time_feat(dj, w1, b1f);
                 }
             }
         }
     }
-    if (cur >= 0)
-        flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, cur != seg_prev && cur != seg_next, accumulate, lane,
-                  part0 ? part0 + (cur == seg_prev ? 0 : W + D) : nullptr);
+    if (cur >= 0) {
+        const bool cut_head = head_cut && cur == seg_first, cut = cut_head || (tail_cut && cur == seg_last);
+        flush_run(out + (int64_t)cur * ld_out, acc, t0, t1, W, D, !cut, accumulate, lane, part0 ? part0 + (cut_head ? 0 : W + D) : nullptr);
+    }
 }
 
-// Second pass of the deterministic form: one wave per chunk boundary.  The wave at the boundary behind the chunk in which a split segment
-// STARTS adds that segment's parked partials in chunk order and writes (or, `accumulate`, adds to) its row: the only writer of the row.
-__global__ __launch_bounds__(kBlock) void segment_join_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t num_entries, int W, int D,
-                                                                         const float* __restrict__ parts, float* __restrict__ out, int ld_out,
-                                                                         bool accumulate, const int32_t* __restrict__ num_live) {
+// Second pass of the deterministic form: one LANE per chunk looks at the chunk's flags; the rare chunk in which a cut (> 64 entries) segment
+// starts has its wave add that segment's parked partials in chunk order and write (or, `accumulate`, add to) its row -- the only writer of
+// the row.  A launch over a list without hub segments is ~chunks / 64 waves that read one flag each.
+__global__ __launch_bounds__(kBlock) void segment_join_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t chunks, int W, int D,
+                                                                         const float* __restrict__ parts, const int32_t* __restrict__ chunk_flags,
+                                                                         float* __restrict__ out, int ld_out, bool accumulate) {
     const int lane = lane_id();
-    const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block() + 1;   // boundary between chunk c - 1 and chunk c
-    const int64_t e = c * kChunk;
-    if (num_live) {
-        const int64_t live = *num_live;
-        if (live < num_entries) num_entries = live;
-    }
-    if (e >= num_entries) return;
-    const int sg = ent_seg[e];
-    if (ent_seg[e - 1] != sg) return;                                               // nothing continues across this boundary
-    if (c > 1 && ent_seg[(c - 1) * kChunk - 1] == sg) return;                      // the segment started earlier: that boundary's wave joins it
+    const int64_t c_lane = ((int64_t)blockIdx.x * kWavesPerBlock + wave_in_block()) * kWave + lane;
+    const int fl = c_lane < chunks ? chunk_flags[c_lane] : 0;
+    unsigned long long todo = __ballot((fl & 2) != 0);
     const int ldp = W + D;
     const bool wa = lane < (W >> 2);
-    const float* p = parts + ((c - 1) * 2 + 1) * (int64_t)ldp;                      // the start chunk's last run
-    float4 acc = wa ? ld4(p + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float t0 = lane < D ? p[W + lane] : 0.f, t1 = lane + kWave < D ? p[W + lane + kWave] : 0.f;
-    for (int64_t j = c;; ++j) {
-        p = parts + (j * 2) * (int64_t)ldp;                                         // chunk j's first run continues the segment
-        if (wa) { const float4 v = ld4(p + lane * 4); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-        if (lane < D) t0 += p[W + lane];
-        if (lane + kWave < D) t1 += p[W + lane + kWave];
-        const int64_t nx = (j + 1) * kChunk;
-        if (nx >= num_entries || ent_seg[nx] != sg) break;
-    }
-    float* o = out + (int64_t)sg * ld_out;
-    if (accumulate) {
-        if (wa) { const float4 old = ld4(o + lane * 4); st4(o + lane * 4, make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w)); }
-        if (lane < D) o[W + lane] += t0;
-        if (lane + kWave < D) o[W + lane + kWave] += t1;
-    } else {
-        if (wa) st4(o + lane * 4, acc);
-        if (lane < D) o[W + lane] = t0;
-        if (lane + kWave < D) o[W + lane + kWave] = t1;
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t c = c_lane - lane + src;                                      // the chunk in which a cut segment starts
+        const int sg = ent_seg[(c + 1) * kChunk];                                   // (it goes on into the next chunk: that entry exists)
+        const float* p = parts + (c * 2 + 1) * (int64_t)ldp;
+        float4 acc = wa ? ld4(p + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float t0 = lane < D ? p[W + lane] : 0.f, t1 = lane + kWave < D ? p[W + lane + kWave] : 0.f;
+        for (int64_t j = c + 1; j < chunks; ++j) {
+            p = parts + (j * 2) * (int64_t)ldp;                                     // chunk j's first run continues the segment
+            if (wa) { const float4 v = ld4(p + lane * 4); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            if (lane < D) t0 += p[W + lane];
+            if (lane + kWave < D) t1 += p[W + lane + kWave];
+            if (!(chunk_flags[j] & 4)) break;
+        }
+        float* o = out + (int64_t)sg * ld_out;
+        if (accumulate) {
+            if (wa) { const float4 old = ld4(o + lane * 4); st4(o + lane * 4, make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w)); }
+            if (lane < D) o[W + lane] += t0;
+            if (lane + kWave < D) o[W + lane + kWave] += t1;
+        } else {
+            if (wa) st4(o + lane * 4, acc);
+            if (lane < D) o[W + lane] = t0;
+            if (lane + kWave < D) o[W + lane + kWave] = t1;
+        }
     }
 }
 
-// Pre-pass for an UNINITIALISED output: only the rows of segments that straddle a chunk boundary are accumulated with atomics and need
-// zeros; every other row that owns entries is written whole by one wave.  One thread per chunk boundary.
+// Pre-pass for an UNINITIALISED output in the atomic form: only the rows of CUT segments (more than 64 entries, see above) are accumulated
+// with atomics and need zeros; every other row that owns entries is written whole by one wave.  One wave per chunk boundary.
 __global__ __launch_bounds__(kBlock) void segment_zero_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t num_entries,
                                                                          float* __restrict__ out, int ld_out, int width,
                                                                          const int32_t* __restrict__ num_live) {
@@ -174,6 +215,7 @@ __global__ __launch_bounds__(kBlock) void segment_zero_split_rows_kernel(const i
     if (e >= num_entries) return;
     const int sg = ent_seg[e];
     if (ent_seg[e - 1] != sg) return;
+    if (run_backward(ent_seg, e, sg, lane) + run_forward(ent_seg, e, num_entries, sg, lane) <= kChunk) return;   // short: one wave sums it
     float* o = out + (int64_t)sg * ld_out;
     for (int k = lane * 4; k < width; k += kWave * 4) st4(o + k, make_float4(0.f, 0.f, 0.f, 0.f));
 }
@@ -253,8 +295,9 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
 using namespace lstep;
 
 extern "C" int64_t lstep_segment_rows_sum_workspace(int64_t num_entries, int32_t width, int32_t time_dim) {
-    if (num_entries <= kChunk) return 0;       // one chunk: nothing can be split
-    return ((num_entries + kChunk - 1) / kChunk) * 2 * (int64_t)(width + time_dim) * (int64_t)sizeof(float);
+    if (num_entries <= kChunk) return 0;       // one chunk: nothing can be cut
+    const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
+    return chunks * 2 * (int64_t)(width + time_dim) * (int64_t)sizeof(float) + ((chunks * (int64_t)sizeof(int32_t) + 15) / 16) * 16;
 }
 
 extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
@@ -274,20 +317,22 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     const unsigned bgrid = (unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock);
     float* parts = nullptr;
-    if (workspace && chunks > 1) {       // deterministic form: split segments are joined in chunk order by a second pass
+    int32_t* flags = nullptr;
+    if (workspace && chunks > 1) {       // deterministic form: cut segments are joined in chunk order by a second pass
         if (((uintptr_t)workspace & 15) || workspace_bytes < lstep_segment_rows_sum_workspace(num_entries, width, time_dim))
             return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: workspace too small or misaligned (need %lld bytes, 16-byte aligned)",
                              (long long)lstep_segment_rows_sum_workspace(num_entries, width, time_dim));
         parts = (float*)workspace;
+        flags = (int32_t*)(parts + chunks * 2 * (int64_t)(width + time_dim));
     }
     if (!parts && accumulate == 2 && chunks > 1)   // uninitialised output, atomic form: zero just the rows the atomics will add to
         hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3(bgrid), dim3(kBlock), 0, (hipStream_t)stream, ent_seg, num_entries, out,
                            (int)ld_out, (int)(width + time_dim), num_live);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts, flags);
     if (parts)
-        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3(bgrid), dim3(kBlock), 0, (hipStream_t)stream, ent_seg, num_entries, (int)width,
-                           (int)time_dim, parts, out, (int)ld_out, accumulate == 1, num_live);
+        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                           ent_seg, chunks, (int)width, (int)time_dim, parts, flags, out, (int)ld_out, accumulate == 1);
     return check_launch("segment_rows_sum_kernel");
 }
 
@@ -306,17 +351,19 @@ extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, in
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     float* parts = nullptr;
+    int32_t* flags = nullptr;
     if (workspace && chunks > 1) {
         if (((uintptr_t)workspace & 15) || workspace_bytes < lstep_segment_rows_sum_workspace(num_entries, width, 0))
             return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: workspace too small or misaligned");
         parts = (float*)workspace;
+        flags = (int32_t*)(parts + chunks * 2 * (int64_t)width);
     }
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table,
                        (const float*)nullptr, (const float*)nullptr, 0, ent_seg, ent_row, (const float*)nullptr, num_entries, out, (int)ld_out,
-                       accumulate == 1, num_live, parts);
+                       accumulate == 1, num_live, parts, flags);
     if (parts)
-        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                           (hipStream_t)stream, ent_seg, num_entries, (int)width, 0, parts, out, (int)ld_out, accumulate == 1, num_live);
+        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                           ent_seg, chunks, (int)width, 0, parts, flags, out, (int)ld_out, accumulate == 1);
     return check_launch("segment_rows_sum_kernel<live>");
 }
 

@@ -124,9 +124,12 @@ class HistoryRing:
         self._dev_mirror = self.start
 
     def replay_tick(self):
-        """A captured iteration was replayed: its kernels advanced the device position; the host mirrors follow."""
+        """A captured iteration was replayed: its kernels advanced the device position; the host mirrors follow.  The slide of its commit
+        is pending (the next replay applies it first thing, ``early_advance``; a launch-by-launch iteration settles it at its start)."""
         self.start = (self.start + 1) % self.S
         self._dev_mirror = self.start
+        if self.sparse:
+            self._advance = self.start
 
     def begin_slot(self, slot: int = None, all_changed: bool = False):
         """Reset the change bits of the snapshot about to be built (on the current stream): nothing changed yet, or everything."""
@@ -213,8 +216,12 @@ class HistoryRing:
         """Sparse rings: bring ``oldest`` to the window's new first snapshot after a ``commit`` that slid the window.  Call when the
         current stream has been given everything that still reads the OLD window (the FFT filter's backward pass): the update runs on
         the copy stream behind that point.  Readers of the NEW window need not wait for it -- they take the rows it moves from the
-        first slot itself (``lstep_history_filter_runs_*``) -- only for the update before it (``wait_window``)."""
+        first slot itself (``lstep_history_filter_runs_*``) -- only for the update before it (``wait_window``).
+        Inside a captured iteration nothing is launched here: the slide stays pending and is applied at the START of the next replay
+        (``early_advance``), beside the forward pass instead of between the backward pass and the optimiser step."""
         if not self.sparse or self._advance is None:
+            return
+        if torch.cuda.is_current_stream_capturing():
             return
         slot, self._advance = self._advance, None
         dev = self.buf.device
@@ -229,13 +236,29 @@ class HistoryRing:
                                                                       nat.current_stream()))
             ev = torch.cuda.Event()
             ev.record()
-        if torch.cuda.is_current_stream_capturing():
-            # inside a captured iteration the graph orders everything: the caller joins the advance stream before the capture ends,
-            # and replays follow each other on one stream, so the next window read needs no event
-            torch.cuda.current_stream(dev).wait_event(ev)
-            self._advanced = [None, None]
-        else:
-            self._advanced = [self._advanced[1], ev]
+        self._advanced = [self._advanced[1], ev]
+
+    def early_advance(self):
+        """Captured iterations: apply the slide the PREVIOUS iteration's commit left pending, as the first thing of this one.  It only
+        writes rows whose change bit of the window's first slot is set, and every reader of this iteration's window takes exactly those
+        rows from the slot itself, so it may run beside the whole forward and backward pass; the caller joins its stream before the
+        capture ends, i.e. before the next replay's advance.  At capture time the launch-by-launch iteration before has already applied
+        its slide: the same rows are copied once more (idempotent)."""
+        assert self.sparse and torch.cuda.is_current_stream_capturing()
+        slot = self._advance if self._advance is not None else self.start
+        assert slot == self.start, "the pending slide is the window's first slot"
+        self._advance = None
+        dev = self.buf.device
+        here = torch.cuda.Event()
+        here.record()
+        side = self.advance_stream or self._copy_stream
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            side.wait_event(here)
+            ref = self._ref(slot)
+            nat.check(nat.load_library().lstep_history_advance_oldest(nat.ptr(self.oldest), nat.ptr(self.buf if ref is not None else self.buf[slot]),
+                                                                      self.P, self.P, nat.ptr(self.mask), self.words, slot, self.rows, ref,
+                                                                      nat.current_stream()))
+        self._advanced = [None, None]
 
     def wait_window(self):
         """Make the current stream wait until the window can be read: ``oldest`` is at most one slide behind."""
@@ -515,7 +538,7 @@ class GraphedTrainStep:
                 self.out = eng._train_iteration(self.optimizer, batch_idx, self.src, self.dst, self.ts, self.eid, self.neg, None, None)
             main = torch.cuda.current_stream(eng.device)
             if eng.use_aux:
-                main.wait_stream(_aux_stream(eng.device))
+                main.wait_stream(_aux_stream(eng.device))      # (the backward pass's side stream was joined by join_aux_stream already)
             main.wait_stream(eng._update_stream)
         self.graph = graph
         graph.replay()      # capturing records the launches without running them: this replay IS the iteration
@@ -689,12 +712,17 @@ class LstepEngine:
         initialisation)."""
         from .optim import FusedAdam
         ring = self.ring
-        return (self.use_step_graph and batch_idx > 0 and self.device_counts and ring.len == ring.T and ring._advance is None
+        return (self.use_step_graph and batch_idx > 0 and self.device_counts and ring.len == ring.T
                 and isinstance(optimizer, FusedAdam) and self._steady_eager_steps >= 2 and self.overlap_update and self.fused_loss)
 
     def _train_iteration(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
         bb, ring = self.backbone, self.ring
         out, loss = None, None
+        if ring.sparse:
+            if torch.cuda.is_current_stream_capturing():
+                ring.early_advance()         # the previous iteration's slide: beside this iteration instead of in front of its optimiser step
+            else:
+                ring.apply_advance()         # (a slide left pending by a replayed iteration; nothing reads the old window any more)
         if (self._ring_on_device and ring.dev_start is None and ring.sparse and ring.len == ring.T and ring._advance is None):
             ring.position_on_device()
         bb.prepare_step()
@@ -817,6 +845,8 @@ class LstepEngine:
     # ---- evaluate_model_utils.py:38-142 (call under torch.no_grad())
     def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
         bb, ring = self.backbone, self.ring
+        if ring.sparse:
+            ring.apply_advance()             # (a slide left pending by a replayed training iteration)
         if (self._ring_on_device and ring.dev_start is None and ring.sparse and ring.len == ring.T and ring._advance is None):
             ring.position_on_device()
         on_device = self.device_counts and ring.len > 0

@@ -447,6 +447,7 @@ class _TailWeightsReplay(torch.autograd.Function):
 
 
 _AUX_STREAMS = {}
+_SIDE_STREAMS = {}        # device -> stream for HBM-bound parameter-gradient work that should not queue behind the matrix-core products
 _PENDING_AUX_GRADS = {}   # device -> [(parameter, gradient part produced on the auxiliary stream)]: added in LSTEP.join_aux_stream
 
 
@@ -457,6 +458,17 @@ def _aux_stream(dev):
     st = _AUX_STREAMS.get(dev)
     if st is None:
         st = _AUX_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _side_stream(dev):
+    """Third stream of the backward pass: the edge-row re-gather behind d(edge_agg.weight) (HBM-bound, 0.3 ms at the bench shape, no
+    consumer before the optimiser).  On the auxiliary stream it would wait for ~1 ms of weight-gradient products; beside them it fills
+    the memory system the matrix-core kernels leave idle.  Joined by ``LSTEP.join_aux_stream``."""
+    dev = torch.device(dev)
+    st = _SIDE_STREAMS.get(dev)
+    if st is None:
+        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -910,6 +922,7 @@ class _GatherAggregate(torch.autograd.Function):
             else:
                 grad_rows = torch.zeros(ctx.pe_shape, dtype=torch.float32, device=dev)
         tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
+        g_w = None
         if ctx.explicit is not None and (g_edge is not None or grad_rows is not None or hits is not None):
             l1, lg, l3 = ctx.explicit
             num_rows = int(mod.node_raw_features.shape[0])
@@ -925,25 +938,33 @@ class _GatherAggregate(torch.autograd.Function):
                                                             mod.ld_edge, mod.ld_pe, ctx.ld_self, nat.ptr(slot_of) if use_slot else None, None,
                                                             nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
         elif g_edge is not None or grad_rows is not None or hits is not None:
+            # Two consumers with very different urgency share this kernel: the spliced-row HITS (a few index reads per row) head the
+            # critical chain sort -> segment sums -> history-filter backward, while the slot dots re-read 688 * k bytes of edge rows per row
+            # (0.3 ms at the bench shape) for ONE parameter gradient, d(edge_agg.weight), that nothing waits for before the optimiser.  In the
+            # engine's iteration (auxiliary stream on) they are launched apart: hits here, the slot dots on the auxiliary stream.
+            aux_split = (g_edge is not None and hits is not None and mod.__dict__.get("aux_wgrad_stream", False)
+                         and mod.edge_agg.weight.grad is None and os.environ.get("LSTEP_NO_SPLIT_GATHER_BWD") != "1")
             with torch.cuda.device(dev):
                 nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
-                                                         nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, nat.ptr(g_edge), nat.ptr(g_pe),
-                                                         nat.ptr(g_self), mod.ld_edge, mod.ld_pe, ctx.ld_self,
-                                                         nat.ptr(slot_of) if use_slot else None, nat.ptr(slot_dot),
+                                                         nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, None if aux_split else nat.ptr(g_edge),
+                                                         nat.ptr(g_pe), nat.ptr(g_self), mod.ld_edge, mod.ld_pe, ctx.ld_self,
+                                                         nat.ptr(slot_of) if use_slot else None, None if aux_split else nat.ptr(slot_dot),
                                                          nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
-        g_w = None
-        if slot_dot is not None and mod.__dict__.get("aux_wgrad_stream", False) and mod.edge_agg.weight.grad is None:
-            # d(edge_agg.weight) = column sums of the slot dots: a parameter gradient, nothing in the backward chain waits for it, so the
-            # reduction (a slow shape for the library: 49 152 x 20 -> 20) goes to the auxiliary stream; join_aux_stream() orders its reader
-            # (.grad is still None, so autograd will adopt the tensor as it is, without touching it on this stream)
-            aux = _aux_stream(dev)
-            done = torch.cuda.Event()
-            done.record()
-            with torch.cuda.stream(aux):
-                aux.wait_event(done)
-                g_w = slot_dot.sum(dim=0)
-            slot_dot.record_stream(aux)
-            g_w.record_stream(torch.cuda.current_stream(dev))
+            if aux_split:
+                aux = _side_stream(dev)
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(aux), torch.cuda.device(dev):
+                    aux.wait_event(ready)
+                    nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
+                                                             nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, nat.ptr(g_edge), None, None,
+                                                             mod.ld_edge, mod.ld_pe, ctx.ld_self, None, nat.ptr(slot_dot), None, None,
+                                                             nat.current_stream()))
+                    g_w = slot_dot.sum(dim=0)
+                for t_ in (g_edge, slot_dot, ids, times, count):
+                    t_.record_stream(aux)
+                g_w.record_stream(torch.cuda.current_stream(dev))
+        g_w_done = g_w is not None
         _flush_deferred(dev)     # the critical kernel is out: now launch the postponed auxiliary-stream work
         if use_slot:
             grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self, ctx.self_groups)
@@ -1272,6 +1293,8 @@ class LSTEP(nn.Module):
         """Make the current stream wait for the weight-gradient work that ``aux_wgrad_stream = True`` put on the auxiliary stream
         (call after ``backward()`` and before anything reads the parameter gradients)."""
         _flush_deferred()
+        for dev, st in _SIDE_STREAMS.items():
+            torch.cuda.current_stream(dev).wait_stream(st)
         for dev, st in _AUX_STREAMS.items():     # keyed by the tensors' device (always indexed, unlike a bare "cuda")
             torch.cuda.current_stream(dev).wait_stream(st)
             for p, g in _PENDING_AUX_GRADS.pop(dev, []):     # (see _TailWeightsReplay._backward)

@@ -439,7 +439,8 @@ def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch):
 
 
 def ws_used(nat, n_ent, P, D):
-    return int(nat.load_library().lstep_segment_rows_sum_workspace(n_ent, P, D)) == ((n_ent + 63) // 64) * 2 * (P + D) * 4
+    chunks = (n_ent + 63) // 64
+    return int(nat.load_library().lstep_segment_rows_sum_workspace(n_ent, P, D)) == chunks * 2 * (P + D) * 4 + (chunks * 4 + 15) // 16 * 16
 
 
 def test_large_tables_64bit_addressing_vs_oracle(hip):
@@ -1435,7 +1436,7 @@ def _sync_engine_state(src, dst):
             pd.copy_(ps)
     o_d.load_state_dict(o_s.state_dict())
     rs, rd = e_s.ring, e_d.ring
-    assert (rs.start, rs.len, rs._advance) == (rd.start, rd.len, rd._advance)
+    assert (rs.start, rs.len) == (rd.start, rd.len)      # (a replayed iteration leaves its slide pending: `oldest` is copied below)
     for name in ("buf", "mask", "table", "oldest"):
         getattr(rd, name).copy_(getattr(rs, name))
     torch.cuda.synchronize()
