@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 29
+#define LSTEP_ABI_VERSION 30
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -303,8 +303,8 @@ int lstep_sort_live_bounded(const int32_t* keys, int64_t n, int32_t key_bits, in
                             int64_t workspace_bytes, int32_t* sorted_keys, int32_t* order, int32_t* live_index, int32_t* count, void* stream);
 /* lstep_segment_rows_sum (no time part, accumulate 0 / 1) over such a padded list: only the first min(*num_live, num_entries) entries count. */
 int lstep_segment_rows_sum_live(const float* table, int32_t width, int32_t ld_table, const int32_t* ent_seg, const int32_t* ent_row,
-                                int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate, void* workspace,
-                                int64_t workspace_bytes, void* stream);
+                                int32_t row_div, int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate,
+                                void* workspace, int64_t workspace_bytes, void* stream);      /* table row of entry e = ent_row[e] / row_div */
 /* out[keys[e], :width] += table[e / div, :width] for e = live_index[i], i in [capacity, *count). */
 int lstep_scatter_add_overflow(float* out, int32_t width, int32_t ld_out, const int32_t* keys, const int32_t* live_index, const int32_t* count,
                                int64_t capacity, int32_t div, const float* table, int32_t ld_table, void* stream);
@@ -409,6 +409,23 @@ int lstep_fft_coef_bwd(const float* grad_coef, const float* filter_weight, const
 int lstep_small_gemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c, int64_t sc_i,
                      int64_t sc_j, int32_t m, int32_t n, int32_t k, float alpha, float beta, void* stream);
 
+/* The weight composition of the dense tail around those products (lstep_amd/model.py `_combined_tail`: out_node_emb . node_mlp . edge_mlp_2
+ * pre-multiplied, edge_agg folded into edge_mlp_1's bias, models/LSTEP.py:161-170,219,240-247,264), everything that is not a matrix product in
+ * one launch per direction.  dims = {F, D+F, P, P+D, Ce, Fn, Cp, Pp, K} (the widths and their 16-aligned paddings, K = num_neighbors).
+ * pack: params = the 16 parameter tensors {edge_mlp_1.weight, .bias, edge_agg.weight, .bias, edge_mlp_2.weight, .bias, node_mlp.weight, .bias,
+ *   out_node_emb.weight, .bias, self_update_neighbor_pe.weight, .bias, pe_neighbor_mlp_1.weight, .bias, pe_neighbor_mlp_2.weight, .bias}
+ *   (contiguous fp32), M [F, D+F] = Wo_a Wn_b.  flat = {W1p [Ce,Ce], b1p [Ce], Wn1p [Pp,Cp], bn1p [Pp], Wq [Pp,2Pp], bq [Pp], Wall [Fn,Fn+Ce+Pp],
+ *   const [Fn]} back to back, with Wall[:F,:F] and Wall[:F,Fn:Fn+D+F] already holding the products Wo_a Wn_a and M W2; flat_t = the transposes
+ *   of the four matrices back to back; a_sum [1] = sum of edge_agg.weight.
+ * unpack (the hand-derived backward): grads_in = gradients of the 8 blocks of flat; fwd = {edge_mlp_1.bias, edge_mlp_2.bias, node_mlp.bias,
+ *   out_node_emb.weight, M, a_sum}; dM [F, D+F] holds dA2 W2^T on entry and dA2 W2^T + dc b2^T on return; grads_out = dense gradients
+ *   {edge_mlp_1.weight, .bias, edge_agg.weight, .bias, edge_mlp_2.bias, node_mlp.bias, out_node_emb.weight (= [dc bn^T | d Wo_b]: the caller
+ *   adds dA1 Wn_a^T + dM Wn_b^T to the first block), .bias, self_update_neighbor_pe.weight, .bias, pe_neighbor_mlp_1.weight, .bias,
+ *   pe_neighbor_mlp_2.weight, .bias}. */
+int lstep_tail_weights_pack(const float* const* params, const float* M, const int32_t* dims, float* flat, float* flat_t, float* a_sum, void* stream);
+int lstep_tail_weights_unpack(const float* const* grads_in, const float* const* fwd, float* const* grads_out, float* dM, const int32_t* dims,
+                              void* stream);
+
 /* U1 / U2 -- the message lists of update_pe, one kernel each (models/LSTEP.py:277-290, 305-324).
  * _p1: order int32 [num_entries <= 2 batch] = positions of cat[src, dst] grouped by receiving endpoint (lstep_group_by_key);
  *      ent_row[e] = the other endpoint, ent_dt[e] = float(double(now32) - times[.]) with now32 a float32 DEVICE scalar (the reference
@@ -418,6 +435,14 @@ int lstep_small_gemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b,
  * _p2: for the n_real grouped live slots (order / seg from lstep_group_by_key on those keys): ent_row = bn[slot / K], ent_dt = now32 -
  *      nt[slot] (float32 - float32, LSTEP.py:314), ent_seg = seg + shift; touched int64 [shift + nseg] = [0 if shift] + uniq[:nseg]
  *      (shift = 1 when padding slots exist: row 0 is updated too and takes segment 0, LSTEP.py:317-324). */
+/* What an engine iteration derives from its batch first, in one launch: ids3 = cat[src, dst, neg] (neg may be NULL: two blocks), t3 = the times
+ * repeated per block (train_LSTEP_link_prediction.py:233-251), keys = int32 cat[src, dst] (the grouping keys of train:221-222) and
+ * now32[0] = float32(max times) (models/LSTEP.py:277).  All device pointers; ids3 / t3 hold 3 * batch entries. */
+int lstep_batch_prepare(const int64_t* src, const int64_t* dst, const int64_t* neg, const double* times, int64_t batch, int64_t* ids3, double* t3,
+                        int32_t* keys, float* now32, void* stream);
+/* row[:width] = the block partials of lstep_padding_rows_sum added in block order, row[width:row_width] = 0 (update_pe phase 2: the padding
+ * row's aggregate, models/LSTEP.py:316-322). */
+int lstep_padding_rows_finish(const float* partial, int64_t blocks, int32_t width, float* row, int32_t row_width, void* stream);
 int lstep_update_entries_p1(const int32_t* order, int64_t num_entries, const int64_t* src, const int64_t* dst, const double* times,
                             const float* now32, int64_t batch, int32_t* ent_row, float* ent_dt, void* stream);
 int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank, int32_t* keys, void* stream);

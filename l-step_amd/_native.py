@@ -15,11 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
-SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip", "update.hip", "adam.hip"]
+SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip", "update.hip", "adam.hip",
+           "compose.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 29
+ABI_VERSION = 30
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -102,7 +103,9 @@ SIGNATURES = {
     "lstep_segment_rows_sum": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _I32, _P, _P, _I64, _P]),
     "lstep_sort_live_bounded_workspace": (_I64, [_I64, _I64, _I32]),
     "lstep_sort_live_bounded": (C.c_int, [_P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P]),
-    "lstep_segment_rows_sum_live": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P]),
+    "lstep_segment_rows_sum_live": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I64, _P, _P, _I32, _I32, _P, _I64, _P]),
+    "lstep_batch_prepare": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
+    "lstep_padding_rows_finish": (C.c_int, [_P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_add_overflow": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
@@ -130,6 +133,8 @@ SIGNATURES = {
     "lstep_linear_wgrad_workspace": (_I64, [_I64, _I32, _I32]),
     "lstep_linear_wgrad": (C.c_int, [_P, _I32, _P, _I32, _I64, _I32, _I32, _P, _I32, _P, _P, _I64, _P]),
     "lstep_small_gemm": (C.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.c_float, C.c_float, _P]),
+    "lstep_tail_weights_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "lstep_tail_weights_unpack": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "lstep_tail_fwd": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "lstep_tail_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),
 }

@@ -49,41 +49,45 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // own batch sizes (200 / 600 edges: 400 / 1200 endpoints) otherwise pay for ~12 dependent library launches of a few microseconds each at
 // the very start of every iteration.  Same outputs as the multi-launch path (the sort is stable in both).
 constexpr int kSmallThreads = 256;
-template <int ITEMS>
-__global__ __launch_bounds__(kSmallThreads) void group_small_kernel(const int32_t* __restrict__ keys, int n, int bits, int32_t limit,
-                                                                    int32_t* __restrict__ sorted_keys, int32_t* __restrict__ order,
-                                                                    int32_t* __restrict__ seg, int32_t* __restrict__ uniq,
-                                                                    int32_t* __restrict__ summary) {
-    using Sort = rocprim::block_radix_sort<uint32_t, kSmallThreads, ITEMS, int32_t>;
-    using Scan = rocprim::block_scan<int32_t, kSmallThreads>;
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void group_small_kernel(const int32_t* __restrict__ keys, int n, int bits, int32_t limit,
+                                                              int32_t* __restrict__ sorted_keys, int32_t* __restrict__ order,
+                                                              int32_t* __restrict__ seg, int32_t* __restrict__ uniq,
+                                                              int32_t* __restrict__ summary) {
+    using Sort = rocprim::block_radix_sort<uint32_t, THREADS, ITEMS, int32_t>;
+    using Scan = rocprim::block_scan<int32_t, THREADS>;
     __shared__ union {
         typename Sort::storage_type sort;
         typename Scan::storage_type scan;
+        uint32_t sk[THREADS * ITEMS + 2];       // the sorted keys, shifted by one: sk[i + 1] = key of entry i (written after the sort is done with its storage)
     } tmp;
-    __shared__ uint32_t sk[kSmallThreads * ITEMS + 1];
     const int t = threadIdx.x;
     uint32_t k[ITEMS];
     int32_t v[ITEMS];
+    // padding sorts last: one bit above the real keys when there is room (then the sort needs bits + 1 bit ranges, not 32)
+    const uint32_t pad = bits < 31 ? (1u << bits) : 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int idx = t * ITEMS + j;                     // blocked arrangement: stability = input order
-        k[j] = idx < n ? (uint32_t)keys[idx] : 0xFFFFFFFFu;   // padding sorts last (real keys are non-negative int32)
+        k[j] = idx < n ? (uint32_t)keys[idx] : pad;
         v[j] = idx;
     }
-    // pad keys have bits above `bits` set; sort them on one more bit range so that they stay behind every real key
-    Sort().sort(k, v, tmp.sort, 0u, 32u);
-    (void)bits;
+    Sort().sort(k, v, tmp.sort, 0u, bits < 31 ? (unsigned)(bits + 1) : 32u);
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) sk[t * ITEMS + j + 1] = k[j];
-    if (t == 0) sk[0] = 0xFFFFFFFFu;
+    for (int j = 0; j < ITEMS; ++j) tmp.sk[t * ITEMS + j + 1] = k[j];
+    if (t == 0) { tmp.sk[0] = 0xFFFFFFFFu; tmp.sk[THREADS * ITEMS + 1] = 0xFFFFFFFFu; }
     __syncthreads();
     int32_t flag[ITEMS], local = 0;
+    uint32_t next[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int idx = t * ITEMS + j;
-        flag[j] = (idx > 0 && idx < n && sk[idx] != k[j]) ? 1 : 0;     // sk[idx] = the key before entry idx
+        flag[j] = (idx > 0 && idx < n && tmp.sk[idx] != k[j]) ? 1 : 0;     // sk[idx] = the key before entry idx
+        next[j] = idx + 1 < n ? tmp.sk[idx + 2] : 0xFFFFFFFFu;             // the key after entry idx
         local += flag[j];
     }
+    __syncthreads();                                       // (the scan reuses the storage)
     int32_t before = 0;
     Scan().exclusive_scan(local, before, 0, tmp.scan);
     int32_t run = before;
@@ -99,10 +103,72 @@ __global__ __launch_bounds__(kSmallThreads) void group_small_kernel(const int32_
             if (idx == 0 || flag[j]) uniq[run] = key;
             if (idx == n - 1) summary[0] = run + 1;
             const bool below = key < limit;
-            const uint32_t next = idx + 1 < n ? sk[idx + 2] : 0xFFFFFFFFu;     // the key after entry idx
-            if (below && (idx == n - 1 || (int64_t)next >= (int64_t)limit)) { summary[1] = idx + 1; summary[2] = run + 1; }
+            if (below && (idx == n - 1 || (int64_t)next[j] >= (int64_t)limit)) { summary[1] = idx + 1; summary[2] = run + 1; }
             if (idx == 0 && !below) { summary[1] = 0; summary[2] = 0; }
         }
+    }
+}
+
+// lstep_sort_live_bounded for up to 65536 keys and a capacity of up to 32768: compaction of the live (non-negative) keys, sentinel
+// padding and the stable sort in ONE workgroup instead of ~9 dependent library launches (at the reference's batch sizes the gradient-hit
+// lists are 12 000 - 36 000 slots long).  Same outputs as the multi-launch path.
+constexpr int kLiveThreads = 1024;
+constexpr int kLiveTile = 8;       // keys per thread and compaction round
+template <int ITEMS>
+__global__ __launch_bounds__(kLiveThreads) void sort_live_small_kernel(const int32_t* __restrict__ keys, int n, int bits, int32_t sentinel, int capacity,
+                                                                       int32_t* __restrict__ sorted_keys, int32_t* __restrict__ order,
+                                                                       int32_t* __restrict__ live_index, int32_t* __restrict__ count) {
+    using Sort = rocprim::block_radix_sort<uint32_t, kLiveThreads, ITEMS, int32_t>;
+    using Scan = rocprim::block_scan<int32_t, kLiveThreads>;
+    __shared__ union {
+        typename Sort::storage_type sort;
+        typename Scan::storage_type scan;
+    } tmp;
+    __shared__ int32_t total_sh;
+    const int t = threadIdx.x;
+    int32_t running = 0;
+    for (int base = 0; base < n; base += kLiveThreads * kLiveTile) {
+        int32_t live[kLiveTile], mine = 0;
+#pragma unroll
+        for (int j = 0; j < kLiveTile; ++j) {
+            const int idx = base + t * kLiveTile + j;
+            live[j] = (idx < n && keys[idx] >= 0) ? 1 : 0;
+            mine += live[j];
+        }
+        int32_t before = 0, tile_total = 0;
+        Scan().exclusive_scan(mine, before, 0, tile_total, tmp.scan);
+        int32_t pos = running + before;
+#pragma unroll
+        for (int j = 0; j < kLiveTile; ++j)
+            if (live[j]) live_index[pos++] = base + t * kLiveTile + j;
+        running += tile_total;
+        __syncthreads();
+    }
+    if (t == 0) { count[0] = running; total_sh = running; }
+    __threadfence_block();
+    __syncthreads();
+    const int total = total_sh;
+    uint32_t k[ITEMS];
+    int32_t v[ITEMS];
+    const uint32_t beyond = bits < 31 ? ((1u << bits) - 1u) : 0x7FFFFFFFu;     // slots past `capacity`: largest key of the sorted bit range
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = t * ITEMS + j;
+        if (i < capacity) {
+            const bool is_live = i < total;
+            const int32_t e = is_live ? live_index[i] : 0;
+            k[j] = is_live ? (uint32_t)keys[e] : (uint32_t)sentinel;
+            v[j] = e;
+        } else {
+            k[j] = beyond;
+            v[j] = 0;
+        }
+    }
+    Sort().sort(k, v, tmp.sort, 0u, (unsigned)bits);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = t * ITEMS + j;
+        if (i < capacity) { sorted_keys[i] = (int32_t)k[j]; order[i] = v[j]; }
     }
 }
 
@@ -178,13 +244,15 @@ extern "C" int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bi
     if (!keys || !workspace || !sorted_keys || !order || !seg || !uniq) return set_error(LSTEP_EINVAL, "lstep_group_by_key: NULL pointer");
     if (workspace_bytes < lstep_group_by_key_workspace(n, key_bits)) return set_error(LSTEP_EINVAL, "lstep_group_by_key: workspace too small");
     const char* no_small = getenv("LSTEP_GROUP_NO_SMALL");      // A/B and the parity test: read per call
-    if (n <= kSmallThreads * 16 && !(no_small && no_small[0] == '1')) {
-        if (n <= kSmallThreads * 2)
-            hipLaunchKernelGGL(group_small_kernel<2>, dim3(1), dim3(kSmallThreads), 0, s, keys, (int)n, key_bits, limit, sorted_keys, order, seg, uniq, summary);
-        else if (n <= kSmallThreads * 8)
-            hipLaunchKernelGGL(group_small_kernel<8>, dim3(1), dim3(kSmallThreads), 0, s, keys, (int)n, key_bits, limit, sorted_keys, order, seg, uniq, summary);
-        else
-            hipLaunchKernelGGL(group_small_kernel<16>, dim3(1), dim3(kSmallThreads), 0, s, keys, (int)n, key_bits, limit, sorted_keys, order, seg, uniq, summary);
+    if (n <= 1024 * 24 && !(no_small && no_small[0] == '1')) {
+#define LSTEP_GROUP_SMALL(TH, IT) hipLaunchKernelGGL((group_small_kernel<TH, IT>), dim3(1), dim3(TH), 0, s, keys, (int)n, key_bits, limit, sorted_keys, order, seg, uniq, summary)
+        if (n <= kSmallThreads * 2) LSTEP_GROUP_SMALL(kSmallThreads, 2);
+        else if (n <= kSmallThreads * 8) LSTEP_GROUP_SMALL(kSmallThreads, 8);
+        else if (n <= kSmallThreads * 16) LSTEP_GROUP_SMALL(kSmallThreads, 16);
+        else if (n <= 1024 * 8) LSTEP_GROUP_SMALL(1024, 8);
+        else if (n <= 1024 * 16) LSTEP_GROUP_SMALL(1024, 16);
+        else LSTEP_GROUP_SMALL(1024, 24);      // (32 keys per thread spill: 24 still fit the 128-register budget of a 1024-thread workgroup)
+#undef LSTEP_GROUP_SMALL
         return check_launch("group_small_kernel");
     }
     char* ws = (char*)workspace;
@@ -272,6 +340,15 @@ extern "C" int lstep_sort_live_bounded(const int32_t* keys, int64_t n, int32_t k
     if (workspace_bytes < lstep_sort_live_bounded_workspace(n, capacity, key_bits))
         return set_error(LSTEP_EINVAL, "lstep_sort_live_bounded: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    const char* no_small = getenv("LSTEP_GROUP_NO_SMALL");
+    if (n <= 65536 && capacity <= kLiveThreads * 24 && !(no_small && no_small[0] == '1')) {
+#define LSTEP_LIVE_SMALL(IT) hipLaunchKernelGGL((sort_live_small_kernel<IT>), dim3(1), dim3(kLiveThreads), 0, s, keys, (int)n, key_bits, sentinel, (int)capacity, sorted_keys, order, live_index, count)
+        if (capacity <= kLiveThreads * 8) LSTEP_LIVE_SMALL(8);
+        else if (capacity <= kLiveThreads * 16) LSTEP_LIVE_SMALL(16);
+        else LSTEP_LIVE_SMALL(24);
+#undef LSTEP_LIVE_SMALL
+        return check_launch("sort_live_small_kernel");
+    }
     char* ws = (char*)workspace;
     int32_t* live_keys = (int32_t*)ws;
     int32_t* live_idx = (int32_t*)(ws + align256((size_t)capacity * 4));

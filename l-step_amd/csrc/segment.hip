@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                                                                    const float* __restrict__ ent_dt, int64_t num_entries,
                                                                    float* __restrict__ out, int ld_out, bool accumulate,
                                                                    const int32_t* __restrict__ num_live, float* __restrict__ parts,
-                                                                   int32_t* __restrict__ chunk_flags) {
+                                                                   int32_t* __restrict__ chunk_flags, int row_div) {
     const int lane = lane_id();
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t e0 = chunk * kChunk;
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
         if (lane < m) {
             sg = ent_seg[c0 + lane];
             r = ent_row[c0 + lane];
+            if (row_div > 1) r /= row_div;      // (ent_row holds slot indices row * K + j: the gradient hits of the gather backward)
             if (D > 0) dt = ent_dt[c0 + lane];
         }
         settle(sg ^ r ^ __float_as_int(dt));
@@ -329,7 +330,7 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
         hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3(bgrid), dim3(kBlock), 0, (hipStream_t)stream, ent_seg, num_entries, out,
                            (int)ld_out, (int)(width + time_dim), num_live);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts, flags);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts, flags, 1);
     if (parts)
         hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                            ent_seg, chunks, (int)width, (int)time_dim, parts, flags, out, (int)ld_out, accumulate == 1);
@@ -338,14 +339,14 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
 
 // lstep_segment_rows_sum (no time part, accumulate 0 / 1) over a PADDED entry list: only the first min(*num_live, num_entries) entries count
 extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, int32_t ld_table, const int32_t* ent_seg, const int32_t* ent_row,
-                                           int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out, int32_t accumulate,
-                                           void* workspace, int64_t workspace_bytes, void* stream) {
+                                           int32_t row_div, int64_t num_entries, const int32_t* num_live, float* out, int32_t ld_out,
+                                           int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
     if (num_entries < 0) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: negative count");
     if (num_entries == 0) return LSTEP_OK;
     if (ld_table == 0) ld_table = width;
     if (ld_out == 0) ld_out = width;
     if (width <= 0 || (width & 3) || width > 4 * kMaxRowVec || ld_table < width || (ld_table & 3) || ld_out < width || (ld_out & 3) ||
-        (accumulate != 0 && accumulate != 1))
+        (accumulate != 0 && accumulate != 1) || row_div < 1)
         return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: unsupported arguments");
     if (!table || !ent_seg || !ent_row || !out || !num_live) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: NULL pointer");
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
@@ -360,7 +361,7 @@ extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, in
     }
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table,
                        (const float*)nullptr, (const float*)nullptr, 0, ent_seg, ent_row, (const float*)nullptr, num_entries, out, (int)ld_out,
-                       accumulate == 1, num_live, parts, flags);
+                       accumulate == 1, num_live, parts, flags, (int)row_div);
     if (parts)
         hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                            ent_seg, chunks, (int)width, 0, parts, flags, out, (int)ld_out, accumulate == 1);

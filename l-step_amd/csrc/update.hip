@@ -81,6 +81,48 @@ __global__ void update_entries_p2_dev_kernel(const int32_t* __restrict__ order, 
     }
 }
 
+// One launch for what an engine iteration derives from its batch before anything else runs: the gather rows cat[src, dst, neg] with their
+// times cat[t, t, t] (train_LSTEP_link_prediction.py:233-251: three combining_pe_raw_feat calls on the same times), the int32 grouping keys
+// cat[src, dst] (train:221-222) and float32(max t) (models/LSTEP.py:277: torch.Tensor([current_time]) rounds to float32 first).  The last
+// workgroup reduces the maximum; the others copy.
+__global__ __launch_bounds__(256) void batch_prepare_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
+                                                            const double* __restrict__ t, int64_t b, int64_t* __restrict__ ids3, double* __restrict__ t3,
+                                                            int32_t* __restrict__ keys, float* __restrict__ now32) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ double part[256];
+        double m = -1.7976931348623157e308;
+        for (int64_t i = threadIdx.x; i < b; i += 256) m = t[i] > m ? t[i] : m;
+        part[threadIdx.x] = m;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) part[threadIdx.x] = part[threadIdx.x + off] > part[threadIdx.x] ? part[threadIdx.x + off] : part[threadIdx.x];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) now32[0] = (float)part[0];
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < b; i += (int64_t)(gridDim.x - 1) * 256) {
+        const int64_t s = src[i], d = dst[i];
+        const double ti = t[i];
+        ids3[i] = s; ids3[b + i] = d;
+        t3[i] = ti; t3[b + i] = ti;
+        if (neg) { ids3[2 * b + i] = neg[i]; t3[2 * b + i] = ti; }
+        keys[i] = (int32_t)s; keys[b + i] = (int32_t)d;
+    }
+}
+
+// row[:width] = sum over the blocks of partial[blk, :width] (in block order: deterministic), row[width:row_width] = 0:
+// the padding row's aggregate of update_pe phase 2 (lstep_padding_rows_sum's per-block sums; its time part is zero, models/LSTEP.py:316)
+__global__ __launch_bounds__(256) void padding_rows_finish_kernel(const float* __restrict__ partial, int64_t blocks, int width, float* __restrict__ row,
+                                                                  int row_width) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= row_width) return;
+    float s = 0.f;
+    if (c < width)
+        for (int64_t k = 0; k < blocks; ++k) s += partial[k * width + c];
+    row[c] = s;
+}
+
 static unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 }  // namespace lstep
@@ -129,4 +171,22 @@ extern "C" int lstep_update_entries_p2_dev(const int32_t* order, const int32_t* 
     hipLaunchKernelGGL(update_entries_p2_dev_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, order, seg, summary, live_rows,
                        capacity, touched_capacity, bn, nt, now32, num_neighbors, uniq, ent_row, ent_dt, ent_seg, touched, counts_out);
     return check_launch("update_entries_p2_dev_kernel");
+}
+
+
+extern "C" int lstep_batch_prepare(const int64_t* src, const int64_t* dst, const int64_t* neg, const double* times, int64_t batch, int64_t* ids3,
+                                   double* t3, int32_t* keys, float* now32, void* stream) {
+    if (batch <= 0) return set_error(LSTEP_EINVAL, "lstep_batch_prepare: empty batch");
+    if (!src || !dst || !times || !ids3 || !t3 || !keys || !now32) return set_error(LSTEP_EINVAL, "lstep_batch_prepare: NULL pointer");
+    const unsigned copy_blocks = (unsigned)((batch + 255) / 256 < 1024 ? (batch + 255) / 256 : 1024);
+    hipLaunchKernelGGL(batch_prepare_kernel, dim3(copy_blocks + 1), dim3(256), 0, (hipStream_t)stream, src, dst, neg, times, batch, ids3, t3, keys, now32);
+    return check_launch("batch_prepare_kernel");
+}
+
+extern "C" int lstep_padding_rows_finish(const float* partial, int64_t blocks, int32_t width, float* row, int32_t row_width, void* stream) {
+    if (blocks < 0 || width <= 0 || row_width < width) return set_error(LSTEP_EINVAL, "lstep_padding_rows_finish: bad sizes");
+    if (!row || (blocks > 0 && !partial)) return set_error(LSTEP_EINVAL, "lstep_padding_rows_finish: NULL pointer");
+    hipLaunchKernelGGL(padding_rows_finish_kernel, dim3((unsigned)((row_width + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, blocks, (int)width,
+                       row, (int)row_width);
+    return check_launch("padding_rows_finish_kernel");
 }

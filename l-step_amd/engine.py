@@ -643,20 +643,36 @@ class LstepEngine:
                 and getattr(bb.neighbor_sampler, "sample_neighbor_strategy", "recent") == "recent"
                 and not any(os.environ.get(v) == "1" for v in ("LSTEP_TORCH_UPDATE", "LSTEP_TORCH_ENTRIES")))
 
-    def _group_batch(self, src, dst, wait):
+    def _group_batch(self, src, dst, wait, keys=None):
         rows = self.backbone.node_raw_features.shape[0]
-        keys = torch.cat([src, dst]).to(torch.int32)
+        if keys is None:
+            keys = torch.cat([src, dst]).to(torch.int32)
         _, order, seg, uniq, counts = nat.group_by_key(keys, max(1, int(rows).bit_length()), rows, wait=wait)
         return order, seg, uniq, counts
 
-    def batch_nodes_device(self, src, dst):
+    def prepare_batch(self, src, dst, neg_dst, ts):
+        """``lstep_batch_prepare``: (cat[src, dst, neg_dst], cat[ts, ts, ts], int32 cat[src, dst], float32(max ts)) in one launch instead
+        of three concatenations, a cast, a reduction and another cast."""
+        n = src.numel()
+        dev = self.device
+        ids3 = torch.empty(3 * n, dtype=torch.int64, device=dev)
+        t3 = torch.empty(3 * n, dtype=torch.float64, device=dev)
+        keys = torch.empty(2 * n, dtype=torch.int32, device=dev)
+        now32 = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(nat.load_library().lstep_batch_prepare(nat.ptr(src.contiguous()), nat.ptr(dst.contiguous()), nat.ptr(neg_dst.contiguous()),
+                                                             nat.ptr(ts.contiguous()), n, nat.ptr(ids3), nat.ptr(t3), nat.ptr(keys), nat.ptr(now32),
+                                                             nat.current_stream()))
+        return ids3, t3, keys, now32
+
+    def batch_nodes_device(self, src, dst, keys=None):
         """``batch_nodes_and_segments`` without any host round trip: (bn int64 [2 B] = the sorted unique endpoints followed by a dead tail
         of node 0, n_live int32 [1] = their number on the device, (order, seg) = the int32 grouping of cat[src, dst] by batch node)."""
         pre = self.__dict__.pop("_prefetched_group", None)
         if pre is not None and pre[0].matches(src, dst) and isinstance(pre[1][3], torch.Tensor):
             order, seg, uniq, summary = pre[1]
         else:
-            order, seg, uniq, summary = self._group_batch(src, dst, wait=None)
+            order, seg, uniq, summary = self._group_batch(src, dst, wait=None, keys=keys)
         bn = torch.empty(uniq.numel(), dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
             nat.check(nat.load_library().lstep_widen_ids(nat.ptr(uniq), uniq.numel(), nat.ptr(summary), nat.ptr(bn), nat.current_stream()))
@@ -727,8 +743,11 @@ class LstepEngine:
             ring.position_on_device()
         bb.prepare_step()
         on_device = self.device_counts and (batch_idx == 0 or ring.len > 0)
+        prep = None
+        if on_device and batch_idx > 0 and src.dtype == torch.int64 and ts.dtype == torch.float64 and os.environ.get("LSTEP_NO_BATCH_PREPARE") != "1":
+            prep = self.prepare_batch(src, dst, neg_dst, ts)
         if on_device:
-            batch_nodes, n_live, presorted = self.batch_nodes_device(src, dst)
+            batch_nodes, n_live, presorted = self.batch_nodes_device(src, dst, keys=prep[2] if prep is not None else None)
         else:
             n_live = None
             batch_nodes, presorted = self.batch_nodes_and_segments(src, dst)
@@ -740,8 +759,8 @@ class LstepEngine:
         else:
             cur, spliced = self._splice(batch_nodes, batch_idx, live=n_live)
             n = src.numel()
-            ids3 = torch.cat([src, dst, neg_dst])
-            emb_p = bb.combining_pe_raw_feat(cur, ids3, torch.cat([ts, ts, ts]), self.K, self.G, spliced=spliced, padded=True, row_blocks=3)
+            ids3, t3 = (prep[0], prep[1]) if prep is not None else (torch.cat([src, dst, neg_dst]), torch.cat([ts, ts, ts]))
+            emb_p = bb.combining_pe_raw_feat(cur, ids3, t3, self.K, self.G, spliced=spliced, padded=True, row_blocks=3)
             emb = emb_p[:, :bb.feat_dim]
             pos_src = emb[:n]
             # both predictor calls of train:254-255 in one launch: rows [pos_src | pos_dst] and [pos_src | neg_dst] (neg_src = pos_src, train:245)
@@ -770,7 +789,8 @@ class LstepEngine:
             if on_device:
                 base, ref = ring.building_ref()
                 bb.update_pe_device(cur, batch_nodes, n_live, src, dst, ts, self.K, presorted, changed=ring.written,
-                                    mirror=base if ref is not None else ring.building(), mirror_ring=ref)
+                                    mirror=base if ref is not None else ring.building(), mirror_ring=ref,
+                                    now32=prep[3] if prep is not None else None)
             else:
                 bb.update_pe(pe=cur, node_ids=batch_nodes, edge_ids=eid, batch_src_node_ids=src, batch_dst_node_ids=dst,
                              node_interact_times=ts, current_time=ts.max(), num_neighbors=self.K, time_gap=self.G,

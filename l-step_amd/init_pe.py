@@ -9,12 +9,15 @@ The reference computes them once per run from the FIRST training batch's edges o
 * ``RandomWalkPE(edge_index, num_nodes, walk_length)`` (``:69-91``): ``pe[n, i] = (P^(i+1))[n, n]`` for the random-walk matrix
   ``P = D_out^-1 A`` (rows without an edge keep degree 1).
 
-**Parity unpinned.**  The reference builds both on ``torch_geometric.utils`` (``get_laplacian``, ``to_scipy_sparse_matrix``,
-``to_torch_csr_tensor``, ``get_self_loop_attr``), which is not installed here and pinned nowhere (the reference has no requirements
-file), so it cannot be run to produce fixtures.  More fundamentally its LapPE output is not a function of its input: a graph of <= 2 B
-edges on N nodes leaves N - O(B) isolated nodes, i.e. one eigenvalue of multiplicity ~N, and ARPACK returns an arbitrary basis of that
-eigenspace that depends on its random start vector.  What IS well defined -- the eigen-equation, orthonormal columns, the eigenvalue
-order, the return-probability definition of RWPE -- is what ``tests/test_host_cpu.py`` checks.
+**Parity pin.**  The reference builds both on ``torch_geometric.utils`` (``get_laplacian``, ``to_scipy_sparse_matrix``,
+``to_torch_csr_tensor``, ``to_edge_index``, ``get_self_loop_attr``, ``scatter``), which is not installed here and pinned nowhere (the
+reference has no requirements file).  ``tests/golden/make_golden.py::gen_init_pe`` runs the reference FILE on shims of those six functions
+written from their documented semantics (as it does for ``torch_scatter``) and ``tests/test_host_cpu.py`` holds this module to the result:
+RWPE entry for entry, the normalised Laplacian and ``edge_weight`` entry for entry, the LapPE columns up to their (random) sign on a graph
+whose small eigenvalues are simple.  What no fixture can pin is LapPE on the reference's ACTUAL input: a graph of <= 2 B edges on N nodes
+leaves N - O(B) isolated nodes, i.e. one eigenvalue of multiplicity ~N, and ARPACK returns an arbitrary basis of that eigenspace that
+depends on its random start vector -- there the output is not a function of the input; the property tests (eigen-equation, orthonormal
+columns, eigenvalue order) cover that case.
 
 Host code (scipy), like the reference: this runs once before the first batch, on <= 2 B edges.
 """

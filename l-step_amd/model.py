@@ -21,6 +21,7 @@ filter is applied as its equivalent real ``[T, P]`` coefficient table (everythin
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import gc
 import math
 import os
@@ -117,12 +118,40 @@ def _mm(a, b, out=None):
     return out
 
 
+def _native_compose(t) -> bool:
+    """The weight composition's non-product work as one native launch per direction (csrc/compose.hip); LSTEP_TORCH_COMPOSE=1 (and
+    every CPU tensor) takes the framework ops."""
+    return t.is_cuda and os.environ.get("LSTEP_TORCH_COMPOSE") != "1"
+
+
 def _tail_weights_forward(dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2):
     """Padded / pre-multiplied weights of the dense tail (see ``_TailWeights``).  Returns (the 8 operands, their 4 transposes for the
     backward kernel, (a_sum, M) for the hand-derived backward)."""
     Fd, C, P, CP, Ce, Fn, Cp, Pp = dims   # F, D+F, P, P+D and their 16-aligned paddings
     dev = W1.device
     sizes = [Ce * Ce, Ce, Pp * Cp, Pp, Pp * 2 * Pp, Pp, Fn * (Fn + Ce + Pp), Fn]
+    if _native_compose(W1):
+        # three products + ONE launch for everything else (csrc/compose.hip) instead of ~20 framework launches
+        params = [t.detach().contiguous() for t in (W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, Wn1, bn1, Wn2, bn2)]
+        W2c, Wnc, Woc = params[4], params[6], params[8]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        flat_t = torch.empty(sizes[0] + sizes[2] + sizes[4] + sizes[6], dtype=torch.float32, device=dev)
+        a_sum = torch.empty(1, dtype=torch.float32, device=dev)
+        M = torch.empty((Fd, C), dtype=torch.float32, device=dev)
+        parts = torch.split(flat, sizes)
+        Wall = parts[6].view(Fn, Fn + Ce + Pp)
+        nat.small_mm(Woc[:, :Fd], Wnc[:, Fd:], out=M)
+        nat.small_mm(Woc[:, :Fd], Wnc[:, :Fd], out=Wall[:Fd, :Fd])
+        nat.small_mm(M, W2c, out=Wall[:Fd, Fn:Fn + C])
+        lib = nat.load_library()
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_tail_weights_pack((ctypes.c_void_p * 16)(*[t.data_ptr() for t in params]), nat.ptr(M),
+                                                  (ctypes.c_int32 * 9)(Fd, C, P, CP, Ce, Fn, Cp, Pp, aw.numel()), nat.ptr(flat), nat.ptr(flat_t),
+                                                  nat.ptr(a_sum), nat.current_stream()))
+        tparts = torch.split(flat_t, [sizes[0], sizes[2], sizes[4], sizes[6]])
+        outs = (parts[0].view(Ce, Ce), parts[1], parts[2].view(Pp, Cp), parts[3], parts[4].view(Pp, 2 * Pp), parts[5], Wall, parts[7])
+        transposed = (tparts[0].view(Ce, Ce), tparts[1].view(Cp, Pp), tparts[2].view(2 * Pp, Pp), tparts[3].view(Fn + Ce + Pp, Fn))
+        return outs, transposed, (a_sum, M)
     flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
     parts = torch.split(flat, sizes)
     W1p, b1p, Wn1p, bn1p = parts[0].view(Ce, Ce), parts[1], parts[2].view(Pp, Cp), parts[3]
@@ -149,6 +178,32 @@ def _tail_weights_forward(dims, W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo, Ws, bs, 
 def _tail_weights_backward(dims, K, b1, W2, b2, Wn, bn, Wo, a_sum, M, gW1p, gb1p, gWn1p, gbn1p, gWq, gbq, gWall, gconst, dense=False):
     """Hand-derived chain rule of ``_tail_weights_forward``: gradients of the 16 parameters in its argument order."""
     Fd, C, P, CP, Ce, Fn, Cp, Pp = dims
+    if _native_compose(W2):
+        # one product, ONE launch for every slice copy / bias / rank-1 term (csrc/compose.hip), five products: seven launches instead of ~20
+        dev = W2.device
+        gin = [g.contiguous() for g in (gW1p, gb1p, gWn1p, gbn1p, gWq, gbq, gWall, gconst)]
+        gWall_c = gin[6]
+        W2c, Wnc, Woc = W2.detach().contiguous(), Wn.detach().contiguous(), Wo.detach().contiguous()
+        shapes = [(C, C), (C,), (1, K), (1,), (C, C), (C,), (Fd, Fd + C), (Fd,), (Fd, Fd + P), (Fd,), (P, P), (P,), (P, CP), (P,), (P, P), (P,)]
+        numels = [int(np.prod(sh)) for sh in shapes]
+        flat = torch.empty(sum(numels), dtype=torch.float32, device=dev)
+        (d_W1, d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, d_bo, d_Ws, d_bs, d_Wn1, d_bn1, d_Wn2, d_bn2) = \
+            [t.view(sh) for t, sh in zip(torch.split(flat, numels), shapes)]
+        dA1, dA2 = gWall_c[:Fd, :Fd], gWall_c[:Fd, Fn:Fn + C]
+        dM = nat.small_mm(dA2, W2c.t())
+        fwd = [t.detach().contiguous() for t in (b1, b2, bn)] + [Woc, M.contiguous(), a_sum.reshape(1).contiguous()]
+        outs14 = (d_W1, d_b1, d_aw, d_ab, d_b2, d_bn, d_Wo, d_bo, d_Ws, d_bs, d_Wn1, d_bn1, d_Wn2, d_bn2)
+        lib = nat.load_library()
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_tail_weights_unpack((ctypes.c_void_p * 8)(*[t.data_ptr() for t in gin]), (ctypes.c_void_p * 6)(*[t.data_ptr() for t in fwd]),
+                                                    (ctypes.c_void_p * 14)(*[t.data_ptr() for t in outs14]), nat.ptr(dM),
+                                                    (ctypes.c_int32 * 9)(Fd, C, P, CP, Ce, Fn, Cp, Pp, K), nat.current_stream()))
+        nat.small_mm(M.t(), dA2, out=d_W2)
+        nat.small_mm(dA1, Wnc[:, :Fd].t(), out=d_Wo[:, :Fd], beta=1.0)
+        nat.small_mm(dM, Wnc[:, Fd:].t(), out=d_Wo[:, :Fd], beta=1.0)
+        nat.small_mm(Woc[:, :Fd].t(), dA1, out=d_Wn[:, :Fd])
+        nat.small_mm(Woc[:, :Fd].t(), dM, out=d_Wn[:, Fd:])
+        return (d_W1, d_b1, d_aw, d_ab, d_W2, d_b2, d_Wn, d_bn, d_Wo, d_bo, d_Ws, d_bs, d_Wn1, d_bn1, d_Wn2, d_bn2)
     db1e = gb1p[:C]
     d_b1 = a_sum * db1e
     d_aw = torch.dot(db1e, b1).expand(1, K)
@@ -765,11 +820,11 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
     if last is not None and (capturing or os.environ.get("LSTEP_SYNC_LIVE_SORT") != "1"):
         capacity = min(n, max(8192, ((3 if capturing else 2) * last + 4095) // 4096 * 4096))
         sorted_keys, order, live_index, count = nat.sort_live_bounded(keys, key_bits, int(out.shape[0]), capacity)
-        ent_row = torch.div(order, div, rounding_mode="floor") if div > 1 else order
         with torch.cuda.device(dev):
             ws, ws_bytes = nat.segment_workspace(dev, capacity, P)
-            nat.check(lib.lstep_segment_rows_sum_live(nat.ptr(table), P, int(table.stride(0)), nat.ptr(sorted_keys), nat.ptr(ent_row), capacity,
-                                                      nat.ptr(count), nat.ptr(out), P, 1 if accumulate else 0, nat.ptr(ws), ws_bytes,
+            # (entry e reads table row order[e] // div: the division is the kernel's, not a framework launch)
+            nat.check(lib.lstep_segment_rows_sum_live(nat.ptr(table), P, int(table.stride(0)), nat.ptr(sorted_keys), nat.ptr(order), max(div, 1),
+                                                      capacity, nat.ptr(count), nat.ptr(out), P, 1 if accumulate else 0, nat.ptr(ws), ws_bytes,
                                                       nat.current_stream()))
             if capacity < n:
                 nat.check(lib.lstep_scatter_add_overflow(nat.ptr(out), P, P, nat.ptr(keys), nat.ptr(live_index), nat.ptr(count), capacity,
@@ -1690,7 +1745,7 @@ class LSTEP(nn.Module):
 
     @torch.no_grad()
     def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None, mirror_ring=None,
-                         mirror_shard=(1, 0), owner=None, owned_idx=None, after_phase1=None):
+                         mirror_shard=(1, 0), owner=None, owned_idx=None, after_phase1=None, now32=None):
         """``update_pe`` for the engine, with every data-dependent size left on the device: no host synchronisation, no second host
         thread, a fixed launch sequence.
 
@@ -1714,7 +1769,8 @@ class LSTEP(nn.Module):
         cap = bn.numel()
         rows = pe.shape[0]
         world, rank = (int(owner[0]), int(owner[1])) if owner is not None else (1, 0)
-        now32 = t.max().to(torch.float32).reshape(1)          # torch.Tensor([current_time]) of models/LSTEP.py:277: float32-rounded
+        if now32 is None:      # torch.Tensor([current_time]) of models/LSTEP.py:277: float32-rounded (the engine hands it over: lstep_batch_prepare)
+            now32 = t.max().to(torch.float32).reshape(1)
         order32, seg32 = presorted
         n2 = order32.numel()
         # ---- phase 1 (LSTEP.py:277-303)
@@ -1778,12 +1834,13 @@ class LSTEP(nn.Module):
                 nat.check(lib.lstep_segment_rows_sum(nat.ptr(y), Pp, Pp, nat.ptr(self.time_encoder.w.weight), nat.ptr(self.time_encoder.w.bias), D,
                                                      nat.ptr(ent_seg), nat.ptr(ent_row), nat.ptr(ent_dt), n, nat.ptr(agg2), Pp + D, 2,
                                                      nat.ptr(summary[1:2]), nat.ptr(ws), ws_bytes, nat.current_stream()))
-            agg2[0].zero_()
-            if rank == 0:
-                part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), Pp), dtype=torch.float32, device=dev)
-                with torch.cuda.device(dev):
+            # row 0's aggregate: the block sums of (number of padded slots) x (row's product), added in block order; zero time part
+            nblk = int(lib.lstep_padding_rows_sum_blocks(cap)) if rank == 0 else 0
+            part = torch.empty((max(nblk, 1), Pp), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                if nblk:
                     nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, None, cap, nat.ptr(y), Pp, Pp, nat.ptr(part), nat.current_stream()))
-                agg2[0, :Pp] = part.sum(dim=0)
+                nat.check(lib.lstep_padding_rows_finish(nat.ptr(part), nblk, Pp, nat.ptr(agg2), Pp + D, nat.current_stream()))
             for ids_, agg_, live_ in ((touched[1:], agg2[1:], counts[0:1]), (touched[:1], agg2[:1], row0_live)):
                 with torch.cuda.device(dev):
                     nat.check(lib.lstep_update_rows_pre(nat.ptr(agg_), int(agg_.stride(0)), nat.ptr(ids_), ids_.numel(), nat.ptr(w1b), nat.ptr(b1),
@@ -1795,13 +1852,13 @@ class LSTEP(nn.Module):
         agg2 = self._segment_sum(pe, tcap, ent_seg, ent_row, ent_dt, exact=True, live=summary[1:2])
         # row 0 collects cat[pe[source], 0] from every padded slot: segment 0 has no entries of its own, its aggregate is the sum over
         # the rows of (their number of padded slots) * pe[source row]
-        agg2[0].zero_()
-        if rank == 0:
-            part = torch.empty((int(lib.lstep_padding_rows_sum_blocks(cap)), P), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
+        nblk = int(lib.lstep_padding_rows_sum_blocks(cap)) if rank == 0 else 0
+        part = torch.empty((max(nblk, 1), P), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            if nblk:
                 nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, nat.ptr(bn), cap, nat.ptr(pe), P, int(pe.stride(0)), nat.ptr(part),
                                                      nat.current_stream()))
-            agg2[0, :P] = part.sum(dim=0)
+            nat.check(lib.lstep_padding_rows_finish(nat.ptr(part), nblk, P, nat.ptr(agg2), int(agg2.shape[1]), nat.current_stream()))
         self._update_rows(pe, touched[1:], agg2[1:], with_self=False, mirror=mirror, live=counts[0:1], ring=mirror_ring, mirror_shard=mirror_shard)
         self._update_rows(pe, touched[:1], agg2[:1], with_self=False, mirror=mirror, live=row0_live, ring=mirror_ring, mirror_shard=mirror_shard)
         if changed is not None:

@@ -578,9 +578,91 @@ def gen_loader():
     print("loader.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------- initial positional encodings
+INIT_PE = dict(num_nodes=40, k=6, walk=5, seed=77)
+
+
+def init_pe_graph():
+    """First-batch-shaped input of train_LSTEP_link_prediction.py:168-189: both directions of a batch's edges (sources first), on a
+    connected multigraph (a ring plus random chords, some edges repeated) over all nodes but three isolated ones."""
+    rng = np.random.RandomState(INIT_PE["seed"])
+    n = INIT_PE["num_nodes"] - 3
+    ring = np.stack([np.arange(n), (np.arange(n) + 1) % n])
+    chords = rng.randint(0, n, size=(2, 30))
+    chords = chords[:, chords[0] != chords[1]]
+    e = np.concatenate([ring, chords, chords[:, :5]], axis=1)          # five parallel edges
+    return np.stack([np.concatenate([e[0], e[1]]), np.concatenate([e[1], e[0]])]).astype(np.int64)
+
+
+def gen_init_pe():
+    """``utils/PositionalEncoding.py`` (RandomWalkPE :69-91, LaplacianPE :42-62) run on ``torch_geometric.utils`` SHIMS: the wheel is not
+    installed (nor pinned by the reference), so the six utilities the file calls are restated from their documented semantics, like the
+    ``torch_scatter`` shim: ``scatter(reduce='sum')`` = index_add into zeros; ``to_torch_csr_tensor`` = the coalesced (duplicates summed) sparse
+    CSR matrix of (edge_index, edge_attr); ``to_edge_index`` = its COO indices and values; ``get_self_loop_attr`` = the diagonal entries, 0
+    where there is none; ``get_laplacian(normalization='sym')`` = self-loops removed, then I - D^-1/2 A D^-1/2 as (edge_index + loops,
+    [-normalised weights, ones]); ``to_scipy_sparse_matrix`` = scipy COO of those."""
+    import scipy.sparse
+    tg = types.ModuleType("torch_geometric")
+    tu = types.ModuleType("torch_geometric.utils")
+
+    def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
+        assert reduce == "sum" and dim == 0
+        return torch.zeros(dim_size, dtype=src.dtype).index_add_(0, index, src)
+
+    def to_torch_csr_tensor(edge_index, edge_attr=None, size=None, is_coalesced=False):
+        n = size if isinstance(size, int) else size[0]
+        return torch.sparse_coo_tensor(edge_index, edge_attr, (n, n)).coalesce().to_sparse_csr()
+
+    def to_edge_index(adj):
+        coo = adj.to_sparse_coo().coalesce()
+        return coo.indices(), coo.values()
+
+    def get_self_loop_attr(edge_index, edge_attr=None, num_nodes=None):
+        mask = edge_index[0] == edge_index[1]
+        out = torch.zeros(num_nodes, dtype=edge_attr.dtype)
+        out[edge_index[0][mask]] = edge_attr[mask]
+        return out
+
+    def get_laplacian(edge_index, edge_weight=None, normalization=None, dtype=None, num_nodes=None):
+        assert normalization == "sym" and edge_weight is None
+        keep = edge_index[0] != edge_index[1]
+        edge_index = edge_index[:, keep]
+        w = torch.ones(edge_index.shape[1])
+        row, col = edge_index
+        deg = torch.zeros(num_nodes).index_add_(0, row, w)
+        dis = deg.pow(-0.5)
+        dis.masked_fill_(dis == float("inf"), 0)
+        w = dis[row] * w * dis[col]
+        loops = torch.arange(num_nodes)
+        return torch.cat([edge_index, torch.stack([loops, loops])], dim=1), torch.cat([-w, torch.ones(num_nodes)])
+
+    def to_scipy_sparse_matrix(edge_index, edge_attr=None, num_nodes=None):
+        return scipy.sparse.coo_matrix((edge_attr.numpy(), (edge_index[0].numpy(), edge_index[1].numpy())), (num_nodes, num_nodes))
+
+    tu.scatter, tu.to_torch_csr_tensor, tu.to_edge_index, tu.get_self_loop_attr = scatter, to_torch_csr_tensor, to_edge_index, get_self_loop_attr
+    tu.get_laplacian, tu.to_scipy_sparse_matrix, tu.is_torch_sparse_tensor = get_laplacian, to_scipy_sparse_matrix, (lambda x: x.is_sparse)
+    tg.utils = tu
+    sys.modules.update({"torch_geometric": tg, "torch_geometric.utils": tu})
+    from utils.PositionalEncoding import LaplacianPE, RandomWalkPE
+    ei = torch.from_numpy(init_pe_graph())
+    N, k, walk = INIT_PE["num_nodes"], INIT_PE["k"], INIT_PE["walk"]
+    out = {"edge_index": ei.numpy()}
+    out["rwpe"] = RandomWalkPE(ei, N, walk).numpy()
+    torch.manual_seed(5)
+    pe, edge_weight = LaplacianPE(ei, N, k)
+    out["lappe_abs"] = np.abs(pe.numpy())                  # (columns carry a random sign, :57-59; eigenvectors are defined up to sign anyway)
+    out["lappe_edge_weight"] = edge_weight.numpy()
+    lap = to_scipy_sparse_matrix(*get_laplacian(ei, normalization="sym", num_nodes=N), N).toarray()
+    ev = np.linalg.eigvalsh(lap)
+    assert np.min(np.diff(ev[:k + 2])) > 1e-3, "the fixture needs non-degenerate small eigenvalues (a unique answer up to sign)"
+    out["laplacian"] = lap
+    np.savez_compressed(os.path.join(HERE, "init_pe.npz"), **out)
+    print("init_pe.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop", "variants", "traces_long", "float64"]
+    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop", "variants", "traces_long", "float64", "init_pe"]
     if "sampler" in which:
         gen_sampler()
     if "time" in which:
@@ -601,3 +683,5 @@ if __name__ == "__main__":
         gen_traces_long()
     if "float64" in which:
         gen_float64()
+    if "init_pe" in which:
+        gen_init_pe()

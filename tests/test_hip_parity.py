@@ -942,6 +942,37 @@ def test_engine_lookahead_and_streams_do_not_change_results(hip, monkeypatch):
     assert float(d.max()) <= 5e-3 and float((d > 5e-5).float().mean()) <= 1e-3
 
 
+@pytest.mark.parametrize("K", [20, 5])
+def test_native_weight_composition_matches_framework_ops(hip, monkeypatch, K):
+    """``lstep_tail_weights_pack`` / ``_unpack`` (csrc/compose.hip: every non-product step of the dense tail's weight composition and of
+    its hand-derived backward in one launch each) against the same composition written with framework ops (LSTEP_TORCH_COMPOSE=1), itself
+    checked against autograd on the CPU (tests/test_host_cpu.py): the 8 operands, their 4 transposes, a_sum and M; then the 16 parameter
+    gradients for random operand gradients."""
+    from lstep_amd import model as M
+    torch.manual_seed(7)
+    Fd, D, P = 172, 100, 172
+    dims = (Fd, D + Fd, P, P + D, 272, 176, 272, 176)
+    C, CP = D + Fd, P + D
+    shapes = [(C, C), (C,), (1, K), (1,), (C, C), (C,), (Fd, Fd + C), (Fd,), (Fd, Fd + P), (Fd,), (P, P), (P,), (P, CP), (P,), (P, P), (P,)]
+    params = [0.1 * torch.randn(sh, device=DEV) for sh in shapes]
+    res = {}
+    for mode in ("native", "torch"):
+        monkeypatch.setenv("LSTEP_TORCH_COMPOSE", "1" if mode == "torch" else "0")
+        outs, transposed, (a_sum, Mm) = M._tail_weights_forward(dims, *params)
+        gin = [torch.randn(sh, device=DEV, generator=torch.Generator(device=DEV).manual_seed(11 + i)) for i, sh in enumerate(M._tail_grad_shapes(dims))]
+        W1, b1, aw, ab, W2, b2, Wn, bn, Wo, bo = params[:10]
+        grads = M._tail_weights_backward(dims, K, b1, W2, b2, Wn, bn, Wo, a_sum, Mm, *gin, True)
+        res[mode] = ([o.clone() for o in outs] + [t.clone() for t in transposed] + [a_sum.reshape(1).clone(), Mm.clone()], [g.clone() for g in grads])
+    for i, (a, b) in enumerate(zip(res["native"][0], res["torch"][0])):
+        assert a.shape == b.shape, i
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-6, err_msg=f"forward output {i}")
+    for i, (a, b) in enumerate(zip(res["native"][1], res["torch"][1])):
+        assert tuple(a.shape) == tuple(shapes[i]) and a.is_contiguous(), i
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy().reshape(a.shape), rtol=0, atol=2e-5 * max(1.0, float(b.abs().max())), err_msg=f"gradient {i}")
+    ptrs = [g.data_ptr() for g in res["native"][1]]
+    assert len(set(ptrs)) == len(ptrs), "dense parameter gradients must not share storage"
+
+
 def test_small_gemm_vs_float64(hip):
     """lstep_small_gemm (one wave per 16 x 16 tile, element strides) on transposed / sliced operands and accumulating outputs."""
     from lstep_amd import _native as nat

@@ -38,7 +38,7 @@ def test_abi_exports_every_declared_symbol(lib):
         assert hasattr(raw, n), f"{n} declared in include/lstep_hip.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes prototype"
     assert sorted(nat.SIGNATURES) == names
-    assert lib.lstep_abi_version() == nat.ABI_VERSION == 29
+    assert lib.lstep_abi_version() == nat.ABI_VERSION == 30
 
 
 def test_abi_argument_validation_without_gpu(lib):
@@ -295,3 +295,25 @@ def test_chunked_oracle_training_step_equals_the_protocol_iteration():
         a, b = ga[k], gb[k]
         d = float((torch.view_as_real(a - b) if a.is_complex() else (a - b)).abs().max())
         assert d <= 2e-6 * max(1.0, float(a.abs().max())), (k, d)
+
+
+def test_initial_positional_encodings_match_the_reference(golden):
+    """``lstep_amd.init_pe`` (scipy) against ``utils/PositionalEncoding.py`` itself, run by tests/golden/make_golden.py on shims of the six
+    ``torch_geometric.utils`` functions it calls (their documented semantics; the wheel is absent and unpinned): RWPE entry for entry; the
+    normalised Laplacian and the ``edge_weight`` LaplacianPE returns; its eigenvector columns up to the sign the reference randomises
+    (``:57-59``) on a graph whose small eigenvalues are simple."""
+    from lstep_amd import init_pe
+    z = golden("init_pe")
+    ei, n = z["edge_index"], 40
+    k, walk = z["lappe_abs"].shape[1], z["rwpe"].shape[1]
+    rw = init_pe.random_walk_pe(ei, n, walk)
+    assert rw.dtype == torch.float32 and tuple(rw.shape) == (n, walk)
+    np.testing.assert_allclose(rw.numpy(), z["rwpe"], rtol=0, atol=1e-6)
+    assert float(z["rwpe"][-3:].max()) == 0.0 and float(z["rwpe"][:, 1].min()) >= 0.0      # isolated nodes never return; the fixture has them
+    lap, edge_weight = init_pe.sym_normalised_laplacian(ei, n)
+    np.testing.assert_allclose(lap.toarray(), z["laplacian"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(edge_weight.numpy(), z["lappe_edge_weight"], rtol=0, atol=1e-6)
+    pe, ew = init_pe.laplacian_pe(ei, n, k, generator=torch.Generator().manual_seed(1))
+    assert pe.dtype == torch.float64 and tuple(pe.shape) == (n, k)
+    np.testing.assert_allclose(np.abs(pe.numpy()), z["lappe_abs"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ew.numpy(), z["lappe_edge_weight"], rtol=0, atol=1e-6)
