@@ -251,6 +251,8 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    if os.environ.get("LSTEP_SYNC_DEBUG") == "1":      # diagnostic: print every call that makes the host wait for the GPU inside the timed steps
+        torch.cuda.set_sync_debug_mode("warn")
     sink = []
     model[0].gather_event_sink = sink
     trace = os.environ.get("LSTEP_BENCH_TRACE") == "1"      # per-step host / GPU times on stderr (does not drain the GPU between steps)

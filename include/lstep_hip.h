@@ -443,6 +443,15 @@ int lstep_batch_prepare(const int64_t* src, const int64_t* dst, const int64_t* n
 /* row[:width] = the block partials of lstep_padding_rows_sum added in block order, row[width:row_width] = 0 (update_pe phase 2: the padding
  * row's aggregate, models/LSTEP.py:316-322). */
 int lstep_padding_rows_finish(const float* partial, int64_t blocks, int32_t width, float* row, int32_t row_width, void* stream);
+/* Owner-sharded PE table (one process per GPU, node id owned by rank id % world): the request lists of one gather.  lstep_pull_keys: for
+ * the ids {nbr[0..n_nbr), ids[0..n_ids), 0} -- the sampled neighbour slots of a batch's gather rows (models/LSTEP.py:233), the rows themselves
+ * (:232) and the padding row -- keys = owner * num_rows + id, or world * num_rows for ids this rank owns; group them with lstep_group_by_key
+ * (limit = world * num_rows).  lstep_pull_blocks: from the grouped unique keys, count[p] = distinct ids wanted from owner p and
+ * req[p, 0..capacity) = those ids, -1 beyond.  New design: the reference is single-process. */
+int lstep_pull_keys(const int64_t* nbr, int64_t n_nbr, const int64_t* ids, int64_t n_ids, int32_t world, int32_t rank, int64_t num_rows, int32_t* keys,
+                    void* stream);
+int lstep_pull_blocks(const int32_t* uniq, const int32_t* summary, int32_t world, int64_t num_rows, int64_t capacity, int32_t* req, int32_t* count,
+                      void* stream);
 int lstep_update_entries_p1(const int32_t* order, int64_t num_entries, const int64_t* src, const int64_t* dst, const double* times,
                             const float* now32, int64_t batch, int32_t* ent_row, float* ent_dt, void* stream);
 int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank, int32_t* keys, void* stream);

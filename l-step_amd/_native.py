@@ -104,6 +104,8 @@ SIGNATURES = {
     "lstep_sort_live_bounded_workspace": (_I64, [_I64, _I64, _I32]),
     "lstep_sort_live_bounded": (C.c_int, [_P, _I64, _I32, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_segment_rows_sum_live": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I64, _P, _P, _I32, _I32, _P, _I64, _P]),
+    "lstep_pull_keys": (C.c_int, [_P, _I64, _P, _I64, _I32, _I32, _I64, _P, _P]),
+    "lstep_pull_blocks": (C.c_int, [_P, _P, _I32, _I64, _I64, _P, _P, _P]),
     "lstep_batch_prepare": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_padding_rows_finish": (C.c_int, [_P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_add_overflow": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _I32, _P]),

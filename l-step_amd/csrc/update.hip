@@ -123,6 +123,37 @@ __global__ __launch_bounds__(256) void padding_rows_finish_kernel(const float* _
     row[c] = s;
 }
 
+// ---- owner-sharded PE table (lstep_amd/parallel.py, form "pull"): the request lists of one gather.
+// keys[i] = owner(id) * num_rows + id for the ids this rank does NOT own among {neighbour slots, the rows themselves, the padding row 0},
+// `sentinel` (= world * num_rows: dropped by the grouping) for the ones it owns: sorting the keys groups the distinct ids by owner.
+__global__ void pull_keys_kernel(const int64_t* __restrict__ nbr, int64_t n_nbr, const int64_t* __restrict__ ids, int64_t n_ids, int32_t world,
+                                 int32_t rank, int64_t num_rows, int32_t* __restrict__ keys) {
+    const int64_t total = n_nbr + n_ids + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = i < n_nbr ? nbr[i] : (i < n_nbr + n_ids ? ids[i - n_nbr] : 0);
+        const int64_t owner = id % world;
+        keys[i] = owner == rank ? (int32_t)(world * num_rows) : (int32_t)(owner * num_rows + id);
+    }
+}
+
+// From the grouped keys (uniq sorted by (owner, id), summary[2] of them below the sentinel): count[p] = ids requested from owner p and the
+// fixed-capacity request blocks req[p, :capacity] = those ids (global), -1 beyond.  One workgroup per owner; the block boundaries are found by
+// binary search.
+__global__ __launch_bounds__(256) void pull_blocks_kernel(const int32_t* __restrict__ uniq, const int32_t* __restrict__ summary, int32_t world,
+                                                          int64_t num_rows, int64_t capacity, int32_t* __restrict__ req, int32_t* __restrict__ count) {
+    const int p = blockIdx.x;
+    const int64_t n = summary[2];
+    auto lower = [&](int64_t key) {      // first position whose key >= `key`
+        int64_t lo = 0, hi = n;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)uniq[mid] < key) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    const int64_t b = lower((int64_t)p * num_rows), e = lower((int64_t)(p + 1) * num_rows);
+    if (threadIdx.x == 0) count[p] = (int32_t)(e - b);
+    for (int64_t i = threadIdx.x; i < capacity; i += 256)
+        req[(int64_t)p * capacity + i] = (b + i < e) ? (int32_t)((int64_t)uniq[b + i] - (int64_t)p * num_rows) : -1;
+}
+
 static unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
 
 }  // namespace lstep
@@ -189,4 +220,23 @@ extern "C" int lstep_padding_rows_finish(const float* partial, int64_t blocks, i
     hipLaunchKernelGGL(padding_rows_finish_kernel, dim3((unsigned)((row_width + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, blocks, (int)width,
                        row, (int)row_width);
     return check_launch("padding_rows_finish_kernel");
+}
+
+
+extern "C" int lstep_pull_keys(const int64_t* nbr, int64_t n_nbr, const int64_t* ids, int64_t n_ids, int32_t world, int32_t rank, int64_t num_rows,
+                               int32_t* keys, void* stream) {
+    if (n_nbr < 0 || n_ids < 0 || world < 1 || rank < 0 || rank >= world || num_rows <= 0 || (int64_t)world * num_rows >= ((int64_t)1 << 31))
+        return set_error(LSTEP_EINVAL, "lstep_pull_keys: bad sizes (world * num_rows must fit int32)");
+    if (!keys || (n_nbr > 0 && !nbr) || (n_ids > 0 && !ids)) return set_error(LSTEP_EINVAL, "lstep_pull_keys: NULL pointer");
+    hipLaunchKernelGGL(pull_keys_kernel, dim3(grid_for(n_nbr + n_ids + 1)), dim3(256), 0, (hipStream_t)stream, nbr, n_nbr, ids, n_ids, world, rank, num_rows,
+                       keys);
+    return check_launch("pull_keys_kernel");
+}
+
+extern "C" int lstep_pull_blocks(const int32_t* uniq, const int32_t* summary, int32_t world, int64_t num_rows, int64_t capacity, int32_t* req,
+                                 int32_t* count, void* stream) {
+    if (world < 1 || num_rows <= 0 || capacity <= 0) return set_error(LSTEP_EINVAL, "lstep_pull_blocks: bad sizes");
+    if (!uniq || !summary || !req || !count) return set_error(LSTEP_EINVAL, "lstep_pull_blocks: NULL pointer");
+    hipLaunchKernelGGL(pull_blocks_kernel, dim3((unsigned)world), dim3(256), 0, (hipStream_t)stream, uniq, summary, world, num_rows, capacity, req, count);
+    return check_launch("pull_blocks_kernel");
 }

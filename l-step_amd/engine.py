@@ -821,10 +821,18 @@ class LstepEngine:
         if on_device:
             # nothing in update_pe waits for the GPU any more: its ~25 launches go out from THIS thread onto the side stream (0.1 ms of
             # host time), then the backward pass onto the main stream -- no second thread contending for the interpreter lock
-            with torch.cuda.stream(side):
-                update_and_append()
+            bwd_first = torch.cuda.is_current_stream_capturing() and os.environ.get("LSTEP_CAPTURE_BWD_FIRST") == "1"
+            if not bwd_first:
+                with torch.cuda.stream(side):
+                    update_and_append()
             optimizer.zero_grad()
             _backward_unit(loss)
+            if bwd_first:
+                # (A/B switch, off: capturing the backward pass BEFORE update_pe -- same dependencies, other capture order -- in the hope that
+                # the replayed backward pass would start right behind the loss kernel instead of ~0.4 ms later (profiles/r03_a_timeline.txt):
+                # measured 3.67 against 3.51 ms at c4, 0.625 / 0.600 at B = 200, 1.35 / 1.26 at B = 4096.  DESIGN.md appendix A.)
+                with torch.cuda.stream(side):
+                    update_and_append()
             bb.join_aux_stream()
             ring.apply_advance()  # the backward pass is enqueued: the window's oldest snapshot may move on behind it
             main.wait_stream(side)

@@ -994,11 +994,13 @@ class _GatherAggregate(torch.autograd.Function):
                                                             nat.ptr(grad_rows), nat.ptr(hits), nat.current_stream()))
         elif g_edge is not None or grad_rows is not None or hits is not None:
             # Two consumers with very different urgency share this kernel: the spliced-row HITS (a few index reads per row) head the
-            # critical chain sort -> segment sums -> history-filter backward, while the slot dots re-read 688 * k bytes of edge rows per row
-            # (0.3 ms at the bench shape) for ONE parameter gradient, d(edge_agg.weight), that nothing waits for before the optimiser.  In the
-            # engine's iteration (auxiliary stream on) they are launched apart: hits here, the slot dots on the auxiliary stream.
+            # chain sort -> segment sums -> history-filter backward, while the slot dots re-read 688 * k bytes of edge rows per row
+            # (0.3 ms at the bench shape) for ONE parameter gradient, d(edge_agg.weight), that nothing waits for before the optimiser.
+            # LSTEP_SPLIT_GATHER_BWD=1 launches them apart (hits here, the slot dots on a side stream).  Off by default: measured 3.38
+            # against 3.37 ms per step at c4 -- the backward phase is bound by the matrix-core kernels the three streams share, not by
+            # this chain.
             aux_split = (g_edge is not None and hits is not None and mod.__dict__.get("aux_wgrad_stream", False)
-                         and mod.edge_agg.weight.grad is None and os.environ.get("LSTEP_NO_SPLIT_GATHER_BWD") != "1")
+                         and mod.edge_agg.weight.grad is None and os.environ.get("LSTEP_SPLIT_GATHER_BWD") == "1")
             with torch.cuda.device(dev):
                 nat.check(lib.lstep_gather_aggregate_bwd(ctx.sampler.csr, nat.ptr(mod.edge_raw_features), Fd, P, nat.ptr(tw), nat.ptr(tb), D,
                                                          nat.ptr(ids), nat.ptr(times), nat.ptr(count), B, K, None if aux_split else nat.ptr(g_edge),

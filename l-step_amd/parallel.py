@@ -159,8 +159,9 @@ def reduce_scatter_var(t: torch.Tensor, counts, group=None):
     return out.to(t.device) if staged else out
 
 
-def all_reduce_gradients(params, group=None):
-    """One flat bucket for all parameter gradients (complex ones viewed as real); missing grads count as zero."""
+def all_reduce_gradients(params, group=None, extra: torch.Tensor = None):
+    """One flat bucket for all parameter gradients (complex ones viewed as real); missing grads count as zero.  ``extra`` (1-D float32,
+    optional) rides in the same bucket and is returned summed over the ranks (the three loss scalars: one collective less per step)."""
     views = []
     for p in params:
         if not p.requires_grad:
@@ -168,9 +169,12 @@ def all_reduce_gradients(params, group=None):
         if p.grad is None:
             p.grad = torch.zeros_like(p)
         views.append(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad)
-    flat = torch.cat([v.reshape(-1) for v in views])
+    parts = [v.reshape(-1) for v in views] + ([extra.reshape(-1).to(views[0].dtype)] if extra is not None else [])
+    flat = torch.cat(parts)
     all_reduce_sum(flat, group)
-    torch._foreach_copy_(views, [c.view_as(v) for c, v in zip(torch.split(flat, [v.numel() for v in views]), views)])
+    chunks = torch.split(flat, [p.numel() for p in parts])
+    torch._foreach_copy_(views, [c.view_as(v) for c, v in zip(chunks, views)])
+    return chunks[-1] if extra is not None else None
 
 
 def pack_ids(z: torch.Tensor, ids: torch.Tensor, width: int) -> torch.Tensor:
@@ -280,31 +284,29 @@ class RowPull:
         self.dl, self.key = dl, key
         W, rank, dev, rows = dl.W, dl.rank, dl.device, dl.num_rows
         nbr = dl.bb.neighbor_sampler.sample_device(ids, times, dl.K)[0]
-        every = torch.cat([nbr.reshape(-1), ids, torch.zeros(1, dtype=torch.int64, device=dev)])
-        owner = torch.remainder(every, W)
+        lib = nat.load_library()
+        n = nbr.numel() + ids.numel() + 1
         sentinel = W * rows
-        keys = torch.where(owner == rank, torch.full_like(every, sentinel), owner * rows + every).to(torch.int32)
+        keys = torch.empty(n, dtype=torch.int32, device=dev)
+        ids = ids.contiguous()
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_pull_keys(nat.ptr(nbr), nbr.numel(), nat.ptr(ids), ids.numel(), W, rank, rows, nat.ptr(keys), nat.current_stream()))
         _, _, _, uniq, summary = nat.group_by_key(keys, max(1, int(sentinel + 1).bit_length()), sentinel, wait=None)
-        n = uniq.numel()
-        pos = torch.arange(n, device=dev)
-        u = torch.where(pos < summary[2], uniq, torch.full_like(uniq, 2 ** 31 - 1))        # sorted by (owner, id); the tail is uninitialised
-        bounds = torch.arange(W + 1, device=dev, dtype=torch.int32) * rows
-        off = torch.searchsorted(u, bounds)                                                   # [W + 1]
-        cnt = (off[1:] - off[:-1]).to(torch.int32)                                            # ids requested from every owner
-        self._parts = (u, off, cnt, n)
+        self._parts = (uniq, summary, n)
         self._send_requests(dl._pull_capacity(n))
         self.done = None
 
     def _send_requests(self, C: int):
         """Every owner receives its block of ``C`` id slots (-1 = unused) and every rank the whole count matrix; nothing here waits for the GPU."""
+        from . import _native as nat
         dl = self.dl
         W, dev, rows = dl.W, dl.device, dl.num_rows
-        u, off, cnt, n = self._parts
-        col = torch.arange(C, device=dev)
-        idx = (off[:W].unsqueeze(1) + col.unsqueeze(0)).clamp(max=n - 1)
-        valid = col.unsqueeze(0) < cnt.unsqueeze(1)
-        base = (torch.arange(W, device=dev, dtype=torch.int32) * rows).unsqueeze(1)
-        self.req = torch.where(valid, u[idx] - base, torch.full((1, 1), -1, dtype=torch.int32, device=dev))       # [W, C] global ids
+        uniq, summary, n = self._parts
+        self.req = torch.empty((W, C), dtype=torch.int32, device=dev)
+        cnt = torch.empty(W, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(nat.load_library().lstep_pull_blocks(nat.ptr(uniq), nat.ptr(summary), W, rows, C, nat.ptr(self.req), nat.ptr(cnt),
+                                                           nat.current_stream()))
         self.C = C
         group = dl.pull_group
         self.asked = exchange_rows(self.req.reshape(W * C), [C] * W, [C] * W, group, async_op=True)       # [W * C]: block p = what rank p wants from me
@@ -330,7 +332,7 @@ class RowPull:
             # some owner was asked for more ids than a block holds (ids concentrated on one owner: every rank sees the same matrix and
             # takes this branch together): send the lists again in blocks that hold any list, then go on
             self.asked.wait()
-            self._send_requests(self._parts[3])
+            self._send_requests(self._parts[2])
             dl._pull_min_capacity = max(dl._pull_min_capacity, max(max(row) for row in cm))
             C = self.C
             if self.cm_event is not None:
@@ -441,6 +443,10 @@ class DistributedLstep:
         self.replicated = self.form == "replicate"
         self.pull_group = None
         self._pending_pull, self._pull_min_capacity = None, 0
+        # the pull's own stream: its request (a sampler launch and a ~1 M-key sort) runs beside the forward pass, its row exchange behind
+        # update_pe -- on neither the critical stream nor in front of update_pe on the update stream
+        self._pull_stream = (torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("LSTEP_PULL_PRIORITY", "1") == "1" else 0)
+                             if torch.device(dev).type == "cuda" else None)
         if self.form in ("replicate", "pull"):
             self._ring = ShardedSparseRing(self.table, self.W, self.rank, self.bb.num_fft_batches)
             engine.ring = self._ring        # (lets the engine's grouping helpers take their device-count branch; its own iterations are not used)
@@ -537,7 +543,7 @@ class DistributedLstep:
         order = torch.argsort(owner, stable=True)                      # bn is sorted by id: this orders it by (owner rank, node id)
         first = sum(counts[:self.rank])
         owned_idx = order[first:first + counts[self.rank]]             # positions in bn of the nodes this rank owns
-        self._owned_idx = owned_idx
+        self._owned_idx, self._owner_order = owned_idx, order
         mine = bn[owned_idx]                                           # (sizes known on the host: no boolean-mask compaction)
         self.ring.wait_window()
         rows_mine = self.bb.filter_history(self.ring.buf, self.ring.geom(), mine // self.W, batch_idx, mask=self.ring.mask,
@@ -718,15 +724,18 @@ class DistributedLstep:
 
     def _owned_positions(self, bn, owner_counts):
         order = torch.argsort(bn % self.W, stable=True)
+        self._owner_order = order
         first = sum(owner_counts[:self.rank])
         return order[first:first + owner_counts[self.rank]]
 
-    def _share_phase1_rows(self, owner_counts):
+    def _share_phase1_rows(self, owner_counts, bn):
         """``update_pe_device(after_phase1=...)``: phase 2's messages carry the phase-1 rows of ALL batch nodes (models/LSTEP.py:311-320),
-        so every owner hands out the ones it just computed -- the "all-gather of updated positional encodings" of north_star: U x 692 B."""
+        so every owner hands out the ones it just computed -- the "all-gather of updated positional encodings" of north_star: U x 688 B.
+        Every rank knows which rows arrive in which order (the batch nodes by (owner, id): ``_owner_order``): plain rows travel."""
         def share(ids1):
             if not _skip_single(self.W):
-                self._write_rows(all_gather_var(self._rows_with_ids(ids1), self.group, counts=owner_counts)[0])
+                rows_all, _ = all_gather_var(self.table.index_select(0, ids1), self.group, counts=owner_counts)
+                self.table.index_copy_(0, bn.index_select(0, self._owner_order), rows_all)
         return share
 
     def full_table(self) -> torch.Tensor:
@@ -775,26 +784,39 @@ class DistributedLstep:
             self._prefetch(lookahead[:2])
         ahead = lookahead if (lookahead is not None and len(lookahead) >= 4) else None
         nxt = None
+        ps = self._pull_stream
+        if ahead is not None:       # the next batch's requests: independent of everything this iteration computes
+            if ps is not None:
+                ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                nxt = RowPull(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]))
 
         def update_and_append():
-            nonlocal nxt
-            if ahead is not None:       # the next batch's requests: independent of this update, issued first so the counts reach the host early
-                nxt = RowPull(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]))
             bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building(),
                                 mirror_shard=(self.W, self.rank), owner=(self.W, self.rank), owned_idx=owned_idx,
-                                after_phase1=self._share_phase1_rows(owner_counts))
+                                after_phase1=self._share_phase1_rows(owner_counts, bn))
             if batch_idx == 0 and initial_pe is not None:
                 self.sync_full_table()
                 initial_pe.copy_(self.table)
             ring.commit()
 
+        def fetch_next(after=None):
+            """Serve and receive the next gather's rows on the pull stream, behind ``after`` (update_pe's end) or the current stream."""
+            if ps is not None:
+                if after is not None:
+                    ps.wait_event(after)
+                else:
+                    ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                self._poison_foreign_rows()
+                nxt.fetch()
+            self._pending_pull = nxt
+
         if loss is None:
             update_and_append()
             ring.apply_advance()
             if nxt is not None:
-                self._poison_foreign_rows()
-                nxt.fetch()
-                self._pending_pull = nxt
+                fetch_next()
             return out
         main, side = torch.cuda.current_stream(self.device), self.eng._update_stream
         overlap = self.eng.overlap_update
@@ -814,22 +836,17 @@ class DistributedLstep:
         if rows_mine.numel():
             rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
         bb.join_aux_stream()
-        all_reduce_gradients(self._trainable, self.group)
+        v = all_reduce_gradients(self._trainable, self.group, extra=torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]]))
         ring.apply_advance()             # the backward pass is enqueued: the window's oldest snapshot may move on behind it
         if nxt is not None:
-            # the rows of the NEXT gather: behind update_pe on its stream (the owners' rows are final there), underneath the backward pass
-            # on the GPU; the host only reads counts that arrived while it was enqueueing the backward pass
-            with torch.cuda.stream(side) if overlap else contextlib.nullcontext():
-                self._poison_foreign_rows()
-                nxt.fetch()
-            self._pending_pull = nxt
+            # the rows of the NEXT gather: behind update_pe (the owners' rows are final there), underneath the backward pass on the GPU;
+            # the host only reads counts that arrived while it was enqueueing the backward pass
+            fetch_next(updated)
         if updated is not None:
             main.wait_event(updated)     # the optimiser may only step once update_pe has read its weights; the ring shard is appended
         optimizer.step()
         self.slot_of.index_fill_(0, bn, -1)
-        v = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
-        all_reduce_sum(v, self.group)
-        out["lp_loss"], out["pe_loss"], out["loss"] = (v / self.W).unbind(0)
+        out["lp_loss"], out["pe_loss"], out["loss"] = (v / self.W).unbind(0)       # global means (they travelled with the gradient bucket)
         return out
 
     def _eval_iteration_pull(self, batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead):
@@ -854,16 +871,23 @@ class DistributedLstep:
         if lookahead is not None:
             self._prefetch(lookahead[:2])
         nxt = None
+        ps = self._pull_stream
         if lookahead is not None and len(lookahead) >= 5:
-            nxt = RowPull(self, *self._slice_rows((lookahead[0], lookahead[1], lookahead[3], lookahead[4]), lookahead[2]), key=TensorsKey(*lookahead[:5]))
+            if ps is not None:
+                ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                nxt = RowPull(self, *self._slice_rows((lookahead[0], lookahead[1], lookahead[3], lookahead[4]), lookahead[2]), key=TensorsKey(*lookahead[:5]))
         bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, changed=ring.written, mirror=ring.building(),
                             mirror_shard=(self.W, self.rank), owner=(self.W, self.rank), owned_idx=owned_idx,
-                            after_phase1=self._share_phase1_rows(owner_counts))
+                            after_phase1=self._share_phase1_rows(owner_counts, bn))
         ring.commit()
         ring.apply_advance()
         if nxt is not None:
-            self._poison_foreign_rows()
-            nxt.fetch()
+            if ps is not None:
+                ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                self._poison_foreign_rows()
+                nxt.fetch()
             self._pending_pull = nxt
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}
 
@@ -908,15 +932,13 @@ class DistributedLstep:
         if rows_mine.numel():
             rows_mine.backward(g_mine)                   # -> fft_filter / fft_agg through this rank's history shard
         bb.join_aux_stream()
-        all_reduce_gradients(self._trainable, self.group)
+        v = all_reduce_gradients(self._trainable, self.group, extra=torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]]))
         ring.apply_advance()             # the backward pass is enqueued: the window's oldest snapshot may move on behind it
         if overlap:
             main.wait_stream(side)       # the optimiser may only step once update_pe has read its weights
         optimizer.step()
         self.slot_of.index_fill_(0, bn, -1)
-        v = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
-        all_reduce_sum(v, self.group)
-        out["lp_loss"], out["pe_loss"], out["loss"] = (v / self.W).unbind(0)
+        out["lp_loss"], out["pe_loss"], out["loss"] = (v / self.W).unbind(0)       # global means (they travelled with the gradient bucket)
         return out
 
     def _eval_iteration_replicated(self, batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead):
