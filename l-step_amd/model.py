@@ -545,8 +545,12 @@ def wait_aux_param_update(dev):
 _DEFERRED = {}     # device -> callables: auxiliary-stream work whose launch is postponed until the critical kernels are out
 
 
-def _defer(dev, fn):
-    _DEFERRED.setdefault(torch.device(dev), []).append(fn)
+def _defer(dev, fn, front: bool = False):
+    q = _DEFERRED.setdefault(torch.device(dev), [])
+    if front:       # (the products must precede the work that consumes them, which an earlier node of the backward pass may have queued)
+        q.insert(0, fn)
+    else:
+        q.append(fn)
 
 
 def _flush_deferred(dev=None):
@@ -611,13 +615,23 @@ class _FusedTail(torch.autograd.Function):
             aux = ctx.aux
             ready = torch.cuda.Event()
             ready.record()
-            # the four products themselves go out now (four launches, ~50 us of host time: they are the long pole of the auxiliary
-            # stream); what consumes them (weight-composition backward, gradient assignment) is postponed
-            with torch.cuda.stream(aux):
-                aux.wait_event(ready)
-                weight_gradients()
-            for t in (d_h1, d_p1, d_z, g_out, x_edge, x_pe, cat1, cat2):
-                t.record_stream(aux)
+
+            def products():
+                with torch.cuda.stream(aux):
+                    aux.wait_event(ready)
+                    weight_gradients()
+                for t in (d_h1, d_p1, d_z, g_out, x_edge, x_pe, cat1, cat2):
+                    t.record_stream(aux)
+
+            if os.environ.get("LSTEP_WGRAD_LATE") != "1":
+                # the four products themselves go out now (four launches, ~50 us of host time: they are the long pole of the auxiliary
+                # stream); what consumes them (weight-composition backward, gradient assignment) is postponed
+                products()
+            else:
+                # (A/B switch, off: submit the critical gather backward -> sort -> segment sums -> filter backward chain BEFORE the products;
+                # in the PROFILED replay the gather backward starts 0.65 ms after its input is ready, profiles/r03_b_timeline.txt, but the
+                # un-profiled step does not move: 3.33 against 3.35 ms.  DESIGN.md appendix A.)
+                _defer(dev, products, front=True)
             grads = tuple(gb)
         else:
             grads = weight_gradients()
@@ -1022,7 +1036,8 @@ class _GatherAggregate(torch.autograd.Function):
                     t_.record_stream(aux)
                 g_w.record_stream(torch.cuda.current_stream(dev))
         g_w_done = g_w is not None
-        _flush_deferred(dev)     # the critical kernel is out: now launch the postponed auxiliary-stream work
+        if os.environ.get("LSTEP_WGRAD_LATE") != "1":
+            _flush_deferred(dev)     # the critical kernel is out: now launch the postponed auxiliary-stream work
         if use_slot:
             grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self, ctx.self_groups)
         if g_w is None and slot_dot is not None:
@@ -1159,6 +1174,7 @@ class _HistoryFilter(torch.autograd.Function):
                                                                 nat.ptr(g), nat.ptr(partial), ctx.ring, nat.current_stream()))
                     diff = partial.sum(dim=0)
                     nat.check(lib.lstep_history_filter_runs_finish(nat.ptr(diff), t_len, P, nat.ptr(g_coef), nat.current_stream()))
+        _flush_deferred(ids.device)      # the critical chain is out: now the postponed parameter-gradient work (see ``_FusedTail.backward``)
         return g_coef, None, None, None, None, None, None, None, None
 
 
