@@ -104,21 +104,39 @@ def default_workload(gpus: int) -> str:
     return "synth-4M-100M" if gpus >= 8 else "synth-1M-20M"
 
 
+def visible_gpus() -> int:
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent of the ranks must stay GPU-free: a process that
+    has initialised HIP must not fork / exec workers): the *_VISIBLE_DEVICES lists if set, otherwise the KFD topology (GPU nodes have a
+    non-zero simd_count)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return -1        # unknown: let the ranks fail fast on a missing device
+    return n
+
+
 def launch_ranks(gpus: int, argv) -> int:
-    import socket
     import subprocess
-    have = torch.cuda.device_count()       # (does not initialise the GPU runtime)
-    if have < gpus and os.environ.get("LSTEP_SINGLE_DEVICE") != "1":
+    have = visible_gpus()
+    if 0 <= have < gpus and os.environ.get("LSTEP_SINGLE_DEVICE") != "1":
         print(f"bench.py: --gpus {gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: torchrun picks (and keeps) a free rendezvous port itself -- no bind-then-release race
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={gpus}",
+           os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
 
 

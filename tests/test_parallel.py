@@ -169,9 +169,17 @@ def _gpu_worker(rank, world, port, q, backend="gloo", ahead=False):
         np.testing.assert_allclose(dl.ring.as_reference_tensor().cpu().numpy(), z["train/final_history"][rank::world, -TRACE_T:, :], **tol)
         model.eval()
         with torch.no_grad():
-            for b, (src, dst, t, eid, neg_src, neg_dst) in enumerate(eval_batches(g)):
+            ebatches = eval_batches(g)
+            eneg = [(torch.from_numpy(b_[4]).to(dev), torch.from_numpy(b_[5]).to(dev)) for b_ in ebatches]
+            for b, (src, dst, t, eid, neg_src, neg_dst) in enumerate(ebatches):
                 lo = TRACE_START + (TRACE_BATCHES + b) * TRACE_B
-                res = dl.eval_iteration(b, *stream.batch(lo, lo + TRACE_B), torch.from_numpy(neg_src).to(dev), torch.from_numpy(neg_dst).to(dev))
+                nxt = None
+                if ahead and b + 1 < len(ebatches):            # the evaluation loop's look-ahead names both negative sets
+                    s2, d2, t2, _ = stream.batch(lo + TRACE_B, lo + 2 * TRACE_B)
+                    nxt = (s2, d2, t2, eneg[b + 1][0], eneg[b + 1][1])
+                res = dl.eval_iteration(b, *stream.batch(lo, lo + TRACE_B), eneg[b][0], eneg[b][1], lookahead=nxt)
+                if pull and ahead:
+                    assert (dl._pending_pull is not None) == (nxt is not None)
                 np.testing.assert_allclose(global_predicts(res["predicts"]), z[f"eval/b{b}/predicts"], **tol)
                 check_table(z[f"eval/b{b}/snapshot"])
         # LSTEP_PULL_POISON=1 did poison: rows nobody delivered were NaN in the cache (and no result above ever saw one)
