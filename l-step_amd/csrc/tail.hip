@@ -95,14 +95,24 @@ __global__ __launch_bounds__(kBlock, 1) void tail_fwd_kernel(const TailFwdParams
     }
     mma_wx<kTp, S>(q, wlane(p.wq, kC2), kC2, kTp, c2_l);
     mma_wr<kTp, S, kTp>(q, wlane(p.wq + kPp, kC2), kC2, p1);
+    {   // the own rows as ONE batch of loads (p1 is dead: its registers take them).  Loaded tile by tile, each load waits out a full memory
+        // latency behind the previous tile's store -- the compiler may not hoist a load over a store that might alias, and the wave has its
+        // SIMD to itself: nothing covers the wait.
+        f32x4 own[kTp][S];
 #pragma unroll
-    for (int t = 0; t < kTp; ++t) {
+        for (int t = 0; t < kTp; ++t) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const f32x4 own = *reinterpret_cast<const f32x4*>(p.c2 + row[s] * kC2 + 16 * t + 4 * g);
+            for (int s = 0; s < S; ++s) own[t][s] = ldv4(p.c2 + row[s] * kC2 + 16 * t + 4 * g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) q[t][s][v] = own[v] + tanhf(q[t][s][v]);
-            if (live[s]) *reinterpret_cast<f32x4*>(p.c1 + row[s] * kC1 + kFn + kCe + 16 * t + 4 * g) = q[t][s];
+        for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) q[t][s][v] = own[t][s][v] + tanh_fast(q[t][s][v]);
+                if (live[s]) *reinterpret_cast<f32x4*>(p.c1 + row[s] * kC1 + kFn + kCe + 16 * t + 4 * g) = q[t][s];
+            }
         }
     }
 
@@ -202,18 +212,28 @@ __global__ __launch_bounds__(kBlock, 1) void tail_bwd_kernel(const TailBwdParams
         f32x4 dq[kTp][S], dz[kTp][S];
         zero(dq, kTp);
         mma_wx<kTp, S>(dq, wlane(p.wallt + (size_t)(kFn + kCe) * kFn, kFn), kFn, kTn, g_l);
+        {   // q and own as ONE batch of loads (q lands in dz's registers), then the arithmetic and the stores: see tail_fwd_kernel
+            f32x4 ov[kTp][S];
 #pragma unroll
-        for (int t = 0; t < kTp; ++t) {
+            for (int t = 0; t < kTp; ++t) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const f32x4 qv = ldv4(p.c1 + row[s] * kC1 + kFn + kCe + 16 * t + 4 * g);
-                const f32x4 ov = ldv4(p.c2 + row[s] * kC2 + 16 * t + 4 * g);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float th = qv[v] - ov[v];   // tanh(z), from q = own + tanh(z)
-                    dz[t][s][v] = dq[t][s][v] * (1.f - th * th);
+                for (int s = 0; s < S; ++s) {
+                    dz[t][s] = ldv4(p.c1 + row[s] * kC1 + kFn + kCe + 16 * t + 4 * g);
+                    ov[t][s] = ldv4(p.c2 + row[s] * kC2 + 16 * t + 4 * g);
                 }
-                if (live[s]) *reinterpret_cast<f32x4*>(p.dz + row[s] * kPp + 16 * t + 4 * g) = dz[t][s];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float th = dz[t][s][v] - ov[t][s][v];   // tanh(z), from q = own + tanh(z)
+                        dz[t][s][v] = dq[t][s][v] * (1.f - th * th);
+                    }
+                    if (live[s]) *reinterpret_cast<f32x4*>(p.dz + row[s] * kPp + 16 * t + 4 * g) = dz[t][s];
+                }
             }
         }
         mma_wr<kTp, S, kTp>(dq, wlane(p.wqt, kPp), kPp, dz);   // d_own = d_q + WqT[own rows] d_z
@@ -225,14 +245,22 @@ __global__ __launch_bounds__(kBlock, 1) void tail_bwd_kernel(const TailBwdParams
         }
         zero(dq, kTp);                                          // now d_p1
         mma_wr<kTp, S, kTp>(dq, wlane(p.wqt + (size_t)kPp * kPp, kPp), kPp, dz);
+        {   // p1 as one batch of loads (dz is dead)
+            f32x4 pv[kTp][S];
 #pragma unroll
-        for (int t = 0; t < kTp; ++t) {
+            for (int t = 0; t < kTp; ++t) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const f32x4 pv = ldv4(p.c2 + row[s] * kC2 + kPp + 16 * t + 4 * g);
+                for (int s = 0; s < S; ++s) pv[t][s] = ldv4(p.c2 + row[s] * kC2 + kPp + 16 * t + 4 * g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dq[t][s][v] = pv[v] > 0.f ? dq[t][s][v] : 0.f;
-                if (live[s]) *reinterpret_cast<f32x4*>(p.dp1 + row[s] * kPp + 16 * t + 4 * g) = dq[t][s];
+            for (int t = 0; t < kTp; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) dq[t][s][v] = pv[t][s][v] > 0.f ? dq[t][s][v] : 0.f;
+                    if (live[s]) *reinterpret_cast<f32x4*>(p.dp1 + row[s] * kPp + 16 * t + 4 * g) = dq[t][s];
+                }
             }
         }
         // d_xpe = Wn1T d_p1, 17 output tiles as 9 + 8 (register budget)
@@ -260,13 +288,19 @@ __global__ __launch_bounds__(kBlock, 1) void tail_bwd_kernel(const TailBwdParams
             f32x4 dh[G][S];
             zero(dh, G);
             mma_wx<G, S>(dh, wlane(p.wallt + (size_t)(kFn + 16 * t0) * kFn, kFn), kFn, kTn, g_l);
+            f32x4 hv[G][S];     // h1 as one batch of loads
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) hv[t][s] = ldv4(p.c1 + row[s] * kC1 + kFn + 16 * (t0 + t) + 4 * g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < G; ++t) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const f32x4 hv = ldv4(p.c1 + row[s] * kC1 + kFn + 16 * (t0 + t) + 4 * g);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) dh[t][s][v] = hv[v] > 0.f ? dh[t][s][v] : 0.f;
+                    for (int v = 0; v < 4; ++v) dh[t][s][v] = hv[t][s][v] > 0.f ? dh[t][s][v] : 0.f;
                     if (live[s]) *reinterpret_cast<f32x4*>(p.dh1 + row[s] * kCe + 16 * (t0 + t) + 4 * g) = dh[t][s];
                 }
             }
@@ -309,11 +343,14 @@ struct WaveTiles {
 };
 
 // acc[j] += sum over `chunks` 16-wide k chunks of (weight tile at wt[j])[i][k] * X[row i][k], X from global memory (xl = this lane's position)
-template <int T>
-__device__ __forceinline__ void mma1_wx(f32x4 (&acc)[T], const float* const (&wt)[T], int chunks, const float* xl) {
+// kMasked: X's rows hold only `kvalid` (a multiple of 4) meaningful columns from xl on; lanes that would read past them contribute zeros
+// (as mma_wx_masked, lstep_mma.h).
+template <int T, bool kMasked = false>
+__device__ __forceinline__ void mma1_wx(f32x4 (&acc)[T], const float* const (&wt)[T], int chunks, const float* xl, int kvalid = 0, int g = 0) {
     struct Ch { f32x4 a[T]; f32x4 b; };
     auto load = [&](Ch& o, int c) {
-        o.b = ldv4(xl + 16 * c);
+        if constexpr (kMasked) o.b = 16 * c + 4 * g + 4 <= kvalid ? ldv4(xl + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        else o.b = ldv4(xl + 16 * c);
 #pragma unroll
         for (int j = 0; j < T; ++j) o.a[j] = ldv4(wt[j] + 16 * c);
     };
@@ -436,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void tail_fwd_split_kernel(const TailFwdPar
         for (int j = 0; j < kSplitTp; ++j) {
             const f32x4 own = ldv4(p.c2 + row * kC2 + 16 * tp.t[j] + 4 * g);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[j][v] = own[v] + tanhf(acc[j][v]);
+            for (int v = 0; v < 4; ++v) acc[j][v] = own[v] + tanh_fast(acc[j][v]);
             if (tp.valid[j]) {
                 s_q[tp.t[j] * 64 + lane] = acc[j];
                 if (live) *reinterpret_cast<f32x4*>(p.c1 + row * kC1 + kFn + kCe + 16 * tp.t[j] + 4 * g) = acc[j];
@@ -598,8 +635,9 @@ constexpr int kTd = 112, kTt = kTd / 16;     // padded time width of the pre-mul
 // W1b sum time features, and every message's pe row is one of the U batch-node rows: the caller multiplies those U rows by W1a once
 // (a [U, 172] x [172, 172] product instead of 172 x 172 multiply-adds for each of the ~9 U touched rows), the segment sums run over the
 // products, and agg = [sum W1a pe (176) | sum time features (time_dim)].  Here: h = relu(agg[:176] + W1b agg[176:] + b1), w1 = W1b [176, 112].
-template <int S, bool kPre = false>
+template <int S, bool kPre = false, bool kSelf = false>
 __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) {
+    static_assert(!(kPre && kSelf), "the pre-multiplied form is phase 2: no self term");
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
     const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
@@ -611,50 +649,58 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
     if (r0 >= p.n) return;   // no barriers in this kernel
     if (p.ring_start && p.mirror) p.mirror += (int64_t)((*p.ring_start + p.ring_add) % p.ring_slots) * p.ring_stride;
     bool live[S];
-    const float *agg_l[S], *own_l[S];
-    float* own_row[S];
+    const float* agg_l[S];
+    int64_t id[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         int64_t r = r0 + 16 * s + i;
         live[s] = r < p.n;
         if (!live[s]) r = p.n - 1;
         agg_l[s] = p.agg + r * p.ld_agg + 4 * g;
-        own_row[s] = p.table + p.ids[r] * p.pe_dim;
-        own_l[s] = own_row[s] + 4 * g;
+        id[s] = p.ids[r];
     }
     auto wlane = [&](const float* w, int ldw) { return w + i * ldw + 4 * g; };
-    float* mir_row[S];     // where this row goes in the mirror (NULL: nowhere)
+    // A wave has its SIMD to itself (all 512 registers): whatever it waits for, nothing else on the SIMD covers.  So the row loads are batched
+    // -- straight-line code, every load of a batch issued before the first one is used: the partial sums of the pre-multiplied form up
+    // front, the old table rows (into the registers of the dead hidden layer) after the second layer.  Tile-by-tile loops cost one full
+    // memory latency PER TILE: the compiler may not hoist a load over the previous tile's store (they might alias), and a uniform branch
+    // inside a tile loop splits it into blocks that each end in vmcnt(0).  Measured at 290 k rows: 460 -> 367 us.
+    // (Issuing the batches behind the operand loads of the MFMA phase before them does not help: loads return in order, so the next
+    // weight tiles queue behind the batch, and the batch is a bandwidth-bound burst -- every wave of the launch issues it at the same time.)
+    f32x4 h[kTp][S], z[kTp][S];
+    float *own_row[S], *mir_row[S];     // mir_row: where this row goes in the mirror (NULL: nowhere)
 #pragma unroll
     for (int s = 0; s < S; ++s) {
+        own_row[s] = p.table + id[s] * p.pe_dim;
         mir_row[s] = nullptr;
         if (p.mirror) {
-            const int64_t off = own_row[s] - p.table;
             if (p.mirror_world > 1) {
-                const int64_t id = off / p.pe_dim;
-                if (id % p.mirror_world == p.mirror_rank) mir_row[s] = p.mirror + (id / p.mirror_world) * p.pe_dim;
+                if (id[s] % p.mirror_world == p.mirror_rank) mir_row[s] = p.mirror + (id[s] / p.mirror_world) * p.pe_dim;
             } else {
-                mir_row[s] = p.mirror + off;
+                mir_row[s] = p.mirror + id[s] * p.pe_dim;
             }
-        }
-    }
-    f32x4 h[kTp][S], z[kTp][S];
-#pragma unroll
-    for (int t = 0; t < kTp; ++t) {
-        const f32x4 b1v = ldv4(p.b1 + 16 * t + 4 * g);
-        f32x4 b2v = ldv4(p.b2 + 16 * t + 4 * g);
-        if (p.ws != nullptr) b2v += ldv4(p.bs + 16 * t + 4 * g);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            h[t][s] = b1v;
-            z[t][s] = b2v;
         }
     }
     if constexpr (kPre) {
 #pragma unroll
         for (int t = 0; t < kTp; ++t) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) h[t][s] += ldv4(agg_l[s] + 16 * t);      // accumulator layout = row-major float4 at feature 16 t + 4 g
+            for (int s = 0; s < S; ++s) h[t][s] = ldv4(agg_l[s] + 16 * t);      // accumulator layout = row-major float4 at feature 16 t + 4 g
         }
+    }
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+        const f32x4 b1v = ldv4(p.b1 + 16 * t + 4 * g);
+        f32x4 b2v = ldv4(p.b2 + 16 * t + 4 * g);
+        if constexpr (kSelf) b2v += ldv4(p.bs + 16 * t + 4 * g);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if constexpr (kPre) h[t][s] += b1v;
+            else h[t][s] = b1v;
+            z[t][s] = b2v;
+        }
+    }
+    if constexpr (kPre) {
         const float* tf_l[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) tf_l[s] = agg_l[s] + kPp;
@@ -671,27 +717,22 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
         }
     }
     mma_wr<kTp, S, kTp>(z, wlane(p.w2, kPp), kPp, h);
-    if (!kPre && p.ws != nullptr) {
-        // own rows straight from the table: pe_dim = 172 columns, so the last lane group of the last chunk would read past the
-        // row.  Those lanes re-read the row start instead: the padded weight columns they meet are zero.
-        const int last = (p.pe_dim + 15) / 16 - 1;
-        for (int c = 0; c <= last; ++c) {
-            f32x4 a[kTp], b[S];
-            const bool ok = 16 * c + 4 * g + 4 <= p.pe_dim;
+    if constexpr (kSelf) {
+        // own rows straight from the table: pe_dim = 172 columns, so the last lane group of the last chunk would read past the row: masked
+        // (the padded weight columns it would meet are zero)
+        const float* own_l[S];
 #pragma unroll
-            for (int s = 0; s < S; ++s) b[s] = ldv4(ok ? own_l[s] + 16 * c : own_row[s]);
-#pragma unroll
-            for (int t = 0; t < kTp; ++t) a[t] = ldv4(wlane(p.ws, kPp) + (size_t)16 * t * kPp + 16 * c);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-#pragma unroll
-                for (int t = 0; t < kTp; ++t) {
-#pragma unroll
-                    for (int s = 0; s < S; ++s) z[t][s] = mfma4(a[t][v], b[s][v], z[t][s]);
-                }
-            }
-        }
+        for (int s = 0; s < S; ++s) own_l[s] = own_row[s] + 4 * g;
+        mma_wx_masked<kTp, S>(z, wlane(p.ws, kPp), kPp, (p.pe_dim + 15) / 16, own_l, p.pe_dim, g);
     }
+    f32x4 rows[kTp][S];
+#pragma unroll
+    for (int t = 0; t < kTp; ++t) {
+        const int f = 16 * t + 4 * g;
+#pragma unroll
+        for (int s = 0; s < S; ++s) rows[t][s] = ldv4(f + 4 <= p.pe_dim ? own_row[s] + f : own_row[s]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < kTp; ++t) {
         const int f = 16 * t + 4 * g;
@@ -699,15 +740,116 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 if (live[s]) {
-                    f32x4 old = ldv4(own_row[s] + f);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) old[v] += tanhf(z[t][s][v]);
-                    *reinterpret_cast<f32x4*>(own_row[s] + f) = old;
-                    if (mir_row[s]) *reinterpret_cast<f32x4*>(mir_row[s] + f) = old;
+                    for (int v = 0; v < 4; ++v) rows[t][s][v] += tanh_fast(z[t][s][v]);
+                    *reinterpret_cast<f32x4*>(own_row[s] + f) = rows[t][s];
+                    if (mir_row[s]) *reinterpret_cast<f32x4*>(mir_row[s] + f) = rows[t][s];
                 }
             }
         }
     }
+}
+
+// update_pe for few rows: one slab per workgroup, the 11 output tiles of both layers dealt out to its four waves (as tail_fwd_split_kernel
+// above).  At B = 200 .. 4096 the slab-chain kernel's ~45 us are one wave's walk through 2 x 11 tiles whatever the row count, and
+// update_pe runs it twice per step on the chain of dependent kernels that bounds the small-batch step.  Same products in the same order per
+// output element as update_rows_kernel<1, kPre>.
+template <bool kPre>
+__global__ __launch_bounds__(kBlock) void update_rows_split_kernel(UpdateParams p) {
+    __shared__ f32x4 s_h[kTp * 64];
+    const int lane = lane_id(), w = wave_in_block();
+    const int i = lane & 15, g = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    if (p.live) {
+        const int64_t live = *p.live;
+        if (live < p.n) p.n = live;
+    }
+    if (r0 >= p.n) return;   // the whole workgroup: no wave is left waiting at a barrier
+    if (p.ring_start && p.mirror) p.mirror += (int64_t)((*p.ring_start + p.ring_add) % p.ring_slots) * p.ring_stride;
+    const bool live = r0 + i < p.n;
+    const int64_t r = live ? r0 + i : p.n - 1;
+    const float* agg_l = p.agg + r * p.ld_agg + 4 * g;
+    float* own_row = p.table + p.ids[r] * p.pe_dim;
+    float* mir_row = nullptr;
+    if (p.mirror) {
+        const int64_t id = p.ids[r];
+        if (p.mirror_world > 1) {
+            if (id % p.mirror_world == p.mirror_rank) mir_row = p.mirror + (id / p.mirror_world) * p.pe_dim;
+        } else {
+            mir_row = p.mirror + id * p.pe_dim;
+        }
+    }
+    const WaveTiles<kSplitTp> tp(w, kTp);
+    {   // ---- h = relu(pe_mlp_1(agg))
+        f32x4 acc[kSplitTp];
+        const float* wt[kSplitTp];
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            acc[j] = ldv4(p.b1 + 16 * tp.t[j] + 4 * g);
+            if constexpr (kPre) {
+                acc[j] += ldv4(agg_l + 16 * tp.t[j]);
+                wt[j] = p.w1 + (size_t)(16 * tp.t[j] + i) * kTd + 4 * g;
+            } else {
+                wt[j] = p.w1 + (size_t)(16 * tp.t[j] + i) * kCe + 4 * g;
+            }
+        }
+        if constexpr (kPre) mma1_wx<kSplitTp, true>(acc, wt, kTt, agg_l + kPp, p.time_dim, g);
+        else mma1_wx<kSplitTp>(acc, wt, kTe, agg_l);
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[j][v] = fmaxf(acc[j][v], 0.f);
+            if (tp.valid[j]) s_h[tp.t[j] * 64 + lane] = acc[j];
+        }
+    }
+    __syncthreads();
+    f32x4 z[kSplitTp];
+    {   // ---- z = pe_mlp_2(h) [+ self_update_pe(own)]
+        const float* wt[kSplitTp];
+#pragma unroll
+        for (int j = 0; j < kSplitTp; ++j) {
+            z[j] = ldv4(p.b2 + 16 * tp.t[j] + 4 * g);
+            if (p.ws != nullptr) z[j] += ldv4(p.bs + 16 * tp.t[j] + 4 * g);
+            wt[j] = p.w2 + (size_t)(16 * tp.t[j] + i) * kPp + 4 * g;
+        }
+        mma1_wl<kSplitTp, kTp>(z, wt, s_h, lane);
+        if (!kPre && p.ws != nullptr) {
+            // own rows straight from the table, pe_dim = 172 columns: the lanes that would read past the row re-read its start instead
+            // (the padded weight columns they meet are zero)
+            const int last = (p.pe_dim + 15) / 16 - 1;
+            for (int c = 0; c <= last; ++c) {
+                const bool ok = 16 * c + 4 * g + 4 <= p.pe_dim;
+                const f32x4 b = ldv4(ok ? own_row + 4 * g + 16 * c : own_row);
+                f32x4 a[kSplitTp];
+#pragma unroll
+                for (int j = 0; j < kSplitTp; ++j) a[j] = ldv4(p.ws + (size_t)(16 * tp.t[j] + i) * kPp + 4 * g + 16 * c);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                    for (int j = 0; j < kSplitTp; ++j) z[j] = mfma4(a[j][v], b[v], z[j]);
+                }
+            }
+            __syncthreads();   // every wave has read the whole old rows before any wave writes its columns (ws != NULL is uniform)
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSplitTp; ++j) {
+        const int f = 16 * tp.t[j] + 4 * g;
+        if (tp.valid[j] && live && f + 4 <= p.pe_dim) {
+            f32x4 old = ldv4(own_row + f);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) old[v] += tanh_fast(z[j][v]);
+            *reinterpret_cast<f32x4*>(own_row + f) = old;
+            if (mir_row) *reinterpret_cast<f32x4*>(mir_row + f) = old;
+        }
+    }
+}
+
+constexpr int kUpdateSplitMaxSlabs = 700;     // measured: 11 000 rows 40 / 21 us split vs 43 / 24 us whole (plain / pre-multiplied); 12 800 rows 53 / 26 vs 44 / 24
+
+static bool update_split(int64_t n) {
+    const char* off = getenv("LSTEP_UPDATE_NO_SPLIT");   // A/B and the split-vs-whole parity test: read per call
+    return !(off && off[0] == '1') && (n + 15) / 16 <= kUpdateSplitMaxSlabs;
 }
 
 }  // namespace lstep
@@ -727,6 +869,14 @@ static int tail_slabs_per_wave(int64_t m) {
         if (best_cost < 0 || cost < best_cost) { best = s; best_cost = cost; }
     }
     return best;
+}
+
+// update_pe's kernels: the S = 1 form is compiled for two waves per SIMD (<= 256 registers), so one wave's row loads and stores overlap the
+// other's MFMAs.  LSTEP_UPDATE_S=1|2|3 forces a form (tuning).
+static int update_slabs_per_wave(int64_t n) {
+    const char* force = getenv("LSTEP_UPDATE_S");
+    if (force && force[0] >= '1' && force[0] <= '3') return force[0] - '0';
+    return tail_slabs_per_wave(n);
 }
 
 extern "C" int lstep_tail_fwd(const float* x_edge, int32_t ld_edge, const float* x_pe, int32_t ld_pe, float* cat1, float* cat2, float* out,
@@ -790,13 +940,23 @@ extern "C" int lstep_update_rows(const float* agg, int32_t ld_agg, const int64_t
         return set_error(LSTEP_EINVAL, "lstep_update_rows: bad ring reference");
     UpdateParams p{agg, ids, w1, b1, w2, b2, ws, bs, table, mirror, num_live, ring ? ring->start : nullptr, ring ? ring->add : 0,
                    ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, 0, mirror_world, mirror_rank};
-    const int S = tail_slabs_per_wave(n);
+    hipStream_t s = (hipStream_t)stream;
+    if (update_split(n)) {
+        hipLaunchKernelGGL(update_rows_split_kernel<false>, dim3((unsigned)((n + 15) / 16)), dim3(kBlock), 0, s, p);
+        return check_launch("lstep_update_rows<split>");
+    }
+    const int S = update_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
-    hipStream_t s = (hipStream_t)stream;
-    if (S == 1) hipLaunchKernelGGL(update_rows_kernel<1>, grid, block, 0, s, p);
-    else if (S == 2) hipLaunchKernelGGL(update_rows_kernel<2>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(update_rows_kernel<3>, grid, block, 0, s, p);
+    if (ws) {
+        if (S == 1) hipLaunchKernelGGL((update_rows_kernel<1, false, true>), grid, block, 0, s, p);
+        else if (S == 2) hipLaunchKernelGGL((update_rows_kernel<2, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((update_rows_kernel<3, false, true>), grid, block, 0, s, p);
+    } else {
+        if (S == 1) hipLaunchKernelGGL((update_rows_kernel<1, false, false>), grid, block, 0, s, p);
+        else if (S == 2) hipLaunchKernelGGL((update_rows_kernel<2, false, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((update_rows_kernel<3, false, false>), grid, block, 0, s, p);
+    }
     return check_launch("lstep_update_rows");
 }
 
@@ -816,10 +976,14 @@ extern "C" int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int
         return set_error(LSTEP_EINVAL, "lstep_update_rows_pre: bad ring reference");
     UpdateParams p{agg, ids, w1b, b1, w2, b2, nullptr, nullptr, table, mirror, num_live, ring ? ring->start : nullptr, ring ? ring->add : 0,
                    ring ? ring->slots : 1, ring ? ring->slot_stride : 0, n, ld_agg, pe_dim, time_dim, mirror_world, mirror_rank};
-    const int S = tail_slabs_per_wave(n);
+    hipStream_t s = (hipStream_t)stream;
+    if (update_split(n)) {
+        hipLaunchKernelGGL(update_rows_split_kernel<true>, dim3((unsigned)((n + 15) / 16)), dim3(kBlock), 0, s, p);
+        return check_launch("lstep_update_rows_pre<split>");
+    }
+    const int S = update_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;
     const dim3 grid((unsigned)((tasks + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
-    hipStream_t s = (hipStream_t)stream;
     if (S == 1) hipLaunchKernelGGL((update_rows_kernel<1, true>), grid, block, 0, s, p);
     else if (S == 2) hipLaunchKernelGGL((update_rows_kernel<2, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((update_rows_kernel<3, true>), grid, block, 0, s, p);

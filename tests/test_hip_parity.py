@@ -824,6 +824,65 @@ def test_dense_tail_split_kernels_match_whole_slab_kernels_and_float64(hip, monk
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), name
 
 
+@pytest.mark.parametrize("n", [1, 200, 601, 9000, 12000])
+@pytest.mark.parametrize("form", ["phase1", "phase2", "premultiplied"])
+def test_update_rows_split_kernels_match_whole_slab_kernels_and_float64(hip, monkeypatch, n, form):
+    """lstep_update_rows / _pre pick the one-slab-per-workgroup kernel (output tiles dealt out to the four waves, the hidden layer handed on
+    through LDS) for up to 700 slabs and the slab-chain kernels beyond; LSTEP_UPDATE_NO_SPLIT=1 forces the latter.  Both against float64
+    (models/LSTEP.py:292-303 phase 1 with self_update_pe, :327-339 phase 2), with a device-resident live count below the launch's
+    capacity and an owner-sharded mirror slot; rows outside ``ids[:live]`` must stay untouched."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    gen = torch.Generator(device=DEV).manual_seed(17 * n + len(form))
+    rnd = lambda *sh, s=1.0: s * torch.randn(*sh, device=DEV, generator=gen)  # noqa: E731
+    N, P, TD, W, R = 3 * n + 40, 172, 100, 3, 1
+    live_n = max(1, n - 5)
+    table0 = rnd(N, P, s=0.3)
+    ids = torch.randperm(N, device=DEV, generator=gen)[:n].contiguous()
+    pad = lambda w, r, c: torch.nn.functional.pad(w, (0, c - w.shape[1], 0, r - w.shape[0])).contiguous()  # noqa: E731
+    w1, b1, w2, b2, ws, bs = rnd(P, P + TD, s=0.07), rnd(P, s=0.1), rnd(P, P, s=0.07), rnd(P, s=0.1), rnd(P, P, s=0.07), rnd(P, s=0.1)
+    pe_sum, tf_sum = rnd(n, P), rnd(n, TD)
+    d = lambda t: t.double()  # noqa: E731
+    h = torch.relu(torch.cat([d(pe_sum), d(tf_sum)], 1) @ d(w1).t() + d(b1))
+    z = h @ d(w2).t() + d(b2)
+    if form == "phase1":
+        z = z + d(table0[ids]) @ d(ws).t() + d(bs)
+    want = d(table0).clone()
+    want[ids[:live_n]] += torch.tanh(z[:live_n])
+    b1p, b2p, bsp = (torch.nn.functional.pad(b, (0, 4)).contiguous() for b in (b1, b2, bs))
+    w1p, w1b, w2p, wsp = pad(w1, 176, P + TD), pad(w1[:, P:], 176, 112), pad(w2, 176, 176), pad(ws, 176, 176)
+    live = torch.tensor([live_n], dtype=torch.int32, device=DEV)
+    got = {}
+    for split in (True, False):
+        monkeypatch.setenv("LSTEP_UPDATE_NO_SPLIT", "0" if split else "1")
+        table = table0.clone()
+        mirror = torch.full(((N + W - 1) // W, P), float("nan"), device=DEV)
+        if form == "premultiplied":
+            agg = torch.zeros(n, 176 + TD, device=DEV)
+            agg[:, :P] = (d(pe_sum) @ d(w1[:, :P]).t()).float()
+            agg[:, 176:] = tf_sum
+            nat.check(lib.lstep_update_rows_pre(nat.ptr(agg), 176 + TD, nat.ptr(ids), n, nat.ptr(w1b), nat.ptr(b1p), nat.ptr(w2p), nat.ptr(b2p),
+                                                nat.ptr(table), nat.ptr(mirror), P, TD, nat.ptr(live), None, W, R, nat.current_stream()))
+        else:
+            agg = torch.cat([pe_sum, tf_sum], 1).contiguous()
+            with_self = form == "phase1"
+            nat.check(lib.lstep_update_rows(nat.ptr(agg), P + TD, nat.ptr(ids), n, nat.ptr(w1p), nat.ptr(b1p), nat.ptr(w2p),
+                                            nat.ptr(b2p), nat.ptr(wsp) if with_self else None, nat.ptr(bsp) if with_self else None, nat.ptr(table),
+                                            nat.ptr(mirror), P, nat.ptr(live), None, W, R, nat.current_stream()))
+        torch.cuda.synchronize()
+        got[split] = table
+        assert float((table.double() - want).abs().max()) <= 2e-5, (split, form)
+        untouched = torch.ones(N, dtype=torch.bool, device=DEV)
+        untouched[ids[:live_n]] = False
+        assert torch.equal(table[untouched], table0[untouched])
+        mine = ids[:live_n][ids[:live_n] % W == R]
+        assert torch.equal(mirror[mine // W], table[mine])
+        others = torch.ones(mirror.shape[0], dtype=torch.bool, device=DEV)
+        others[mine // W] = False
+        assert bool(torch.isnan(mirror[others]).all())
+    assert float((got[True] - got[False]).abs().max()) <= 2e-6     # same products in the same order per output element
+
+
 @pytest.mark.parametrize("n", [1, 200, 601, 8192])
 def test_link_predictor_split_kernels_match_whole_slab_kernels_and_float64(hip, monkeypatch, n):
     """lstep_head_fwd / _bwd: the one-slab-per-workgroup kernels (up to 512 slabs of 16 edges) and the one-slab-per-wave kernels
