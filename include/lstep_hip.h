@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 30
+#define LSTEP_ABI_VERSION 31
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -316,12 +316,16 @@ int lstep_sort_live(const int32_t* keys, int64_t n, int32_t key_bits, void* work
  *   loss = (1 - pe_weight) * lp_loss + pe_weight * pe_loss,
  * e_x = rows[slot_of[x]] if slot_of[x] >= 0 (the spliced, differentiable row of batch node x) else table[x].
  * logits [2 n] (positive | negative edges), ids int64 [3 n] (src | dst | negative dst).  Outputs: predicts [2 n] (the clamped
- * probabilities), losses [3] = {lp_loss, pe_loss, loss}, and the gradient of `loss`: d_logits [2 n], d_rows [U, pe_dim]
- * (accumulated with float atomics: the caller zeroes it).  workspace: lstep_link_loss_workspace(n) bytes. */
+ * probabilities), losses [3] = {lp_loss, pe_loss, loss}, and the gradient of `loss`: d_logits [2 n], and for the positional-encoding
+ * rows one gradient row PER OCCURRENCE, g_rows [3 n, pe_dim] (16-byte aligned): row i = d loss / d e_src of edge i, row n + i = d e_dst,
+ * row 2 n + i = d e_neg, with neg_slot [n] = slot_of[negative endpoint of edge i].  The gradient of spliced row u is the sum of the rows
+ * whose endpoint is u: the caller reduces them with lstep_segment_rows_sum over its grouping of cat[src, dst] by batch node (fixed
+ * summation order) and lstep_scatter_add_rows for the negatives that happen to be batch nodes -- no atomics on hub rows.
+ * workspace: lstep_link_loss_workspace(n) bytes. */
 int64_t lstep_link_loss_workspace(int64_t n);
 int lstep_link_loss(const float* logits, const int64_t* ids, int64_t n, const float* table, const float* rows, const int32_t* slot_of,
-                    int32_t pe_dim, float pe_weight, float neg_weight, float* predicts, float* d_logits, float* d_rows, float* losses,
-                    void* workspace, int64_t workspace_bytes, void* stream);
+                    int32_t pe_dim, float pe_weight, float neg_weight, float* predicts, float* d_logits, float* g_rows, int32_t* neg_slot,
+                    float* losses, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Link predictor (models/modules.py:42-68, MergeLayer) over the padded embeddings emb [rows, 176] of one batch, with no
  * concatenation materialised: for edge e < n the positive pair is (emb[pos_first + e], emb[pos_second + e]), the negative pair

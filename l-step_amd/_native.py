@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 30
+ABI_VERSION = 31
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -129,7 +129,7 @@ SIGNATURES = {
     "lstep_head_bwd": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_head_pack": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "lstep_link_loss_workspace": (_I64, [_I64]),
-    "lstep_link_loss": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _I64, _P]),
+    "lstep_link_loss": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "lstep_sort_live_workspace": (_I64, [_I64, _I32]),
     "lstep_sort_live": (C.c_int, [_P, _I64, _I32, _P, _I64, _P, _P, C.POINTER(C.c_int64), _P]),
     "lstep_linear_wgrad_workspace": (_I64, [_I64, _I32, _I32]),

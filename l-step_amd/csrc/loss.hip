@@ -5,6 +5,9 @@
 // with e_x = the CURRENT positional-encoding row of node x: the spliced FFT row rows[slot_of[x]] when x is a batch node (that row
 // carries gradient), else the constant table row.  The ~25 small launches of the framework's forward and the ~35 of its backward
 // become one launch + a fixed-order reduction of the per-workgroup partial sums.
+// The gradient of the spliced rows leaves as one row PER OCCURRENCE (edge i: its source, destination and negative endpoint), streamed out:
+// the caller reduces the rows by spliced row with lstep_segment_rows_sum over the grouping of cat[src, dst] it already has (deterministic,
+// hub-safe).  Float atomics into the spliced rows instead (8.4 M of them at B = 16384) cost 72 us of the 1 M-node step.
 #include "lstep_common.h"
 
 namespace lstep {
@@ -17,7 +20,8 @@ struct LinkLossParams {
     const int32_t* slot_of;  // [N + 1]
     float* predicts;         // [2 n]
     float* d_logits;         // [2 n]
-    float* d_rows;           // [U, P], zero on entry
+    float* g_rows;           // [3 n, P] gradient of e_src (row i), e_dst (n + i), e_neg (2 n + i) of edge i
+    int32_t* neg_slot;       // [n] slot_of[negative endpoint of edge i]
     float* partial;          // [grid, 3]
     int64_t n;
     int32_t pe_dim;
@@ -63,20 +67,11 @@ __global__ __launch_bounds__(kBlock) void link_loss_kernel(const LinkLossParams 
             sp += dpx * dpx + dpy * dpy + dpz * dpz + dpw * dpw;
             sn += dnx * dnx + dny * dny + dnz * dnz + dnw * dnw;
             const float w = q.neg_weight;
-            if (sa >= 0) {
-                float* d = q.d_rows + (int64_t)sa * P + c0;
-                atomicAdd(d + 0, gs * (dpx - w * dnx)); atomicAdd(d + 1, gs * (dpy - w * dny));
-                atomicAdd(d + 2, gs * (dpz - w * dnz)); atomicAdd(d + 3, gs * (dpw - w * dnw));
-            }
-            if (sb >= 0) {
-                float* d = q.d_rows + (int64_t)sb * P + c0;
-                atomicAdd(d + 0, -gs * dpx); atomicAdd(d + 1, -gs * dpy); atomicAdd(d + 2, -gs * dpz); atomicAdd(d + 3, -gs * dpw);
-            }
-            if (sc >= 0) {
-                float* d = q.d_rows + (int64_t)sc * P + c0;
-                atomicAdd(d + 0, gs * w * dnx); atomicAdd(d + 1, gs * w * dny); atomicAdd(d + 2, gs * w * dnz); atomicAdd(d + 3, gs * w * dnw);
-            }
+            st4(q.g_rows + i * P + c0, make_float4(gs * (dpx - w * dnx), gs * (dpy - w * dny), gs * (dpz - w * dnz), gs * (dpw - w * dnw)));
+            st4(q.g_rows + (q.n + i) * P + c0, make_float4(-gs * dpx, -gs * dpy, -gs * dpz, -gs * dpw));
+            st4(q.g_rows + (2 * q.n + i) * P + c0, make_float4(gs * w * dnx, gs * w * dny, gs * w * dnz, gs * w * dnw));
         }
+        if (lane == 0) q.neg_slot[i] = sc;
     }
     bce = wave_sum(bce); sp = wave_sum(sp); sn = wave_sum(sn);
     if (lane == 0) { sh[wave][0] = bce; sh[wave][1] = sp; sh[wave][2] = sn; }
@@ -119,14 +114,15 @@ extern "C" int64_t lstep_link_loss_workspace(int64_t n) {
 }
 
 extern "C" int lstep_link_loss(const float* logits, const int64_t* ids, int64_t n, const float* table, const float* rows, const int32_t* slot_of,
-                               int32_t pe_dim, float pe_weight, float neg_weight, float* predicts, float* d_logits, float* d_rows, float* losses,
-                               void* workspace, int64_t workspace_bytes, void* stream) {
+                               int32_t pe_dim, float pe_weight, float neg_weight, float* predicts, float* d_logits, float* g_rows, int32_t* neg_slot,
+                               float* losses, void* workspace, int64_t workspace_bytes, void* stream) {
     if (n <= 0 || pe_dim <= 0 || (pe_dim & 3)) return set_error(LSTEP_EINVAL, "lstep_link_loss: bad sizes (n > 0, pe_dim a multiple of 4)");
-    if (!logits || !ids || !table || !rows || !slot_of || !predicts || !d_logits || !d_rows || !losses || !workspace)
+    if (!logits || !ids || !table || !rows || !slot_of || !predicts || !d_logits || !g_rows || !neg_slot || !losses || !workspace)
         return set_error(LSTEP_EINVAL, "lstep_link_loss: NULL pointer");
+    if (((uintptr_t)g_rows) & 15) return set_error(LSTEP_EINVAL, "lstep_link_loss: g_rows must be 16-byte aligned");
     if (workspace_bytes < lstep_link_loss_workspace(n)) return set_error(LSTEP_EINVAL, "lstep_link_loss: workspace too small");
     const int blocks = (int)(lstep_link_loss_workspace(n) / (3 * sizeof(float)));
-    LinkLossParams q{logits, ids, table, rows, slot_of, predicts, d_logits, d_rows, (float*)workspace, n, pe_dim, pe_weight, neg_weight};
+    LinkLossParams q{logits, ids, table, rows, slot_of, predicts, d_logits, g_rows, neg_slot, (float*)workspace, n, pe_dim, pe_weight, neg_weight};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(link_loss_kernel, dim3(blocks), dim3(kBlock), 0, s, q);
     hipLaunchKernelGGL(link_loss_finish_kernel, dim3(1), dim3(kWave), 0, s, (const float*)workspace, blocks, n, pe_dim, pe_weight, neg_weight, losses);

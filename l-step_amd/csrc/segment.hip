@@ -7,7 +7,10 @@
 namespace lstep {
 
 constexpr int kSegInFlight = 8;
-constexpr int kChunk = 64;   // entries per wave: bounds the work of one wave whatever the segment-length distribution is
+constexpr int kShort = 64;   // segments of up to 64 entries are summed by one wave; longer ones (hub nodes) are cut at the chunk boundaries
+// Entries per wave (`chunk`, a launch parameter): 64 for long lists, 16 for short ones.  A wave keeps 8 rows in flight, so a 64-entry chunk
+// is 8 dependent rounds of memory latency whatever the list length: 32 768 entries = 512 waves took 38 us (22 MB: latency, not bandwidth).
+__host__ __device__ inline int segment_chunk(int64_t num_entries) { return num_entries <= 65536 ? 16 : 64; }
 
 // flush one run of a segment: plain store when this chunk holds the whole segment.  A segment split over several chunks (long segments =
 // hub nodes): with a scratch buffer (`part`, this run's slot) the partial sum is parked there and segment_join_split_rows_kernel adds the
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
                                                                    const float* __restrict__ ent_dt, int64_t num_entries,
                                                                    float* __restrict__ out, int ld_out, bool accumulate,
                                                                    const int32_t* __restrict__ num_live, float* __restrict__ parts,
-                                                                   int32_t* __restrict__ chunk_flags, int row_div) {
+                                                                   int32_t* __restrict__ chunk_flags, int row_div, int kChunk) {
     const int lane = lane_id();
     const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t e0 = chunk * kChunk;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
     if (e0 > 0 && ent_seg[e0 - 1] == seg_first) {
         const int back = run_backward(ent_seg, e0, seg_first, lane);
         const int lead = run_forward(ent_seg, e0, num_entries, seg_first, lane);
-        if (back + lead <= kChunk) b0 = e0 + lead; else head_cut = true;
+        if (back + lead <= kShort) b0 = e0 + lead; else head_cut = true;
     }
     // tail: a segment that goes on into the next chunk.  Short and begun here: read on to its end; long: cut.
     int64_t b1 = e1;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
     if (e1 < num_entries && ent_seg[e1] == seg_last) {
         const int tail = run_backward(ent_seg, e1, seg_last, lane);
         const int fwd = run_forward(ent_seg, e1, num_entries, seg_last, lane);
-        if (tail + fwd <= kChunk) b1 = e1 + fwd; else tail_cut = true;
+        if (tail + fwd <= kShort) b1 = e1 + fwd; else tail_cut = true;
     }
     if (chunk_flags && lane == 0)
         chunk_flags[chunk] = (head_cut ? 1 : 0) | ((tail_cut && !(head_cut && seg_first == seg_last)) ? 2 : 0) |
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
 // the row.  A launch over a list without hub segments is ~chunks / 64 waves that read one flag each.
 __global__ __launch_bounds__(kBlock) void segment_join_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t chunks, int W, int D,
                                                                          const float* __restrict__ parts, const int32_t* __restrict__ chunk_flags,
-                                                                         float* __restrict__ out, int ld_out, bool accumulate) {
+                                                                         float* __restrict__ out, int ld_out, bool accumulate, int kChunk) {
     const int lane = lane_id();
     const int64_t c_lane = ((int64_t)blockIdx.x * kWavesPerBlock + wave_in_block()) * kWave + lane;
     const int fl = c_lane < chunks ? chunk_flags[c_lane] : 0;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void segment_join_split_rows_kernel(const i
 // with atomics and need zeros; every other row that owns entries is written whole by one wave.  One wave per chunk boundary.
 __global__ __launch_bounds__(kBlock) void segment_zero_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t num_entries,
                                                                          float* __restrict__ out, int ld_out, int width,
-                                                                         const int32_t* __restrict__ num_live) {
+                                                                         const int32_t* __restrict__ num_live, int kChunk) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block() + 1;   // boundary between chunk c - 1 and chunk c: one wave each
     const int64_t e = c * kChunk;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void segment_zero_split_rows_kernel(const i
     if (e >= num_entries) return;
     const int sg = ent_seg[e];
     if (ent_seg[e - 1] != sg) return;
-    if (run_backward(ent_seg, e, sg, lane) + run_forward(ent_seg, e, num_entries, sg, lane) <= kChunk) return;   // short: one wave sums it
+    if (run_backward(ent_seg, e, sg, lane) + run_forward(ent_seg, e, num_entries, sg, lane) <= kShort) return;   // short: one wave sums it
     float* o = out + (int64_t)sg * ld_out;
     for (int k = lane * 4; k < width; k += kWave * 4) st4(o + k, make_float4(0.f, 0.f, 0.f, 0.f));
 }
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
 using namespace lstep;
 
 extern "C" int64_t lstep_segment_rows_sum_workspace(int64_t num_entries, int32_t width, int32_t time_dim) {
+    const int kChunk = segment_chunk(num_entries);
     if (num_entries <= kChunk) return 0;       // one chunk: nothing can be cut
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     return chunks * 2 * (int64_t)(width + time_dim) * (int64_t)sizeof(float) + ((chunks * (int64_t)sizeof(int32_t) + 15) / 16) * 16;
@@ -314,6 +318,7 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
         return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: unsupported widths W=%d D=%d ld_table=%d ld_out=%d", width, time_dim, ld_table, ld_out);
     if (!table || !ent_seg || !ent_row || !out || (time_dim > 0 && (!time_w || !time_b || !ent_dt)))
         return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: NULL pointer");
+    const int kChunk = segment_chunk(num_entries);
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     const unsigned bgrid = (unsigned)((chunks - 1 + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -328,12 +333,12 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
     }
     if (!parts && accumulate == 2 && chunks > 1)   // uninitialised output, atomic form: zero just the rows the atomics will add to
         hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3(bgrid), dim3(kBlock), 0, (hipStream_t)stream, ent_seg, num_entries, out,
-                           (int)ld_out, (int)(width + time_dim), num_live);
+                           (int)ld_out, (int)(width + time_dim), num_live, kChunk);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
-                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts, flags, 1);
+                       time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts, flags, 1, kChunk);
     if (parts)
         hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                           ent_seg, chunks, (int)width, (int)time_dim, parts, flags, out, (int)ld_out, accumulate == 1);
+                           ent_seg, chunks, (int)width, (int)time_dim, parts, flags, out, (int)ld_out, accumulate == 1, kChunk);
     return check_launch("segment_rows_sum_kernel");
 }
 
@@ -349,6 +354,7 @@ extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, in
         (accumulate != 0 && accumulate != 1) || row_div < 1)
         return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: unsupported arguments");
     if (!table || !ent_seg || !ent_row || !out || !num_live) return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: NULL pointer");
+    const int kChunk = segment_chunk(num_entries);
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
     const unsigned grid = (unsigned)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     float* parts = nullptr;
@@ -361,10 +367,10 @@ extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, in
     }
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table,
                        (const float*)nullptr, (const float*)nullptr, 0, ent_seg, ent_row, (const float*)nullptr, num_entries, out, (int)ld_out,
-                       accumulate == 1, num_live, parts, flags, (int)row_div);
+                       accumulate == 1, num_live, parts, flags, (int)row_div, kChunk);
     if (parts)
         hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                           ent_seg, chunks, (int)width, 0, parts, flags, out, (int)ld_out, accumulate == 1);
+                           ent_seg, chunks, (int)width, 0, parts, flags, out, (int)ld_out, accumulate == 1, kChunk);
     return check_launch("segment_rows_sum_kernel<live>");
 }
 

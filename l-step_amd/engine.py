@@ -428,25 +428,42 @@ def _lookup_rows(table: torch.Tensor, spliced: SplicedRows, ids: torch.Tensor) -
 
 class _LinkLoss(torch.autograd.Function):
     """``lstep_link_loss``: link-prediction BCE + positional-encoding MSE terms of train:257-275 and the gradient of their weighted
-    sum in one launch (the gradient is produced by the forward kernel; backward only scales it by the incoming gradient)."""
+    sum (the gradient is produced in forward; backward only scales it by the incoming gradient).  The kernel emits the gradient of the
+    positional-encoding rows per occurrence; ``groups = (seg, order)`` -- the int32 grouping of cat[src, dst] by batch node the engine made
+    for the batch-node set -- lets ``lstep_segment_rows_sum`` reduce them by spliced row in a fixed order (the negatives that happen to be
+    batch nodes, and everything when no grouping is given, go through ``lstep_scatter_add_rows``)."""
 
     @staticmethod
-    def forward(ctx, logits, rows, table, slot_of, ids, pe_weight, neg_weight):
+    def forward(ctx, logits, rows, table, slot_of, ids, pe_weight, neg_weight, groups=None):
         ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         lib = nat.load_library()
         dev = logits.device
         n = ids.numel() // 3
+        P = rows.shape[1]
         logits = logits.contiguous()
         predicts = torch.empty(2 * n, dtype=torch.float32, device=dev)
         d_logits = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        g_rows = torch.empty((3 * n, P), dtype=torch.float32, device=dev)
+        neg_slot = torch.empty(n, dtype=torch.int32, device=dev)
         d_rows = torch.zeros_like(rows)
         losses = torch.empty(3, dtype=torch.float32, device=dev)
         ws = nat._workspace(dev, int(lib.lstep_link_loss_workspace(n)))
         rows_c = rows.detach().contiguous()
         with torch.cuda.device(dev):
-            nat.check(lib.lstep_link_loss(nat.ptr(logits), nat.ptr(ids), n, nat.ptr(table), nat.ptr(rows_c), nat.ptr(slot_of), rows.shape[1],
-                                          float(pe_weight), float(neg_weight), nat.ptr(predicts), nat.ptr(d_logits), nat.ptr(d_rows),
-                                          nat.ptr(losses), nat.ptr(ws), ws.numel(), nat.current_stream()))
+            nat.check(lib.lstep_link_loss(nat.ptr(logits), nat.ptr(ids), n, nat.ptr(table), nat.ptr(rows_c), nat.ptr(slot_of), P,
+                                          float(pe_weight), float(neg_weight), nat.ptr(predicts), nat.ptr(d_logits), nat.ptr(g_rows),
+                                          nat.ptr(neg_slot), nat.ptr(losses), nat.ptr(ws), ws.numel(), nat.current_stream()))
+            ld = int(d_rows.stride(0))
+            if groups is not None and groups[0].numel() == 2 * n:
+                seg, order = groups
+                sws, sws_bytes = nat.segment_workspace(dev, 2 * n, P)
+                nat.check(lib.lstep_segment_rows_sum(nat.ptr(g_rows), P, P, None, None, 0, nat.ptr(seg), nat.ptr(order), None, 2 * n,
+                                                     nat.ptr(d_rows), ld, 1, None, nat.ptr(sws), sws_bytes, nat.current_stream()))
+                g_neg = g_rows[2 * n:]
+                nat.check(lib.lstep_scatter_add_rows(nat.ptr(d_rows), P, ld, nat.ptr(neg_slot), n, nat.ptr(g_neg), P, nat.current_stream()))
+            else:
+                slots = slot_of[ids].contiguous()
+                nat.check(lib.lstep_scatter_add_rows(nat.ptr(d_rows), P, ld, nat.ptr(slots), 3 * n, nat.ptr(g_rows), P, nat.current_stream()))
         ctx.save_for_backward(d_logits, d_rows)
         lp, pe, loss = losses[0], losses[1], losses[2]
         ctx.mark_non_differentiable(lp, pe, predicts)
@@ -455,11 +472,11 @@ class _LinkLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_lp, g_pe, g_pred):
         if g_loss is None:
-            return (None,) * 7
+            return (None,) * 8
         d_logits, d_rows = ctx.saved_tensors
         if _LinkLoss.unit_gradient:      # the engine's own ``loss.backward()``: the incoming gradient is the scalar 1 (two launches less)
-            return d_logits, d_rows, None, None, None, None, None
-        return g_loss * d_logits, g_loss * d_rows, None, None, None, None, None
+            return d_logits, d_rows, None, None, None, None, None, None
+        return g_loss * d_logits, g_loss * d_rows, None, None, None, None, None, None
 
     unit_gradient = False     # set by LstepEngine around its own backward call (a plain ``loss.backward()``)
 
@@ -770,7 +787,7 @@ class LstepEngine:
                 else:
                     logits = self.predictor(input_1=torch.cat([pos_src, pos_src], dim=0), input_2=emb[n:]).squeeze(dim=-1)
                 loss, lp_loss, pe_loss, predicts = _LinkLoss.apply(logits, spliced.rows, cur, spliced.slot_of, ids3, self.pe_weight,
-                                                                   self.neg_sample_weight)
+                                                                   self.neg_sample_weight, getattr(spliced, "self_groups", None))
             else:   # the same terms with framework ops (LSTEP_TORCH_LOSS=1, the A/B switch)
                 predicts = self._probabilities(torch.cat([pos_src, pos_src], dim=0), emb[n:])
                 labels = self._labels(n)

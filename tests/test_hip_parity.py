@@ -379,8 +379,9 @@ def test_segment_rows_sum_vs_index_add(hip):
         assert float((out.double() - 2 * ref).abs().max()) <= 2 * tol
 
 
-def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch):
-    """Segments far longer than a 64-entry chunk (hub nodes) are cut into per-chunk partial sums; with the scratch buffer the library joins
+@pytest.mark.parametrize("n_ent", [40000, 90000])      # 16-entry and 64-entry chunks
+def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch, n_ent):
+    """Segments far longer than a chunk (hub nodes; more than 64 entries) are cut into per-chunk partial sums; with the scratch buffer the library joins
     them in chunk order (``segment_join_split_rows_kernel``), so the result is a function of the inputs alone: bit-identical from run to
     run and whatever else keeps the GPU busy (replicas of the PE table that run the same update_pe on different GPUs must not drift
     apart: ADVICE r2).  With time features (update_pe's form), plain, accumulating, and with a device-resident entry count; and equal,
@@ -388,7 +389,7 @@ def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch):
     from lstep_amd import _native as nat
     lib = nat.load_library()
     torch.manual_seed(5)
-    n_rows, n_ent, nsrc, P, D = 9, 40000, 5000, 172, 100
+    n_rows, nsrc, P, D = 9, 5000, 172, 100
     table = torch.randn(nsrc, P, device=DEV)
     seg = torch.sort(torch.randint(0, n_rows, (n_ent,), device=DEV)).values.to(torch.int32)          # ~4400 entries = 70 chunks per segment
     row = torch.randint(0, nsrc, (n_ent,), device=DEV, dtype=torch.int32)
@@ -439,7 +440,8 @@ def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch):
 
 
 def ws_used(nat, n_ent, P, D):
-    chunks = (n_ent + 63) // 64
+    chunk = 16 if n_ent <= 65536 else 64          # segment.hip: short lists are cut finer (a chunk is a wave's dependent rounds of latency)
+    chunks = (n_ent + chunk - 1) // chunk
     return int(nat.load_library().lstep_segment_rows_sum_workspace(n_ent, P, D)) == chunks * 2 * (P + D) * 4 + (chunks * 4 + 15) // 16 * 16
 
 
@@ -648,10 +650,21 @@ def test_link_loss_matches_framework_ops(hip):
     logits0[0], logits0[n] = 40.0, -40.0                        # saturated sigmoid on both sides
     logits0[1], logits0[n + 1] = -30.0, 30.0
     rows0 = torch.randn(U, P, generator=g)
-    for pe_w, neg_w in [(0.5, 0.3), (0.0, 1.0), (1.0, 0.0)]:
+    # the engine's grouping of cat[src, dst] by batch node (segment = spliced row): the fixed-order reduction of the per-occurrence gradient rows
+    from lstep_amd import _native as nat
+    keys = torch.cat([src, dst]).to(torch.int32).to(DEV)
+    _, order, seg, uniq, _ = nat.group_by_key(keys, (N + 1).bit_length(), N + 1, wait=True)
+    rank_of = torch.full((N + 1,), -1, dtype=torch.int64)
+    present = torch.unique(torch.cat([src, dst]))
+    rank_of[present] = torch.arange(present.numel())
+    seg_slot = slot_of.to(DEV)[present.to(DEV)][seg.long()].contiguous()      # segment k is the k-th smallest endpoint: its spliced row
+    grouped = []
+    for pe_w, neg_w, groups in [(0.5, 0.3, None), (0.5, 0.3, (seg_slot, order)), (0.5, 0.3, (seg_slot, order)), (0.0, 1.0, None), (1.0, 0.0, (seg_slot, order))]:
         la, ra = logits0.clone().to(DEV).requires_grad_(True), rows0.clone().to(DEV).requires_grad_(True)
-        loss, lp, pe, pred = _LinkLoss.apply(la, ra, table, slot_of.to(DEV), ids, pe_w, neg_w)
+        loss, lp, pe, pred = _LinkLoss.apply(la, ra, table, slot_of.to(DEV), ids, pe_w, neg_w, groups)
         loss.backward()
+        if groups is not None and pe_w == 0.5:
+            grouped.append(ra.grad.clone())
         lb, rb = logits0.clone().to(DEV).requires_grad_(True), rows0.clone().to(DEV).requires_grad_(True)
         so = slot_of.to(DEV)[ids].long()
         e = torch.where((so >= 0).unsqueeze(1), rb[so.clamp(min=0)], table[ids])
@@ -664,6 +677,10 @@ def test_link_loss_matches_framework_ops(hip):
         np.testing.assert_allclose(pred.cpu().numpy(), p2.detach().cpu().numpy(), rtol=0, atol=1e-7)
         np.testing.assert_allclose(la.grad.cpu().numpy(), lb.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose(ra.grad.cpu().numpy(), rb.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    # the grouped reduction has a fixed summation order, except for the rows of negatives that are batch nodes (float atomics)
+    clean = torch.ones(U, dtype=torch.bool)
+    clean[slot_of[neg[:5]].long()] = False
+    assert torch.equal(grouped[0][clean.to(DEV)], grouped[1][clean.to(DEV)])
 
 
 @pytest.mark.parametrize("n", [16384 // 64, 41, 1])
