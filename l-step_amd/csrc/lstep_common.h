@@ -22,6 +22,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 __device__ __forceinline__ int bcast_i32(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+__device__ __forceinline__ int64_t bcast_i64(int64_t v, int src_lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffff), src_lane);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+    return ((int64_t)hi << 32) | (int64_t)lo;
+}
 __device__ __forceinline__ float bcast_f32(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }

@@ -258,17 +258,34 @@ __global__ __launch_bounds__(kBlock) void padding_rows_sum_kernel(const int64_t*
     const bool wa = lane < (W >> 2);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t r0 = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kPadRowsPerWave;
-    for (int64_t r = r0; r < r0 + kPadRowsPerWave && r < n; ++r) {
-        int zeros = 0;
-        for (int j0 = 0; j0 < K; j0 += kWave) {
-            const bool z = (j0 + lane < K) && nbr[r * K + j0 + lane] == 0;
-            zeros += __popcll(__ballot(z));
-        }
-        if (zeros == 0) continue;   // wave-uniform
-        if (wa) {
-            const float4 v = ld4(table + (ids ? ids[r] : r) * (int64_t)ld + lane * 4);
-            const float w = (float)zeros;
-            acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+    // All 16 rows of the wave at once: their slot lists in one batch of loads, then their table rows in one batch (rows without padding
+    // re-read the first row with weight 0).  Row by row it is 16 x 2 dependent memory latencies per wave: 52 us at 32 768 rows.
+    int64_t id = 0;
+    if (lane < kPadRowsPerWave) {
+        const int64_t r = r0 + lane < n ? r0 + lane : n - 1;
+        id = ids ? ids[r] : r;
+    }
+    int zeros[kPadRowsPerWave];
+#pragma unroll
+    for (int u = 0; u < kPadRowsPerWave; ++u) zeros[u] = 0;
+    for (int j0 = 0; j0 < K; j0 += kWave) {
+        bool z[kPadRowsPerWave];
+#pragma unroll
+        for (int u = 0; u < kPadRowsPerWave; ++u) z[u] = (r0 + u < n) && (j0 + lane < K) && nbr[(r0 + u) * K + j0 + lane] == 0;
+#pragma unroll
+        for (int u = 0; u < kPadRowsPerWave; ++u) zeros[u] += __popcll(__ballot(z[u]));
+    }
+    const int64_t id0 = bcast_i64(id, 0);
+    float4 v[kPadRowsPerWave];
+    if (wa) {
+#pragma unroll
+        for (int u = 0; u < kPadRowsPerWave; ++u) v[u] = ld4(table + (zeros[u] ? bcast_i64(id, u) : id0) * (int64_t)ld + lane * 4);
+#pragma unroll
+        for (int u = 0; u < kPadRowsPerWave; ++u) {      // (row order: the same sum as the row-by-row loop)
+            if (zeros[u]) {
+                const float w = (float)zeros[u];
+                acc.x = fmaf(w, v[u].x, acc.x); acc.y = fmaf(w, v[u].y, acc.y); acc.z = fmaf(w, v[u].z, acc.z); acc.w = fmaf(w, v[u].w, acc.w);
+            }
         }
     }
     if (wa) sh[wave][lane] = acc;

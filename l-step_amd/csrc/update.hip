@@ -91,7 +91,14 @@ __global__ __launch_bounds__(256) void batch_prepare_kernel(const int64_t* __res
     if (blockIdx.x == gridDim.x - 1) {
         __shared__ double part[256];
         double m = -1.7976931348623157e308;
-        for (int64_t i = threadIdx.x; i < b; i += 256) m = t[i] > m ? t[i] : m;
+        // (eight independent loads per round: one load per round is b / 256 dependent memory latencies -- 25 us at b = 16384, at the head of the step)
+        for (int64_t i0 = threadIdx.x; i0 < b; i0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < b ? t[i0 + u * 256] : m;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = v[u] > m ? v[u] : m;
+        }
         part[threadIdx.x] = m;
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) {
@@ -111,16 +118,44 @@ __global__ __launch_bounds__(256) void batch_prepare_kernel(const int64_t* __res
     }
 }
 
-// row[:width] = sum over the blocks of partial[blk, :width] (in block order: deterministic), row[width:row_width] = 0:
-// the padding row's aggregate of update_pe phase 2 (lstep_padding_rows_sum's per-block sums; its time part is zero, models/LSTEP.py:316)
-__global__ __launch_bounds__(256) void padding_rows_finish_kernel(const float* __restrict__ partial, int64_t blocks, int width, float* __restrict__ row,
-                                                                  int row_width) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= row_width) return;
-    float s = 0.f;
-    if (c < width)
-        for (int64_t k = 0; k < blocks; ++k) s += partial[k * width + c];
-    row[c] = s;
+// row[:width] = sum over the blocks of partial[blk, :width], row[width:row_width] = 0: the padding row's aggregate of update_pe phase 2
+// (lstep_padding_rows_sum's per-block sums; its time part is zero, models/LSTEP.py:316).  One workgroup of 16 waves: wave w adds its
+// contiguous share of the blocks in block order, eight loads in flight, lane = one float4 of the row; the 16 wave sums meet in LDS and are added
+// in wave order -- a fixed order, so the result is a function of the inputs alone.  (One thread per column walking all the blocks is
+// `blocks` dependent memory latencies: 196 us for the 512 partial rows of a 32 768-row update, on update_pe's chain.)
+constexpr int kFinishWaves = 16;
+__global__ __launch_bounds__(kFinishWaves * kWave) void padding_rows_finish_kernel(const float* __restrict__ partial, int64_t blocks, int width,
+                                                                                   float* __restrict__ row, int row_width) {
+    __shared__ float4 sh[kFinishWaves][kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int64_t per = (blocks + kFinishWaves - 1) / kFinishWaves;
+    const int64_t k0 = wave * per, k1 = k0 + per < blocks ? k0 + per : blocks;
+    for (int c0 = 0; c0 < row_width; c0 += 4 * kWave) {       // (rows wider than 256 floats: another pass)
+        const int c = c0 + 4 * lane;
+        const bool on = c + 4 <= width;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) {
+            for (int64_t k = k0; k < k1; k += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = k + u < k1 ? ld4(partial + (k + u) * width + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+        }
+        sh[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && c < row_width) {
+            float4 t = sh[0][lane];
+#pragma unroll
+            for (int w = 1; w < kFinishWaves; ++w) { const float4 v = sh[w][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            const float out[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < row_width) row[c + e] = c + e < width ? out[e] : 0.f;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- owner-sharded PE table (lstep_amd/parallel.py, form "pull"): the request lists of one gather.
@@ -217,8 +252,9 @@ extern "C" int lstep_batch_prepare(const int64_t* src, const int64_t* dst, const
 extern "C" int lstep_padding_rows_finish(const float* partial, int64_t blocks, int32_t width, float* row, int32_t row_width, void* stream) {
     if (blocks < 0 || width <= 0 || row_width < width) return set_error(LSTEP_EINVAL, "lstep_padding_rows_finish: bad sizes");
     if (!row || (blocks > 0 && !partial)) return set_error(LSTEP_EINVAL, "lstep_padding_rows_finish: NULL pointer");
-    hipLaunchKernelGGL(padding_rows_finish_kernel, dim3((unsigned)((row_width + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, blocks, (int)width,
-                       row, (int)row_width);
+    if (width & 3) return set_error(LSTEP_EINVAL, "lstep_padding_rows_finish: width must be a multiple of 4");
+    hipLaunchKernelGGL(padding_rows_finish_kernel, dim3(1), dim3(kFinishWaves * kWave), 0, (hipStream_t)stream, partial, blocks, (int)width, row,
+                       (int)row_width);
     return check_launch("padding_rows_finish_kernel");
 }
 

@@ -439,6 +439,36 @@ def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch, n_ent
     assert float(((out - run(0, False, False)).abs() / out.abs().clamp(min=1.0)).max()) <= 1e-4
 
 
+@pytest.mark.parametrize("n", [1, 70, 1000, 32768])
+def test_padding_rows_sum_and_finish_match_float64(hip, n):
+    """update_pe phase 2, row 0 (models/LSTEP.py:317-322: every PADDED neighbour slot scatters cat[pe[source], 0] into row 0):
+    lstep_padding_rows_sum (per-block partial sums, 16 rows per wave in two batches of loads) + lstep_padding_rows_finish (one workgroup,
+    fixed order) against float64; twice the same bits; the columns beyond the PE width come out zero."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    N, K, P, RW = 5000, 20, 172, 276
+    table = torch.randn(N, P, device=DEV, generator=gen)
+    ids = torch.randint(0, N, (n,), device=DEV, generator=gen)
+    nbr = torch.randint(1, N, (n, K), device=DEV, generator=gen)
+    pad = torch.randint(0, K + 1, (n,), device=DEV, generator=gen)
+    pad[torch.rand(n, device=DEV, generator=gen) < 0.5] = 0                      # half the rows have no padding at all
+    nbr[torch.arange(K, device=DEV).unsqueeze(0) < pad.unsqueeze(1)] = 0          # (padding slots lead, as the sampler leaves them)
+    blocks = int(lib.lstep_padding_rows_sum_blocks(n))
+    outs = []
+    for _ in range(2):
+        partial = torch.full((blocks, P), float("nan"), device=DEV)
+        row = torch.full((RW,), float("nan"), device=DEV)
+        nat.check(lib.lstep_padding_rows_sum(nat.ptr(nbr), K, nat.ptr(ids), n, nat.ptr(table), P, P, nat.ptr(partial), nat.current_stream()))
+        nat.check(lib.lstep_padding_rows_finish(nat.ptr(partial), blocks, P, nat.ptr(row), RW, nat.current_stream()))
+        torch.cuda.synchronize()
+        outs.append(row)
+    assert torch.equal(outs[0], outs[1])
+    want = ((nbr == 0).sum(1).double().unsqueeze(1) * table[ids].double()).sum(0)
+    assert float((outs[0][:P].double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert float(outs[0][P:].abs().max()) == 0.0
+
+
 def ws_used(nat, n_ent, P, D):
     chunk = 16 if n_ent <= 65536 else 64          # segment.hip: short lists are cut finer (a chunk is a wave's dependent rounds of latency)
     chunks = (n_ent + chunk - 1) // chunk
