@@ -40,6 +40,29 @@ def gather_algorithmic_bytes(count: torch.Tensor, K: int, G: int, row_bytes: int
     return float((row_bytes * (2 * k + v + 3) + 24 * k + 8 * v).sum().item())
 
 
+def pair_gather_launches(sink, K: int, G: int):
+    """(ms per gather STAGE, algorithmic bytes per stage) from the (start event, end event, per-row counts, branches) records of the timed
+    launches.  The single-GPU engine computes all channels in one launch (branches = 3).  The multi-GPU engine launches the stage as TWO
+    kernels per step -- edge + node channels (1), then the PE channel (2) once the all-gathered spliced rows are in: a (1, 2) pair over
+    the same rows is one stage, its durations add up and its bytes are counted once.  Anything else in the sink is an error, not a
+    silently mis-priced launch."""
+    ms, nbytes, i = [], [], 0
+    while i < len(sink):
+        e0, e1, count, br = sink[i]
+        if br == 3:
+            ms.append(e0.elapsed_time(e1))
+            nbytes.append(gather_algorithmic_bytes(count, K, G))
+            i += 1
+            continue
+        if br != 1 or i + 1 >= len(sink) or sink[i + 1][3] != 2 or sink[i + 1][2].numel() != count.numel():
+            raise RuntimeError(f"gather event sink: launch {i} (branches {br}) is not the first half of an (edge+node, PE) pair")
+        f0, f1 = sink[i + 1][0], sink[i + 1][1]
+        ms.append(e0.elapsed_time(e1) + f0.elapsed_time(f1))
+        nbytes.append(gather_algorithmic_bytes(count, K, G))
+        i += 2
+    return ms, nbytes
+
+
 def cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -324,13 +347,7 @@ def main():
                 rec = table.get(GATHER_KERNEL) or table.get("lstep::gather_aggregate_fwd_kernel<true, true>")   # (name before the explicit-list variant)
                 if rec:
                     traffic, traffic_src = rec["traffic_bytes"], os.path.relpath(cands[-1], ROOT)
-        ms = [a.elapsed_time(b) for a, b, _ in sink]
-        bytes_per_launch = [gather_algorithmic_bytes(c, wl.K, wl.G) for _, _, c in sink]
-        if use_dist and len(ms) % 2 == 0:
-            # the multi-GPU engine launches the gather stage as TWO kernels per step (edge + node channels, then the PE channel once the
-            # all-gathered spliced rows are in): their durations add up, the algorithmic bytes of the stage are counted once
-            ms = [ms[i] + ms[i + 1] for i in range(0, len(ms), 2)]
-            bytes_per_launch = bytes_per_launch[0::2]
+        ms, bytes_per_launch = pair_gather_launches(sink, wl.K, wl.G)
         avg_ms = float(np.mean(ms))
         achieved = float(np.mean(bytes_per_launch)) / (avg_ms * 1e-3) / 1e9
         line = {

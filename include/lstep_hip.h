@@ -211,11 +211,14 @@ int lstep_history_filter_runs_finish(const float* partial_sum, int32_t t_len, in
  * adjacent (ent_seg grouped, e.g. sorted); for every segment s that occurs
  *   out[s, :W]    = sum_e table[ent_row[e], :W]                       (table row stride ld_table floats)
  *   out[s, W:W+D] = sum_e cos(ent_dt[e] * time_w + time_b)            (time_dim D may be 0: no time part, ent_dt unused)
- * `out` (row stride ld_out) MUST be zero-initialised by the caller (accumulate = 0): rows that own no entry stay zero.  Segments inside one
- * 64-entry chunk are plain stores summed in entry order.  A segment that straddles chunk boundaries (long segments = hub nodes):
- *   with `workspace` (lstep_segment_rows_sum_workspace bytes, 16-byte aligned): every chunk parks its partial sum there and a second
- *     pass adds a segment's partials in chunk order -- the result is a function of the inputs alone (replicas of a table that run the
- *     same update on different GPUs stay bit-identical, two runs of one process too);
+ * `out` (row stride ld_out) MUST be zero-initialised by the caller (accumulate = 0): rows that own no entry stay zero.  The entry list is
+ * cut into chunks of 16 entries (lists of up to 65 536 entries) or 64 entries (longer lists), one wave each.  A segment of at most 64
+ * entries belongs WHOLLY to the wave of the chunk it starts in (that wave reads on past its chunk, the next one skips those entries): it is
+ * summed in entry order and written with plain stores.  Only segments of more than 64 entries (hub nodes) are cut at the chunk boundaries:
+ *   with `workspace` (lstep_segment_rows_sum_workspace bytes, 16-byte aligned): every chunk parks its partial sum there and further passes
+ *     join a segment's partials in a fixed-shape tree (aligned groups of 16 whole-chunk partials first, then the groups and the remaining
+ *     chunks in chunk order) -- the result is a function of the inputs alone (replicas of a table that run the same update on different
+ *     GPUs stay bit-identical, two runs of one process too), and a hub with thousands of chunks is not a serial chain;
  *   with workspace = NULL: float atomics into the row, in arrival order (exact up to the order of three or more partial sums).
  * accumulate = 1: the sums are ADDED to what `out` already holds (a second reduction into the same rows, e.g. neighbour + self
  * gradients).  accumulate = 2: `out` is UNINITIALISED memory and (width + time_dim) a multiple of 4 -- every row that owns entries is

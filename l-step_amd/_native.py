@@ -39,32 +39,68 @@ class RingRef(C.Structure):
     _fields_ = [("start", C.c_void_p), ("add", C.c_int32), ("slots", C.c_int32), ("slot_stride", C.c_int64)]
 
 
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in _deps() if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into ``csrc/liblstep_hip.so`` (cross-compiles without a GPU)."""
-    if not force and not _stale():
+def build_library(force: bool = False, verbose: bool = False, defines=(), lib_path: str = None) -> str:
+    """Compile every HIP source for gfx950 into ``csrc/liblstep_hip.so`` (cross-compiles without a GPU): one object per source under
+    ``csrc/build/`` (compiled in parallel, re-compiled only when the source or a header is newer), then one link.  ``defines`` /
+    ``lib_path``: an A/B build with extra -D flags into another file (e.g. ``LSTEP_EXACT_TANH=1``: libm ``tanhf`` instead of the
+    hardware-exp form, tools/drift.py), loaded with the ``LSTEP_LIB`` environment variable."""
+    out = lib_path or LIB_PATH
+    if lib_path is None and not defines and not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise LstepNativeError("hipcc not found: cannot build liblstep_hip.so")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    tag = "".join(c if c.isalnum() else "_" for c in "_".join(defines))
+    objdir = os.path.join(CSRC, "build" + ("_" + tag if tag else ""))
+    os.makedirs(objdir, exist_ok=True)
+    base = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + [f"-D{d}" for d in defines]
+    newest_header = max(os.path.getmtime(h) for h in HEADERS if os.path.exists(h))
+    jobs = []
+    for src in SOURCES:
+        sp, op = os.path.join(CSRC, src), os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), newest_header):
+            jobs.append((sp, op))
+
+    def compile_one(job):
+        sp, op = job
+        cmd = base + ["-c", sp, "-o", op + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            os.replace(op + ".tmp", op)
+        return sp, r
+
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(len(jobs), int(os.environ.get("LSTEP_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))))
+        with ThreadPoolExecutor(workers) as pool:
+            results = list(pool.map(compile_one, jobs))
+        bad = [(sp, r) for sp, r in results if r.returncode != 0]
+        if bad:
+            raise LstepNativeError("hipcc failed:\n" + "\n".join(f"{sp}:\n{r.stdout}{r.stderr}" for sp, r in bad))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES] + ["-o", out + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link))
+    r = subprocess.run(link, capture_output=True, text=True)
     if r.returncode != 0:
-        raise LstepNativeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    global _LIB
-    _LIB = None
-    return LIB_PATH
+        raise LstepNativeError("hipcc (link) failed:\n" + r.stdout + r.stderr)
+    os.replace(out + ".tmp", out)
+    if out == LIB_PATH:
+        global _LIB
+        _LIB = None
+    return out
 
 
 _LIB = None

@@ -164,18 +164,67 @@ __global__ __launch_bounds__(kBlock) void segment_rows_sum_kernel(const float* _
     }
 }
 
+// Hub segments (thousands of entries: a power-law graph's top nodes collect a fifth of a batch's messages) span hundreds of chunks; adding
+// their parked partials one after another is a chain of dependent loads (434 us per launch on the Zipf-1.2 c4 step, round 4).  The join is a
+// FIXED-SHAPE two-level tree instead: a first pass sums every aligned group of kJoinGroup consecutive MIDDLE chunks (chunks that lie wholly
+// inside one cut segment, flags == 5) into one group partial -- all its loads in flight at once, added in chunk order; the second pass walks a
+// cut segment's chunks as before but takes a whole group in one step wherever a group partial exists, eight group partials in flight.  The
+// grouping is a function of the chunk layout, i.e. of the inputs alone: results stay deterministic (replicas on different GPUs bit-identical).
+constexpr int kJoinGroup = 16;
+constexpr int kJoinMinChunks = 4 * kJoinGroup;     // shorter lists: the serial walk is at most that many steps, skip the first pass
+
+__global__ __launch_bounds__(kBlock) void segment_join_groups_kernel(int64_t chunks, int W, int D, const float* __restrict__ parts,
+                                                                     const int32_t* __restrict__ chunk_flags, float* __restrict__ gparts,
+                                                                     int32_t* __restrict__ gflags) {
+    const int lane = lane_id();
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    const int64_t groups = chunks / kJoinGroup;
+    if (g >= groups) return;
+    const int64_t c0 = g * kJoinGroup;
+    const int fl = lane < kJoinGroup ? chunk_flags[c0 + lane] : 5;
+    const bool all = __ballot(fl == 5) == ~0ull;
+    if (lane == 0) gflags[g] = all ? 1 : 0;
+    if (!all) return;
+    const int ldp = W + D;
+    const bool wa = lane < (W >> 2);
+    const float* p = parts + (c0 * 2) * (int64_t)ldp;      // slot 0 of chunk c0; the next chunk's slot 0 is 2 * ldp floats on
+    float4 x[kJoinGroup];
+    float a0[kJoinGroup], a1[kJoinGroup];
+#pragma unroll
+    for (int u = 0; u < kJoinGroup; ++u) {
+        x[u] = wa ? ld4(p + (int64_t)u * 2 * ldp + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        a0[u] = lane < D ? p[(int64_t)u * 2 * ldp + W + lane] : 0.f;
+        a1[u] = lane + kWave < D ? p[(int64_t)u * 2 * ldp + W + lane + kWave] : 0.f;
+    }
+    float4 acc = x[0];
+    float t0 = a0[0], t1 = a1[0];
+#pragma unroll
+    for (int u = 1; u < kJoinGroup; ++u) {
+        acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w;
+        t0 += a0[u];
+        t1 += a1[u];
+    }
+    float* o = gparts + g * (int64_t)ldp;
+    if (wa) st4(o + lane * 4, acc);
+    if (lane < D) o[W + lane] = t0;
+    if (lane + kWave < D) o[W + lane + kWave] = t1;
+}
+
 // Second pass of the deterministic form: one LANE per chunk looks at the chunk's flags; the rare chunk in which a cut (> 64 entries) segment
-// starts has its wave add that segment's parked partials in chunk order and write (or, `accumulate`, add to) its row -- the only writer of
-// the row.  A launch over a list without hub segments is ~chunks / 64 waves that read one flag each.
+// starts has its wave add that segment's parked partials in chunk order (whole groups of middle chunks through their group partial, see
+// above) and write (or, `accumulate`, add to) its row -- the only writer of the row.  A launch over a list without hub segments is
+// ~chunks / 64 waves that read one flag each.
 __global__ __launch_bounds__(kBlock) void segment_join_split_rows_kernel(const int32_t* __restrict__ ent_seg, int64_t chunks, int W, int D,
                                                                          const float* __restrict__ parts, const int32_t* __restrict__ chunk_flags,
-                                                                         float* __restrict__ out, int ld_out, bool accumulate, int kChunk) {
+                                                                         float* __restrict__ out, int ld_out, bool accumulate, int kChunk,
+                                                                         const float* __restrict__ gparts, const int32_t* __restrict__ gflags) {
     const int lane = lane_id();
     const int64_t c_lane = ((int64_t)blockIdx.x * kWavesPerBlock + wave_in_block()) * kWave + lane;
     const int fl = c_lane < chunks ? chunk_flags[c_lane] : 0;
     unsigned long long todo = __ballot((fl & 2) != 0);
     const int ldp = W + D;
     const bool wa = lane < (W >> 2);
+    const int64_t groups = gflags ? chunks / kJoinGroup : 0;
     while (todo) {
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -184,12 +233,43 @@ __global__ __launch_bounds__(kBlock) void segment_join_split_rows_kernel(const i
         const float* p = parts + (c * 2 + 1) * (int64_t)ldp;
         float4 acc = wa ? ld4(p + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float t0 = lane < D ? p[W + lane] : 0.f, t1 = lane + kWave < D ? p[W + lane + kWave] : 0.f;
-        for (int64_t j = c + 1; j < chunks; ++j) {
+        int64_t j = c + 1;
+        while (j < chunks) {
+            if (groups && (j & (kJoinGroup - 1)) == 0) {
+                // how many consecutive whole groups of middle chunks start here (they all belong to this segment: chunk j - 1 goes on into j)
+                const int64_t g0 = j / kJoinGroup;
+                const bool full = (g0 + lane < groups) && gflags[g0 + lane] != 0;
+                const unsigned long long nf = ~__ballot(full);
+                const int run = nf ? __builtin_ctzll(nf) : kWave;
+                if (run > 0) {
+                    for (int q = 0; q < run; q += kSegInFlight) {
+                        float4 x[kSegInFlight];
+                        float a0[kSegInFlight], a1[kSegInFlight];
+#pragma unroll
+                        for (int u = 0; u < kSegInFlight; ++u) {
+                            const float* gp = gparts + (g0 + ((q + u) < run ? (q + u) : (run - 1))) * (int64_t)ldp;
+                            x[u] = wa ? ld4(gp + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            a0[u] = lane < D ? gp[W + lane] : 0.f;
+                            a1[u] = lane + kWave < D ? gp[W + lane + kWave] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < kSegInFlight; ++u) {
+                            if ((q + u) >= run) break;
+                            acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w;
+                            t0 += a0[u];
+                            t1 += a1[u];
+                        }
+                    }
+                    j += (int64_t)run * kJoinGroup;
+                    continue;
+                }
+            }
             p = parts + (j * 2) * (int64_t)ldp;                                     // chunk j's first run continues the segment
             if (wa) { const float4 v = ld4(p + lane * 4); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
             if (lane < D) t0 += p[W + lane];
             if (lane + kWave < D) t1 += p[W + lane + kWave];
             if (!(chunk_flags[j] & 4)) break;
+            ++j;
         }
         float* o = out + (int64_t)sg * ld_out;
         if (accumulate) {
@@ -315,11 +395,43 @@ __global__ __launch_bounds__(kBlock) void scatter_add_rows_kernel(float* __restr
 
 using namespace lstep;
 
+namespace {
+// scratch of the deterministic form: [chunks * 2 partial rows | chunk flags | chunks / kJoinGroup group partial rows | group flags], 16-byte aligned pieces
+struct JoinLayout {
+    int64_t flags_off, gparts_off, gflags_off, total, groups;
+};
+inline JoinLayout join_layout(int64_t chunks, int64_t ldp) {
+    auto up16 = [](int64_t b) { return (b + 15) / 16 * 16; };
+    JoinLayout l;
+    l.groups = chunks >= kJoinMinChunks ? chunks / kJoinGroup : 0;
+    l.flags_off = up16(chunks * 2 * ldp * (int64_t)sizeof(float));
+    l.gparts_off = l.flags_off + up16(chunks * (int64_t)sizeof(int32_t));
+    l.gflags_off = l.gparts_off + up16(l.groups * ldp * (int64_t)sizeof(float));
+    l.total = l.gflags_off + up16(l.groups * (int64_t)sizeof(int32_t));
+    return l;
+}
+
+// the two passes that join the parked partials of cut segments (deterministic form)
+inline void launch_join(const int32_t* ent_seg, int64_t chunks, int W, int D, void* workspace, float* out, int ld_out, bool accumulate, int kChunk,
+                        hipStream_t stream) {
+    const JoinLayout l = join_layout(chunks, W + D);
+    float* parts = (float*)workspace;
+    int32_t* flags = (int32_t*)((char*)workspace + l.flags_off);
+    float* gparts = l.groups ? (float*)((char*)workspace + l.gparts_off) : nullptr;
+    int32_t* gflags = l.groups ? (int32_t*)((char*)workspace + l.gflags_off) : nullptr;
+    if (l.groups)
+        hipLaunchKernelGGL(segment_join_groups_kernel, dim3((unsigned)((l.groups + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, stream,
+                           chunks, W, D, parts, flags, gparts, gflags);
+    hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ent_seg, chunks, W,
+                       D, parts, flags, out, ld_out, accumulate, kChunk, gparts, gflags);
+}
+}  // namespace
+
 extern "C" int64_t lstep_segment_rows_sum_workspace(int64_t num_entries, int32_t width, int32_t time_dim) {
     const int kChunk = segment_chunk(num_entries);
     if (num_entries <= kChunk) return 0;       // one chunk: nothing can be cut
     const int64_t chunks = (num_entries + kChunk - 1) / kChunk;
-    return chunks * 2 * (int64_t)(width + time_dim) * (int64_t)sizeof(float) + ((chunks * (int64_t)sizeof(int32_t) + 15) / 16) * 16;
+    return join_layout(chunks, width + time_dim).total;
 }
 
 extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t ld_table, const float* time_w, const float* time_b,
@@ -346,16 +458,14 @@ extern "C" int lstep_segment_rows_sum(const float* table, int32_t width, int32_t
             return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum: workspace too small or misaligned (need %lld bytes, 16-byte aligned)",
                              (long long)lstep_segment_rows_sum_workspace(num_entries, width, time_dim));
         parts = (float*)workspace;
-        flags = (int32_t*)(parts + chunks * 2 * (int64_t)(width + time_dim));
+        flags = (int32_t*)((char*)workspace + join_layout(chunks, width + time_dim).flags_off);
     }
     if (!parts && accumulate == 2 && chunks > 1)   // uninitialised output, atomic form: zero just the rows the atomics will add to
         hipLaunchKernelGGL(segment_zero_split_rows_kernel, dim3(bgrid), dim3(kBlock), 0, (hipStream_t)stream, ent_seg, num_entries, out,
                            (int)ld_out, (int)(width + time_dim), num_live, kChunk);
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table, time_w,
                        time_b, (int)time_dim, ent_seg, ent_row, ent_dt, num_entries, out, (int)ld_out, accumulate == 1, num_live, parts, flags, 1, kChunk);
-    if (parts)
-        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                           ent_seg, chunks, (int)width, (int)time_dim, parts, flags, out, (int)ld_out, accumulate == 1, kChunk);
+    if (parts) launch_join(ent_seg, chunks, (int)width, (int)time_dim, workspace, out, (int)ld_out, accumulate == 1, kChunk, (hipStream_t)stream);
     return check_launch("segment_rows_sum_kernel");
 }
 
@@ -380,14 +490,12 @@ extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, in
         if (((uintptr_t)workspace & 15) || workspace_bytes < lstep_segment_rows_sum_workspace(num_entries, width, 0))
             return set_error(LSTEP_EINVAL, "lstep_segment_rows_sum_live: workspace too small or misaligned");
         parts = (float*)workspace;
-        flags = (int32_t*)(parts + chunks * 2 * (int64_t)width);
+        flags = (int32_t*)((char*)workspace + join_layout(chunks, width).flags_off);
     }
     hipLaunchKernelGGL(segment_rows_sum_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, table, (int)width, (int)ld_table,
                        (const float*)nullptr, (const float*)nullptr, 0, ent_seg, ent_row, (const float*)nullptr, num_entries, out, (int)ld_out,
                        accumulate == 1, num_live, parts, flags, (int)row_div, kChunk);
-    if (parts)
-        hipLaunchKernelGGL(segment_join_split_rows_kernel, dim3((unsigned)((chunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                           ent_seg, chunks, (int)width, 0, parts, flags, out, (int)ld_out, accumulate == 1, kChunk);
+    if (parts) launch_join(ent_seg, chunks, (int)width, 0, workspace, out, (int)ld_out, accumulate == 1, kChunk, (hipStream_t)stream);
     return check_launch("segment_rows_sum_kernel<live>");
 }
 

@@ -119,6 +119,9 @@ class HistoryRing:
         assert (self._dev_mirror + 1) % self.S == self.start, "exactly one commit per iteration"
         if self._advanced[1] is not None:     # the advance of this iteration reads the position on another stream: it goes first
             torch.cuda.current_stream(self.buf.device).wait_event(self._advanced[1])
+        early = self.__dict__.pop("_early_event", None)
+        if early is not None:                 # (captured iterations: the slide applied at the start of the replay, ``early_advance``)
+            torch.cuda.current_stream(self.buf.device).wait_event(early)
         with torch.cuda.device(self.buf.device):
             nat.check(nat.load_library().lstep_ring_tick(nat.ptr(self.dev_start), self.S, nat.current_stream()))
         self._dev_mirror = self.start
@@ -258,6 +261,10 @@ class HistoryRing:
             nat.check(nat.load_library().lstep_history_advance_oldest(nat.ptr(self.oldest), nat.ptr(self.buf if ref is not None else self.buf[slot]),
                                                                       self.P, self.P, nat.ptr(self.mask), self.words, slot, self.rows, ref,
                                                                       nat.current_stream()))
+            # the slide reads the device-resident ring position: ``tick`` (which moves it) waits for this event, which also joins the slide's
+            # stream into the capturing one whichever stream it is (the auxiliary stream, or the ring's copy stream with LSTEP_NO_AUX_STREAM=1)
+            self._early_event = torch.cuda.Event()
+            self._early_event.record()
         self._advanced = [None, None]
 
     def wait_window(self):
@@ -761,7 +768,8 @@ class LstepEngine:
         bb.prepare_step()
         on_device = self.device_counts and (batch_idx == 0 or ring.len > 0)
         prep = None
-        if on_device and batch_idx > 0 and src.dtype == torch.int64 and ts.dtype == torch.float64 and os.environ.get("LSTEP_NO_BATCH_PREPARE") != "1":
+        if (on_device and batch_idx > 0 and src.dtype == dst.dtype == neg_dst.dtype == torch.int64 and ts.dtype == torch.float64
+                and src.device == dst.device == neg_dst.device == ts.device and os.environ.get("LSTEP_NO_BATCH_PREPARE") != "1"):
             prep = self.prepare_batch(src, dst, neg_dst, ts)
         if on_device:
             batch_nodes, n_live, presorted = self.batch_nodes_device(src, dst, keys=prep[2] if prep is not None else None)

@@ -955,7 +955,7 @@ class _GatherAggregate(torch.autograd.Function):
                 count.fill_(int(K))
         if sink is not None:
             e1.record()
-            sink.append((e0, e1, count))
+            sink.append((e0, e1, count, int(branches)))      # (branches: which channels this launch computed -- bench.py pairs split launches by it)
         ctx.mod, ctx.sampler, ctx.K, ctx.branches, ctx.ld_self, ctx.self_groups = mod, s, int(K), int(branches), ld_self, self_groups
         ctx.explicit = explicit
         ctx.pe_shape = tuple(pe.shape) if pe is not None else None

@@ -3,6 +3,7 @@ produced and (b) the CPU oracle on seeded inputs.  Bars: index tensors bit-exact
 within 1e-4 abs in fp32 (BASELINE.json north_star) -- the asserted tolerance is tighter (5e-5) so drift shows early
 (the largest observed difference, 2.2e-5, is fp32 re-association in the row-0 padding sum of update_pe).
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -379,8 +380,8 @@ def test_segment_rows_sum_vs_index_add(hip):
         assert float((out.double() - 2 * ref).abs().max()) <= 2 * tol
 
 
-@pytest.mark.parametrize("n_ent", [40000, 90000])      # 16-entry and 64-entry chunks
-def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch, n_ent):
+@pytest.mark.parametrize("n_ent,n_rows", [(40000, 9), (90000, 9), (600000, 2)])      # 16-entry chunks, 64-entry chunks, two giant hubs (> 64 groups of 16 chunks each)
+def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch, n_ent, n_rows):
     """Segments far longer than a chunk (hub nodes; more than 64 entries) are cut into per-chunk partial sums; with the scratch buffer the library joins
     them in chunk order (``segment_join_split_rows_kernel``), so the result is a function of the inputs alone: bit-identical from run to
     run and whatever else keeps the GPU busy (replicas of the PE table that run the same update_pe on different GPUs must not drift
@@ -389,9 +390,10 @@ def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch, n_ent
     from lstep_amd import _native as nat
     lib = nat.load_library()
     torch.manual_seed(5)
-    n_rows, nsrc, P, D = 9, 5000, 172, 100
+    nsrc, P, D = 5000, 172, 100
     table = torch.randn(nsrc, P, device=DEV)
-    seg = torch.sort(torch.randint(0, n_rows, (n_ent,), device=DEV)).values.to(torch.int32)          # ~4400 entries = 70 chunks per segment
+    # ~4400 / 10 000 / 300 000 entries per segment: 280 / 156 / 4700 chunks, joined through the two-level tree (groups of 16 middle chunks)
+    seg = torch.sort(torch.randint(0, n_rows, (n_ent,), device=DEV)).values.to(torch.int32)
     row = torch.randint(0, nsrc, (n_ent,), device=DEV, dtype=torch.int32)
     dt = torch.rand(n_ent, device=DEV) * 1e4
     tw = torch.from_numpy(1.0 / 10 ** np.linspace(0, 9, D, dtype=np.float32)).to(DEV)
@@ -1497,8 +1499,9 @@ def test_engine_ring_position_on_device_equals_host_position(hip, monkeypatch):
             assert int(eng.ring.dev_start.item()) == eng.ring.start
         res.append((torch.stack(tables).cpu().numpy(), np.array(losses), eng.ring.as_reference_tensor().cpu().numpy()))
     (ta, la, ha), (tb, lb, hb) = res
-    # (not bit-identical run to run: the loss kernel's float atomics sum in varying order and Adam turns rounding-level gradient
-    # differences into +-lr weight steps; a wrong slot anywhere would show at the 1e-1 level)
+    # (not held to bit-identity: the two engines group differently sized lists (the negatives' share of the PE-loss gradient still goes
+    # through float atomics, lstep_scatter_add_rows) and Adam turns rounding-level gradient differences into +-lr weight steps; a wrong
+    # slot anywhere would show at the 1e-1 level)
     np.testing.assert_allclose(ta, tb, rtol=0, atol=2e-5)
     np.testing.assert_allclose(ha, hb, rtol=0, atol=2e-5)
     np.testing.assert_allclose(la, lb, rtol=0, atol=2e-6)
@@ -1541,15 +1544,21 @@ def _check_long_trace_step(z, model, eng, res, b, worst):
     worst[key] = max(worst.get(key, 0.0), d)
 
 
-@pytest.mark.parametrize("graphed", [False, True], ids=["launch-by-launch", "graph-replay"])
-def test_long_training_trace_golden(hip, golden, graphed):
+@pytest.mark.parametrize("graphed", [False, True, "no-aux"], ids=["launch-by-launch", "graph-replay", "graph-replay-no-aux-stream"])
+def test_long_training_trace_golden(hip, golden, graphed, monkeypatch):
     """The path bench.py times, pinned to the REFERENCE: 16 consecutive training batches of tests/golden/traces_long.npz (the reference's
     loop body, train_LSTEP_link_prediction.py:204-311, run by make_golden.py) through the device engine with the one-launch Adam -- once
     launch by launch, once with ``use_step_graph`` (T = 4: batches 0-3 fill the window, 4-5 prime, 6 is captured, 7-15 are replays of
     the captured HIP graph).  Every step: snapshot, losses, link probabilities at the 5e-5 the other golden tests use (north_star: 1e-4)
     and every parameter gradient."""
     z = golden("traces_long")
+    if graphed == "no-aux":
+        # LSTEP_NO_AUX_STREAM=1 alone (round-3 ADVICE): the window slide of a captured iteration then runs on the ring's copy stream, which
+        # the capture must join before the device-resident ring position moves (HistoryRing.early_advance / tick)
+        monkeypatch.setenv("LSTEP_NO_AUX_STREAM", "1")
+        graphed = True
     g, model, eng, opt, stream, init = _long_trace_engine(hip, graphed)
+    assert eng.use_aux == (os.environ.get("LSTEP_NO_AUX_STREAM") != "1")
     worst = {}
     for b in range(LONG_BATCHES):
         res = _long_trace_step(eng, opt, stream, init, g, b)
