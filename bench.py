@@ -300,8 +300,11 @@ def main():
     marks = []
     barrier()
     t0 = time.perf_counter()
+    host_s = 0.0
     for i in range(args.steps):
+        h0 = time.perf_counter()
         step(args.warmup + i)
+        host_s += time.perf_counter() - h0
         if trace:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -322,6 +325,8 @@ def main():
         # duration is measured the same way on the next batches of the same stream, issued launch by launch right after the timed region
         eng_g = getattr(runner, "use_step_graph", None)
         runner.use_step_graph = False
+        if use_dist:
+            runner.comm_log = []        # the same launch-by-launch iterations time every collective between HIP events (the `comm` object)
         extra = max(3, min(10, args.steps))
         for i in range(extra):
             step(args.warmup + args.steps + i)
@@ -330,7 +335,23 @@ def main():
         timing_note = (f"the timed steps are graph replays, which cannot carry timed events: HIP events around the gather launch of the {extra} "
                        "iterations issued launch by launch right after the timed region (same stream of batches, same state)")
     model[0].gather_event_sink = None
+    comm = None
     if use_dist:
+        # per collective: bytes moved through this rank's buffers per call and the event-timed duration (launch-by-launch iterations);
+        # host_ms_per_step: time this rank's Python thread spent issuing one TIMED step (a graph replay: input copies + one launch)
+        log, runner.comm_log = (runner.comm_log or []), None
+        agg = {}
+        for name, nbytes, e0, e1 in log:
+            a = agg.setdefault(name, [0, 0, 0.0])
+            a[0] += 1
+            a[1] += nbytes
+            a[2] += e0.elapsed_time(e1)
+        steps_logged = max(1, len([1 for n_, *_ in log if n_ == "all_reduce parameter gradients"]))
+        comm = {"host_ms_per_step": host_s / args.steps * 1e3, "device_driven": bool(getattr(runner, "device_driven", False)),
+                "collectives_per_step": {k: {"calls": v[0] / steps_logged, "bytes_per_call": v[1] // max(v[0], 1), "ms_per_call": v[2] / max(v[0], 1)}
+                                         for k, v in agg.items()},
+                "timing": "HIP events around every collective of the launch-by-launch iterations run after the timed region (rank 0)"}
+        comm["timed_steps_are_graph_replays"] = bool(getattr(runner, "use_step_graph", False)) and args.mode == "train"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -382,6 +403,8 @@ def main():
                          "launch_ms": avg_ms, "launch_timing": timing_note, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
                          "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
         }
+        if comm is not None:
+            line["comm"] = comm
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and not args.zipf:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 31
+#define LSTEP_ABI_VERSION 32
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -459,6 +459,26 @@ int lstep_pull_keys(const int64_t* nbr, int64_t n_nbr, const int64_t* ids, int64
                     void* stream);
 int lstep_pull_blocks(const int32_t* uniq, const int32_t* summary, int32_t world, int64_t num_rows, int64_t capacity, int32_t* req, int32_t* count,
                       void* stream);
+/* Owner-sharded execution with every size on the device (round 4: a rank's iteration is a fixed launch sequence with fixed-capacity
+ * collectives and can be replayed as one HIP graph; the reference is single-process, SURVEY.md 8e -- these replace host-sized
+ * argsort / bincount / index_copy_ chains around its train_LSTEP_link_prediction.py:221-230 splice).
+ * lstep_owner_partition: ids int64 [capacity] = the batch's sorted unique endpoints (lstep_widen_ids: *num_live of them, dead tail = node 0)
+ *   split by owner rank id % world into world blocks of block_slots slots: ids_by_owner int64 [world * block_slots] (block p = the ids owned
+ *   by rank p in ascending order, unused slots = 0), pos_by_owner int32 (the entry's position in `ids`, unused = 0), counts int32 [world]
+ *   (clamped to block_slots).  *overflow is OR-ed with 1 when some owner holds more than block_slots entries (the surplus is dropped: the
+ *   caller's capacity was too small and the step must not be trusted -- it never resets the word).  workspace:
+ *   lstep_owner_partition_workspace(capacity, world) bytes.  world <= 16.
+ * lstep_scatter_owner_rows: rows [world * block_slots, ld_rows] (the all-gathered blocks, same layout) -> table[id, :width] for the
+ *   counts[p] leading slots of every block; slot_of (optional int32 [num_rows]) receives the slot number p * block_slots + i of each id
+ *   (the row of the compact gradient buffer, lstep_gather_aggregate_bwd).
+ * lstep_rows_by_id: ids int32 [n] with holes (-1): direction 0 copies table rows into buf [n, width] (an owner serving a pull request),
+ *   direction 1 writes buf rows into the table (the requester storing what it received). */
+int64_t lstep_owner_partition_workspace(int64_t capacity, int32_t world);
+int lstep_owner_partition(const int64_t* ids, int64_t capacity, const int32_t* num_live, int32_t world, int64_t block_slots, void* workspace,
+                          int64_t workspace_bytes, int64_t* ids_by_owner, int32_t* pos_by_owner, int32_t* counts, int32_t* overflow, void* stream);
+int lstep_scatter_owner_rows(const float* rows, int32_t ld_rows, const int64_t* ids_by_owner, const int32_t* counts, int32_t world,
+                             int64_t block_slots, float* table, int32_t width, int32_t* slot_of, void* stream);
+int lstep_rows_by_id(const int32_t* ids, int64_t n, float* table, int32_t width, float* buf, int32_t direction, void* stream);
 int lstep_update_entries_p1(const int32_t* order, int64_t num_entries, const int64_t* src, const int64_t* dst, const double* times,
                             const float* now32, int64_t batch, int32_t* ent_row, float* ent_dt, void* stream);
 int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank, int32_t* keys, void* stream);

@@ -877,7 +877,8 @@ def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, 
     if g_self is None:
         return total
     if self_groups is None:
-        _segment_reduce_rows(mod, total, self_slot.to(torch.int32), lambda o: o.contiguous(), g_self, accumulate=True)
+        # (div = 1: entry e reads row e -- the form whose sort runs on a capacity taken from earlier batches, without a host round trip)
+        _segment_reduce_rows(mod, total, self_slot.to(torch.int32), lambda o: o.contiguous(), g_self, accumulate=True, div=1)
         return total
     ent_seg, ent_row = self_groups
     n_known = ent_row.numel()
@@ -1763,7 +1764,7 @@ class LSTEP(nn.Module):
 
     @torch.no_grad()
     def update_pe_device(self, pe, bn, n_live, src, dst, t, num_neighbors: int, presorted, changed=None, mirror=None, mirror_ring=None,
-                         mirror_shard=(1, 0), owner=None, owned_idx=None, after_phase1=None, now32=None):
+                         mirror_shard=(1, 0), owner=None, owned_idx=None, after_phase1=None, now32=None, owned_live=None):
         """``update_pe`` for the engine, with every data-dependent size left on the device: no host synchronisation, no second host
         thread, a fixed launch sequence.
 
@@ -1778,7 +1779,8 @@ class LSTEP(nn.Module):
 
         OWNER-COMPUTES form (``lstep_amd.parallel``, one process per GPU): ``owner = (W, r)`` -- this rank computes only the rows with
         id % W == r.  Phase 1: the message sums of all batch nodes are formed (two rows per batch edge, every rank has the inputs), the MLP
-        and the write run for the batch nodes at positions ``owned_idx`` of ``bn`` (int64, sized on the host by the caller);
+        and the write run for the batch nodes at positions ``owned_idx`` of ``bn`` (sized on the host by the caller, or -- ``owned_live``, an
+        int32 [1] device count -- a capacity-sized list whose dead tail points at position 0: ``lstep_owner_partition``);
         ``after_phase1(ids)`` then exchanges the new rows so that ``pe[bn]`` holds every batch node's phase-1 value on every rank
         (phase 2's messages carry them).  Phase 2: the sampled slots whose NEIGHBOUR this rank owns are grouped and summed, only those
         rows go through the MLP; row 0 belongs to rank 0.  Everything stays device-sized."""
@@ -1805,7 +1807,8 @@ class LSTEP(nn.Module):
         else:
             ids1 = bn.index_select(0, owned_idx)
             if ids1.numel():
-                self._update_rows(pe, ids1, agg.index_select(0, owned_idx), with_self=True, mirror=mirror, ring=mirror_ring, mirror_shard=mirror_shard)
+                self._update_rows(pe, ids1, agg.index_select(0, owned_idx), with_self=True, mirror=mirror, live=owned_live, ring=mirror_ring,
+                                  mirror_shard=mirror_shard)
             if changed is not None:
                 changed(ids1, mirror is not None)
             if after_phase1 is not None:

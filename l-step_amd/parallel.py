@@ -40,8 +40,12 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from .engine import HistoryRing, LstepEngine, _LinkLoss, _lookup_rows
+from .engine import HistoryRing, LstepEngine, _LinkLoss, _backward_unit, _lookup_rows
 from .model import SplicedRows
+
+
+class LstepCapacityError(RuntimeError):
+    """A fixed-capacity block of the device-driven multi-GPU iteration was too small for the data (see ``DistributedLstep.check_capacity``)."""
 
 
 # ---------------------------------------------------------------------------------------------- collectives
@@ -159,9 +163,10 @@ def reduce_scatter_var(t: torch.Tensor, counts, group=None):
     return out.to(t.device) if staged else out
 
 
-def all_reduce_gradients(params, group=None, extra: torch.Tensor = None):
+def all_reduce_gradients(params, group=None, extra: torch.Tensor = None, scale: float = None):
     """One flat bucket for all parameter gradients (complex ones viewed as real); missing grads count as zero.  ``extra`` (1-D float32,
-    optional) rides in the same bucket and is returned summed over the ranks (the three loss scalars: one collective less per step)."""
+    optional) rides in the same bucket and is returned summed over the ranks (the three loss scalars: one collective less per step).
+    ``scale``: the reduced bucket (gradients and ``extra``) is multiplied by it (1 / world: the mean over the ranks) in one launch."""
     views = []
     for p in params:
         if not p.requires_grad:
@@ -172,6 +177,8 @@ def all_reduce_gradients(params, group=None, extra: torch.Tensor = None):
     parts = [v.reshape(-1) for v in views] + ([extra.reshape(-1).to(views[0].dtype)] if extra is not None else [])
     flat = torch.cat(parts)
     all_reduce_sum(flat, group)
+    if scale is not None:
+        flat.mul_(scale)
     chunks = torch.split(flat, [p.numel() for p in parts])
     torch._foreach_copy_(views, [c.view_as(v) for c, v in zip(chunks, views)])
     return chunks[-1] if extra is not None else None
@@ -391,15 +398,24 @@ class ShardedSparseRing(HistoryRing):
         self.mark(ids, self.world, self.rank, copy=not mirrored)
 
     def commit(self):
-        dst = self.buf[(self.start + self.len) % self.S]
+        slot = (self.start + self.len) % self.S
+        dst = self.buf[slot]
         if self._all_written or self.len == 0:
             dst.copy_(self.owned())
         else:
+            if self._written:
+                assert self.dev_start is None, "writers without a mirror need the host-resident ring position"
             for ids in self._written:          # writers without a mirror (none on the device-count path): their owned rows, copied now
                 own = ids[ids % self.world == self.rank]
                 dst.index_copy_(0, own // self.world, self.full[own])
-            # local row 0 carries the always-set change bit (lstep_history_slot_bits: it is the padding row on rank 0): keep it valid
-            dst[0].copy_(self.full[self.rank])
+            # local row 0 carries the always-set change bit (lstep_history_slot_bits: it is the padding row on rank 0): keep it valid.
+            # (lstep_copy_rows copies row r of the source to row r of the slot: the source pointer is moved to full[rank], r = 0; the slot is
+            # picked on the device when the ring position lives there)
+            from . import _native as nat
+            ref = self._ref(slot)
+            with torch.cuda.device(self.buf.device):
+                nat.check(nat.load_library().lstep_copy_rows(nat.ptr(self.buf if ref is not None else dst), nat.ptr(self.full[self.rank:]), self.P, self.P,
+                                                             nat.ptr(self._row0), 1, self.rows, ref, nat.current_stream()))
         if self.len == 0:
             self.oldest.copy_(self.owned())
         self._written, self._all_written = [], False
@@ -454,12 +470,31 @@ class DistributedLstep:
                 from .model import _aux_stream
                 self._ring.advance_stream = _aux_stream(dev)
             if self.form == "pull":
-                # the pulled rows travel on a communicator of their own: on the main one they would queue behind the backward pass's
-                # reduce-scatter / all-reduce (a communicator runs its collectives in issue order) instead of underneath them
-                self.pull_group = dist.new_group(backend=dist.get_backend(group)) if not _skip_single(self.W) else group
+                # launch by launch (gloo; LSTEP_PULL_COMM=own; LSTEP_DIST_GRAPH=0) the pulled rows travel on a communicator of their own: on the
+                # main one they would queue behind the backward pass's reduce-scatter / all-reduce (a communicator runs its collectives in
+                # issue order) instead of underneath them.  A captured iteration keeps every collective on the main communicator (below).
+                captured = (os.environ.get("LSTEP_DIST_HOST_COUNTS") != "1" and os.environ.get("LSTEP_DIST_GRAPH", "1") != "0"
+                            and torch.device(dev).type == "cuda" and dist.get_backend(group) != "gloo"
+                            and os.environ.get("LSTEP_PULL_COMM", "main") != "own")
+                self.pull_group = dist.new_group(backend=dist.get_backend(group)) if not (_skip_single(self.W) or captured) else group
         else:
             self._ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
         self._copy_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
+        # DEVICE-DRIVEN iteration (round 4): every collective has a fixed capacity and its live count travels on the device
+        # (``lstep_owner_partition``), so the host never waits for the GPU inside an iteration and -- over RCCL -- the whole training
+        # iteration, collectives included, is captured once and replayed as ONE HIP graph (``GraphedDistStep``), like the single-GPU engine's.
+        # LSTEP_DIST_HOST_COUNTS=1: the host-sized iterations of rounds 2-3 (A/B; also what "allgather" always takes).
+        self.device_driven = self.form in ("replicate", "pull") and os.environ.get("LSTEP_DIST_HOST_COUNTS") != "1"
+        self.use_step_graph = (self.device_driven and os.environ.get("LSTEP_DIST_GRAPH", "1") != "0" and torch.device(dev).type == "cuda"
+                               and dist.get_backend(group) != "gloo")
+        self._graphed, self._steady_steps = {}, 0
+        self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)      # sticky: some fixed-capacity block was too small
+        self._overflow_poll = None
+        self.comm_log = None        # bench.py: a list that receives (name, bytes, start event, end event) of every collective issued eagerly
+        if self.form == "pull" and self.use_step_graph and os.environ.get("LSTEP_PULL_COMM", "main") == "own":
+            # LSTEP_PULL_COMM=own: the pull keeps its own communicator and stream and the iteration is issued launch by launch (capturing an
+            # all-to-all on a second communicator from a side stream faulted in RCCL 2.26: tools/rccl_capture_probe.py)
+            self.use_step_graph = False
         # update_pe's layers are forward-only (no gradient ever reaches them): they stay out of the bucket
         frozen = {id(p) for m in (self.bb.pe_mlp_1, self.bb.pe_mlp_2, self.bb.self_update_pe) for p in m.parameters()}
         self._trainable = [p for p in list(self.bb.parameters()) + list(self.predictor.parameters()) if id(p) not in frozen]
@@ -616,7 +651,10 @@ class DistributedLstep:
                 raise RuntimeError(f"LSTEP_PHASE2={policy} needs the device-count update path (default widths, 'recent' sampling, T <= 126, a GPU)")
             return "allgather"
         if policy == "auto":
-            return "replicate" if self.W <= 4 else "pull"
+            # (round-3 ADVICE: "pull" has never run on more than one real RCCL rank -- no multi-GPU box was ever leased to the builder -- so
+            # it is opt-in, LSTEP_PHASE2=pull, until a multi-rank hardware run of tests/test_parallel.py has passed; "replicate" issues three
+            # plain equal-block collectives per step on one communicator)
+            return "replicate"
         return policy
 
     def _phase2_replicated(self) -> bool:
@@ -654,6 +692,8 @@ class DistributedLstep:
 
     # ---- train:204-311 on a global batch of W*B edges (every rank passes the SAME arrays)
     def train_iteration(self, optimizer, batch_idx: int, src, dst, ts, eid, neg_dst, initial_pe: torch.Tensor = None, lookahead=None):
+        if self.device_driven:
+            return self._train_iteration_device_driven(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
         with self.eng.aux_streams():
             if self.form == "pull":
                 return self._train_iteration_pull(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
@@ -710,6 +750,14 @@ class DistributedLstep:
         even = -(-n // self.W)
         want = max(even + even // 2, self._pull_min_capacity + self._pull_min_capacity // 4, 1024)
         return min(n, -(-want // 1024) * 1024)
+
+    def _pull_capacity_dev(self, n: int) -> int:
+        """Id slots per owner of the device-driven pull (``RowPullDev``): LSTEP_PULL_SLACK (default 1.25) x an even split of the n candidate
+        ids -- the rows travel in blocks of this size too, so the slack is paid in bytes -- never more than n.  An overflow is detected on the
+        device and reported by ``check_capacity``."""
+        even = -(-n // self.W)
+        want = int(even * float(os.environ.get("LSTEP_PULL_SLACK", "1.25"))) + 256
+        return min(n, -(-want // 256) * 256)
 
     def _pull_now(self, blocks, ts):
         """No look-ahead had the rows fetched: request and fetch on the current stream (two host waits)."""
@@ -1061,6 +1109,8 @@ class DistributedLstep:
 
     # ---- evaluate_model_utils.py:38-142 on a global batch (call under torch.no_grad())
     def eval_iteration(self, batch_idx: int, src, dst, ts, eid, neg_src, neg_dst, lookahead=None):
+        if self.device_driven and self._ring.len > 0:
+            return self._eval_iteration_dev(batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead)
         if self.form == "pull":
             return self._eval_iteration_pull(batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead)
         if self.replicated:
@@ -1079,3 +1129,504 @@ class DistributedLstep:
         labels = torch.cat([torch.ones_like(p_pos), torch.zeros_like(p_neg)], dim=0)
         self._update_finish(self._update_start(bn, src, dst, ts))
         return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}
+
+    # =====================================================================================================================================
+    # DEVICE-DRIVEN iteration (round 4).  Same algorithm as the host-sized iterations above, but nothing in it depends on a
+    # count the host would have to read: the batch-node list is capacity-sized (2 x global batch, live count on the device), its split by
+    # owner is W blocks of C slots (``lstep_owner_partition``: ids, positions, per-owner counts -- all on the device), and every collective
+    # moves whole blocks:  all_gather_into_tensor of [C, P] filtered rows -> [W * C, P];  reduce_scatter_tensor of the [W * C, P] gradient
+    # (the gradient buffer IS laid out by (owner, slot): slot_of numbers the spliced rows that way, so no re-ordering copy on either side);
+    # the flat all-reduce;  "pull": all_gather of the [C, P] phase-1 rows, all_to_all_single of [W, Cp] request ids and of [W, Cp, P] rows.
+    # Unused slots carry node 0 / garbage rows that no consumer reads (every consumer takes the per-owner count on the device).
+    # A block that is too small sets a sticky device flag which the host polls WITHOUT waiting (``check_capacity``): the step that
+    # overflowed is invalid and the next call raises ``LstepCapacityError`` (capacity: LSTEP_DIST_SLACK, default 1.25 x an even split;
+    # ids are spread over owners by id % W, so a block is off an even split by ~1 / sqrt(U / W)).
+    # An iteration is then a fixed launch sequence: over RCCL it is captured ONCE, collectives included, and replayed (``GraphedDistStep``).
+    # =====================================================================================================================================
+    def _owner_capacity(self, cap: int) -> int:
+        """Slots per owner block for a capacity-sized list of ``cap`` ids."""
+        if self.W == 1:
+            return cap
+        slack = float(os.environ.get("LSTEP_DIST_SLACK", "1.25"))
+        want = int(-(-cap // self.W) * slack) + 64
+        return min(cap, -(-want // 64) * 64)
+
+    def _partition(self, bn_cap: torch.Tensor, n_live: torch.Tensor):
+        """``lstep_owner_partition`` of the batch-node list: (ids [W * C] int64, positions in bn [W * C] int32, counts [W] int32, C)."""
+        from . import _native as nat
+        lib = nat.load_library()
+        cap, W, dev = bn_cap.numel(), self.W, self.device
+        C = self._owner_capacity(cap)
+        ids = torch.empty(W * C, dtype=torch.int64, device=dev)
+        pos = torch.empty(W * C, dtype=torch.int32, device=dev)
+        counts = torch.empty(W, dtype=torch.int32, device=dev)
+        ws = nat._workspace(dev, int(lib.lstep_owner_partition_workspace(cap, W)))
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_owner_partition(nat.ptr(bn_cap), cap, nat.ptr(n_live), W, C, nat.ptr(ws), ws.numel(), nat.ptr(ids), nat.ptr(pos),
+                                                nat.ptr(counts), nat.ptr(self._overflow), nat.current_stream()))
+        return ids, pos, counts, C
+
+    def check_capacity(self, wait: bool = False):
+        """Raise if a fixed-capacity block overflowed in an EARLIER iteration.  The flag travels to the host asynchronously; without ``wait``
+        this never blocks (an overflow is reported one or two iterations late -- the results since then are invalid either way)."""
+        if not self._overflow.is_cuda:
+            bad = bool(self._overflow.item())
+        else:
+            if wait:
+                bad = bool(self._overflow.item())
+            else:
+                bad = False
+                pend = self._overflow_poll
+                if pend is not None and pend[1].query():
+                    bad = bool(pend[0][0])
+                    self._overflow_poll = pend = None
+                if pend is None and not torch.cuda.is_current_stream_capturing():
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(self._overflow, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._overflow_poll = (host, ev)
+        if bad:
+            raise LstepCapacityError("a fixed-capacity owner block of the device-driven multi-GPU iteration overflowed (node ids are very unevenly "
+                                     "spread over id % world): results since then are invalid; raise LSTEP_DIST_SLACK (default 1.25) or set "
+                                     "LSTEP_DIST_HOST_COUNTS=1 for the host-sized iteration")
+
+    def _log(self, name: str, nbytes: int):
+        """bench.py's ``comm`` object: a pair of timed events around an eagerly issued collective (never inside a capture)."""
+        if self.comm_log is None or torch.cuda.is_current_stream_capturing() or not self.table.is_cuda:
+            return contextlib.nullcontext()
+        log = self.comm_log
+
+        @contextlib.contextmanager
+        def timed():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            yield
+            e1.record()
+            log.append((name, int(nbytes), e0, e1))
+        return timed()
+
+    def _scatter_owner_rows(self, rows_all: torch.Tensor, part, number: bool):
+        """Block p, slot i < counts[p] of the gathered rows -> table[ids[p, i]]; ``number``: slot_of[id] = p * C + i as well."""
+        from . import _native as nat
+        ids, _, counts, C = part
+        with torch.cuda.device(self.device):
+            nat.check(nat.load_library().lstep_scatter_owner_rows(nat.ptr(rows_all), int(rows_all.stride(0)), nat.ptr(ids), nat.ptr(counts), self.W, C,
+                                                                  nat.ptr(self.table), self.bb.pe_dim, nat.ptr(self.slot_of) if number else None,
+                                                                  nat.current_stream()))
+
+    def _splice_start_dev(self, part, batch_idx: int):
+        """Filter the history of the batch nodes this rank owns (its block of the partition, count on the device) and put the all-gather of
+        the [C, P] block IN FLIGHT."""
+        ids, _, counts, C = part
+        r = self.rank
+        self._wait_snapshot()
+        ring = self._ring
+        ring.wait_window()
+        mine_local = torch.div(ids[r * C:(r + 1) * C], self.W, rounding_mode="floor")      # local ring rows (dead slots: node 0 -> row 0)
+        rows_mine = self.bb.filter_history(ring.buf, ring.geom(), mine_local, batch_idx, mask=ring.mask, oldest=ring.oldest,
+                                           live=counts[r:r + 1], ring=ring.window_ref())
+        with self._log("all_gather filtered rows", self.W * C * self.bb.pe_dim * 4):
+            pending = PendingGather(rows_mine.detach(), self.group, counts=[C] * self.W)
+            if self.comm_log is not None:
+                pending.wait()                        # (being timed: not left in flight)
+        return rows_mine, pending
+
+    def _splice_finish_dev(self, started, part):
+        rows_mine, pending = started
+        gathered = pending.wait()                     # [W * C, P], block p = rank p's filtered rows
+        self._scatter_owner_rows(gathered, part, number=True)
+        return rows_mine, gathered.detach().requires_grad_(True)
+
+    def _forward_dev(self, part, batch_idx, ids3, t3, b, pull=None):
+        """FFT splice (owner-sharded filter + fixed-capacity all-gather) and this rank's slice through gather, dense tail, predictor, loss."""
+        started = self._splice_start_dev(part, batch_idx)
+        fused = self.bb._fused_tail_ok()
+        # edge + node channels first: they read no PE row, so their launch overlaps the all-gather of the filtered rows
+        x_edge, x_node, _, _, _ = self.bb._gather(None, ids3, t3, self.K, self.G, nat_branch("edge_node"), wide=fused, row_blocks=3)
+        if pull is not None:
+            pull.wait()      # (rows of this batch's nodes were fetched BEFORE their splice: the all-gathered spliced rows overwrite them next)
+        rows_mine, leaf = self._splice_finish_dev(started, part)
+        spliced = SplicedRows(leaf, self.slot_of)
+        _, _, x_pe, own, _ = self.bb._gather(self.table, ids3, t3, self.K, self.G, nat_branch("pe"), spliced, wide=fused, row_blocks=3)
+        emb_p = self.bb._combined_tail(x_edge, x_node, x_pe, own, fused)
+        logits = self.predictor.pair_logits(emb_p, b, (0, b, 0, 2 * b))
+        loss, lp_loss, pe_loss, predicts = _LinkLoss.apply(logits, leaf, self.table, self.slot_of, ids3, self.eng.pe_weight,
+                                                           self.eng.neg_sample_weight)
+        out = {"lp_loss": lp_loss.detach(), "pe_loss": pe_loss.detach(), "loss": loss.detach(), "predicts": predicts.detach()}
+        return out, loss, rows_mine, leaf
+
+    def _share_phase1_rows_dev(self, part):
+        """``update_pe_device(after_phase1=...)`` with fixed blocks: every owner's [C, P] block of freshly written phase-1 rows is all-gathered
+        and scattered into every table (north_star's "all-gather of updated positional encodings")."""
+        ids, _, _, C = part
+        r = self.rank
+
+        def share(ids1):
+            if _skip_single(self.W):
+                return
+            mine = self.table.index_select(0, ids[r * C:(r + 1) * C])
+            with self._log("all_gather phase-1 rows", self.W * C * self.bb.pe_dim * 4):
+                rows_all, _ = all_gather_var(mine, self.group, counts=[C] * self.W)
+            self._scatter_owner_rows(rows_all, part, number=False)
+        return share
+
+    def _reduce_gradients_dev(self, leaf, rows_mine, part, out):
+        """Backward tail shared by both forms: reduce-scatter of the spliced rows' gradient by owner block, the history-filter backward on this
+        rank's shard, the flat all-reduce (with the three loss scalars), everything scaled to the mean over the ranks."""
+        C, W, P = part[3], self.W, self.bb.pe_dim
+        g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+        with self._log("reduce_scatter row gradient", W * C * P * 4):
+            g_mine = reduce_scatter_var(g_rows, [C] * W, self.group)
+        if W > 1:
+            g_mine = g_mine * (1.0 / W)                  # global mean = mean of the rank means (the local backward was seeded with 1)
+        rows_mine.backward(g_mine)                       # -> fft_filter / fft_agg through this rank's history shard (dead slots: zero gradient)
+        self.bb.join_aux_stream()
+        extra = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
+        with self._log("all_reduce parameter gradients", sum(p.numel() * (2 if p.is_complex() else 1) for p in self._trainable) * 4):
+            v = all_reduce_gradients(self._trainable, self.group, extra=extra, scale=(1.0 / W) if W > 1 else None)
+        return v
+
+    def _batch_dev(self, src, dst, neg_dst, ts):
+        """(global grouping keys / float32(max t), this rank's gather rows and times, B per rank)."""
+        eng, W, r = self.eng, self.W, self.rank
+        b = src.numel() // W
+        prep = eng.prepare_batch(src, dst, neg_dst, ts)
+        if W == 1:
+            return prep, prep[0], prep[1], b
+        sl = slice(r * b, (r + 1) * b)
+        loc = eng.prepare_batch(src[sl], dst[sl], neg_dst[sl], ts[sl])
+        return prep, loc[0], loc[1], b
+
+    def _train_iteration_device_driven(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
+        from .model import drain_dead_graphs
+        drain_dead_graphs()
+        self.check_capacity()
+        assert src.numel() % self.W == 0, "global batch must divide by the world size"
+        ring = self._ring
+        if self._ring_generation != ring.generation:
+            self.drop_captured_iterations()
+            self._ring_generation = ring.generation
+        if self._graph_ready(optimizer, batch_idx, src, ts):
+            gs = self._graphed.get(src.numel())
+            if gs is None or gs.optimizer is not optimizer:
+                if gs is not None:
+                    gs.close()
+                gs = self._graphed[src.numel()] = GraphedDistStep(self, optimizer, src.numel())
+            return gs.step(batch_idx, src, dst, ts, eid, neg_dst, lookahead)
+        if ring.len == ring.T and batch_idx > 0:
+            self._steady_steps += 1
+        with self.eng.aux_streams():
+            return self._train_iteration_dev(optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead)
+
+    _ring_generation = 0
+
+    def _graph_ready(self, optimizer, batch_idx, src, ts) -> bool:
+        from .optim import FusedAdam
+        ring = self._ring
+        return (self.use_step_graph and batch_idx > 0 and ring.len == ring.T and isinstance(optimizer, FusedAdam) and self._steady_steps >= 2
+                and self.eng.overlap_update and src.dtype == torch.int64 and ts.dtype == torch.float64)
+
+    def drop_captured_iterations(self):
+        for gs in self._graphed.values():
+            gs.close()
+        self._graphed, self._steady_steps = {}, 0
+
+    def close(self):
+        self.drop_captured_iterations()
+        self.bb.close()
+
+    def _train_iteration_dev(self, optimizer, batch_idx, src, dst, ts, eid, neg_dst, initial_pe, lookahead):
+        """train:204-311 on a global batch of W * B edges, no host synchronisation anywhere (module comment above)."""
+        eng, bb, ring = self.eng, self.bb, self._ring
+        W, rank = self.W, self.rank
+        pull_form = self.form == "pull"
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            ring.early_advance()             # the previous iteration's slide: beside this iteration
+        else:
+            ring.apply_advance()             # (a slide left pending by a replayed iteration)
+        bb.prepare_step()
+        prep, ids3, t3, b = self._batch_dev(src, dst, neg_dst, ts)
+        bn_cap, n_live, presorted = eng.batch_nodes_device(src, dst, keys=prep[2])
+        part = self._partition(bn_cap, n_live)
+        out = loss = None
+        if batch_idx == 0:
+            self.table.copy_(initial_pe)         # every row valid on every rank
+            self._pending_pull = None
+            ring.begin_slot(all_changed=True)
+        else:
+            pull = None
+            if pull_form and not capturing:
+                # (a captured iteration finds the rows of ITS gather in the table: the previous replay fetched them from its look-ahead
+                # buffers, or ``GraphedDistStep.step`` fetched them launch by launch; every replay ends with all its streams joined)
+                pull = self._take_pull(src, dst, ts, neg_dst) or self._pull_now_dev((src, dst, neg_dst), ts)
+            out, loss, rows_mine, leaf = self._forward_dev(part, batch_idx, ids3, t3, b, pull=pull)
+        nxt = None
+        ps = self._pull_stream
+        ahead = lookahead if (pull_form and lookahead is not None and len(lookahead) >= 4) else None
+        if ahead is not None:       # the next batch's requests: independent of everything this iteration computes
+            if ps is not None:
+                ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                nxt = RowPullDev(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]))
+
+        def update_and_append():
+            base, ref = ring.building_ref()
+            kw = dict(changed=ring.written, mirror=base if ref is not None else ring.building(), mirror_ring=ref, mirror_shard=(W, rank),
+                      now32=prep[3])
+            if pull_form:
+                C = part[3]
+                kw.update(owner=(W, rank), owned_idx=part[1][rank * C:(rank + 1) * C].long(), owned_live=part[2][rank:rank + 1],
+                          after_phase1=self._share_phase1_rows_dev(part))
+            bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, **kw)
+            if batch_idx == 0 and initial_pe is not None:
+                if pull_form:
+                    self.sync_full_table()
+                initial_pe.copy_(self.table)
+            ring.commit()
+
+        def fetch_next(after=None):
+            """Serve and receive the next gather's rows on the pull stream, behind ``after`` (update_pe's end) or the current stream."""
+            if ps is not None:
+                if after is not None:
+                    ps.wait_event(after)
+                else:
+                    ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                self._poison_foreign_rows()
+                nxt.fetch()
+            self._pending_pull = nxt
+
+        if loss is None:
+            update_and_append()
+            ring.apply_advance()
+            if nxt is not None:
+                fetch_next()
+            ring.tick()
+            return out
+        main, side = torch.cuda.current_stream(self.device), eng._update_stream
+        side.wait_stream(main)           # after the forward pass: it reads the table update_pe is about to rewrite
+        with torch.cuda.stream(side):
+            update_and_append()
+            updated = torch.cuda.Event()
+            updated.record()
+        optimizer.zero_grad()
+        _backward_unit(loss)
+        v = self._reduce_gradients_dev(leaf, rows_mine, part, out)
+        ring.apply_advance()             # the backward pass is enqueued: the window's oldest snapshot may move on behind it
+        if nxt is not None:
+            # the rows of the NEXT gather: behind update_pe (the owners' rows are final there).  Launch by launch with a communicator of its
+            # own the exchange runs underneath the backward pass; on the main communicator (captured iterations) it is issued LAST, so the
+            # backward pass's reduce-scatter / all-reduce never queue behind it
+            fetch_next(updated)
+        main.wait_event(updated)         # the optimiser may only step once update_pe has read its weights; the ring shard is appended
+        if nxt is not None and ps is not None and capturing:
+            main.wait_stream(ps)         # (a capture must end with every stream joined)
+        optimizer.step()
+        self.slot_of.index_fill_(0, bn_cap, -1)      # (the dead tail is node 0, whose entry is -1 anyway)
+        ring.tick()
+        out["lp_loss"], out["pe_loss"], out["loss"] = v.unbind(0)       # global means (they travelled with the gradient bucket)
+        return out
+
+    def _pull_now_dev(self, blocks, ts):
+        """No look-ahead had the rows fetched: request and fetch on the current stream (no host wait either: fixed blocks)."""
+        pull = RowPullDev(self, *self._slice_rows(blocks, ts))
+        self._poison_foreign_rows()
+        pull.fetch()
+        return pull
+
+    def _eval_iteration_dev(self, batch_idx, src, dst, ts, eid, neg_src, neg_dst, lookahead):
+        """evaluate_model_utils.py:38-142 on a global batch, device-driven (call under torch.no_grad())."""
+        self.check_capacity()
+        eng, bb, ring = self.eng, self.bb, self._ring
+        W, rank = self.W, self.rank
+        pull_form = self.form == "pull"
+        b = src.numel() // W
+        ring.apply_advance()
+        bn_cap, n_live, presorted = eng.batch_nodes_device(src, dst)
+        part = self._partition(bn_cap, n_live)
+        pull = None
+        if pull_form:
+            pull = self._take_pull(src, dst, ts, neg_src, neg_dst) or self._pull_now_dev((src, dst, neg_src, neg_dst), ts)
+        started = self._splice_start_dev(part, batch_idx)
+        if pull is not None:
+            pull.wait()
+        self._splice_finish_dev(started, part)
+        self.slot_of.index_fill_(0, bn_cap, -1)
+        ids, t4 = self._slice_rows((src, dst, neg_src, neg_dst), ts)
+        emb_p = bb.combining_pe_raw_feat(self.table, ids, t4, self.K, self.G, padded=True, row_blocks=4)
+        if self.predictor.fused_ok(emb_p):
+            predicts = self.predictor.pair_logits(emb_p, b, (0, b, 2 * b, 3 * b)).sigmoid().clamp(0, 1)
+        else:
+            emb = emb_p[:, :bb.feat_dim]
+            predicts = torch.cat([self._probabilities(emb[:b], emb[b:2 * b]), self._probabilities(emb[2 * b:3 * b], emb[3 * b:])], dim=0)
+        labels = torch.cat([torch.ones(b, device=self.device), torch.zeros(b, device=self.device)])
+        nxt = None
+        ps = self._pull_stream
+        if pull_form and lookahead is not None and len(lookahead) >= 5:
+            if ps is not None:
+                ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                nxt = RowPullDev(self, *self._slice_rows((lookahead[0], lookahead[1], lookahead[3], lookahead[4]), lookahead[2]),
+                                 key=TensorsKey(*lookahead[:5]))
+        base, ref = ring.building_ref()
+        kw = dict(changed=ring.written, mirror=base if ref is not None else ring.building(), mirror_ring=ref, mirror_shard=(W, rank))
+        if pull_form:
+            C = part[3]
+            kw.update(owner=(W, rank), owned_idx=part[1][rank * C:(rank + 1) * C].long(), owned_live=part[2][rank:rank + 1],
+                      after_phase1=self._share_phase1_rows_dev(part))
+        bb.update_pe_device(self.table, bn_cap, n_live, src, dst, ts, self.K, presorted, **kw)
+        ring.commit()
+        ring.apply_advance()
+        ring.tick()
+        if nxt is not None:
+            if ps is not None:
+                ps.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
+                self._poison_foreign_rows()
+                nxt.fetch()
+            self._pending_pull = nxt
+        return {"loss": F.binary_cross_entropy(predicts, labels), "predicts": predicts}
+
+
+class RowPullDev:
+    """``RowPull`` with fixed blocks in BOTH directions (device-driven: nothing here reads a count on the host): ``request`` sends every owner a
+    block of ``Cp`` id slots (-1 = unused), ``fetch`` has every owner copy the rows it was asked for into a [W, Cp, P] buffer
+    (``lstep_rows_by_id``), ONE all_to_all_single of equal blocks moves them, and the requester writes the rows of its own id blocks into
+    its table.  A list that does not fit its block sets the engine's sticky overflow flag (``DistributedLstep.check_capacity``)."""
+
+    def __init__(self, dl: "DistributedLstep", ids: torch.Tensor, times: torch.Tensor, key: TensorsKey = None):
+        from . import _native as nat
+        self.dl, self.key = dl, key
+        W, rank, dev, rows = dl.W, dl.rank, dl.device, dl.num_rows
+        nbr = dl.bb.neighbor_sampler.sample_device(ids, times, dl.K)[0]
+        lib = nat.load_library()
+        n = nbr.numel() + ids.numel() + 1
+        sentinel = W * rows
+        keys = torch.empty(n, dtype=torch.int32, device=dev)
+        ids = ids.contiguous()
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_pull_keys(nat.ptr(nbr), nbr.numel(), nat.ptr(ids), ids.numel(), W, rank, rows, nat.ptr(keys), nat.current_stream()))
+        _, _, _, uniq, summary = nat.group_by_key(keys, max(1, int(sentinel + 1).bit_length()), sentinel, wait=None)
+        C = self.C = dl._pull_capacity_dev(n)
+        self.req = torch.empty((W, C), dtype=torch.int32, device=dev)
+        cnt = torch.empty(W, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_pull_blocks(nat.ptr(uniq), nat.ptr(summary), W, rows, C, nat.ptr(self.req), nat.ptr(cnt), nat.current_stream()))
+        dl._overflow.bitwise_or_((cnt > C).any().to(torch.int32))
+        with dl._log("all_to_all pull requests", W * C * 4):
+            self.asked = exchange_rows(self.req.reshape(W * C), [C] * W, [C] * W, dl.pull_group, async_op=True)     # block p = what rank p wants from me
+            if dl.comm_log is not None:
+                self.asked.wait()                     # (being timed: not left in flight)
+        self.done = None
+
+    def fetch(self):
+        """Serve and receive (call when the owned rows are final on the current stream)."""
+        from . import _native as nat
+        dl = self.dl
+        W, C, P, dev = dl.W, self.C, dl.bb.pe_dim, dl.device
+        lib = nat.load_library()
+        asked = self.asked.wait().contiguous()
+        rows_out = torch.empty((W * C, P), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_rows_by_id(nat.ptr(asked), W * C, nat.ptr(dl.table), P, nat.ptr(rows_out), 0, nat.current_stream()))
+        with dl._log("all_to_all pulled rows", W * C * P * 4):
+            rows_in = exchange_rows(rows_out, [C] * W, [C] * W, dl.pull_group, async_op=True).wait().contiguous()
+        req = self.req.reshape(W * C)
+        with torch.cuda.device(dev):
+            nat.check(lib.lstep_rows_by_id(nat.ptr(req), W * C, nat.ptr(dl.table), P, nat.ptr(rows_in), 1, nat.current_stream()))
+        if dl.table.is_cuda:
+            self.done = torch.cuda.Event()
+            self.done.record()
+        self._keep = (asked, rows_out, rows_in, req)
+        self.asked = None
+
+    def wait(self):
+        if self.done is not None:
+            torch.cuda.current_stream(self.dl.device).wait_event(self.done)
+
+
+class GraphedDistStep:
+    """One steady-state training iteration of ``DistributedLstep`` (device-driven form) -- FFT splice with its all-gather, this rank's slice
+    through gather / tail / predictor / loss, update_pe, the backward pass with its reduce-scatter and all-reduce, Adam, the ring tick --
+    captured ONCE as a HIP graph, RCCL collectives included (torch's NCCL process group records them into the capture; verified on this
+    torch / RCCL by tools/rccl_capture_probe.py), and replayed per batch: per step the host copies the batch (and, "pull", the look-ahead
+    batch) into fixed buffers and launches the graph -- like ``engine.GraphedTrainStep`` on one GPU."""
+
+    def __init__(self, dl: DistributedLstep, optimizer, batch: int):
+        dev = dl.device
+        self.dl, self.optimizer, self.B = dl, optimizer, int(batch)
+        i64 = lambda: torch.zeros(self.B, dtype=torch.int64, device=dev)  # noqa: E731
+        f64 = lambda: torch.zeros(self.B, dtype=torch.float64, device=dev)  # noqa: E731
+        self.cur = (i64(), i64(), f64(), i64(), i64())          # src, dst, ts, eid, neg
+        self.nxt = (i64(), i64(), f64(), i64())                 # src, dst, ts, neg of the look-ahead batch ("pull")
+        self.graph, self.out, self.replays, self.hyper = None, None, 0, None
+        self._ahead_key = None
+
+    def _hyper(self):
+        o = self.optimizer
+        return (o.lr, o.weight_decay, tuple(o.betas), o.eps)
+
+    def close(self):
+        from .model import drain_dead_graphs, retire_graph
+        if self.graph is not None:
+            retire_graph(self.graph)
+        self.graph, self.out = None, None
+        drain_dead_graphs()
+
+    def step(self, batch_idx, src, dst, ts, eid, neg_dst, lookahead):
+        dl = self.dl
+        pull = dl.form == "pull"
+        if pull:
+            # the rows of THIS gather were requested and fetched by the previous replay from its look-ahead buffers: valid only if that
+            # look-ahead named exactly this batch; otherwise fetch them now, launch by launch
+            fresh = self._ahead_key is not None and self._ahead_key.matches(src, dst, ts, neg_dst)
+            if not fresh:
+                pend = dl._take_pull(src, dst, ts, neg_dst)        # (fetched by a launch-by-launch iteration from ITS look-ahead)
+                (pend or dl._pull_now_dev((src, dst, neg_dst), ts)).wait()
+            if lookahead is None or len(lookahead) < 4:
+                lookahead = (src, dst, ts, neg_dst)          # (no look-ahead: the rows fetched for "the next batch" are simply not used)
+                self._ahead_key = None
+            else:
+                self._ahead_key = TensorsKey(lookahead[0], lookahead[1], lookahead[2], lookahead[3])
+            torch._foreach_copy_([self.nxt[0], self.nxt[1], self.nxt[3]], [lookahead[0], lookahead[1], lookahead[3]])
+            self.nxt[2].copy_(lookahead[2])
+        torch._foreach_copy_([self.cur[0], self.cur[1], self.cur[3], self.cur[4]], [src, dst, eid, neg_dst])
+        self.cur[2].copy_(ts)
+        dl.eng.__dict__.pop("_prefetched_group", None)
+        dl._pending_pull = None
+        if self.graph is not None and self.hyper != self._hyper():
+            self.close()
+        if self.graph is None:
+            self._capture(batch_idx)
+        else:
+            self.graph.replay()
+            self.replays += 1
+            dl._ring.replay_tick()
+        return self.out
+
+    def _capture(self, batch_idx):
+        from .model import _aux_stream, _no_gc, new_graph
+        dl = self.dl
+        eng, ring = dl.eng, dl._ring
+        torch.cuda.synchronize(dl.device)
+        ring._advanced = [None, None]
+        if ring.dev_start is None:
+            ring.position_on_device()
+        graph = new_graph(self)
+        self.hyper = self._hyper()
+        src, dst, ts, eid, neg = self.cur
+        ahead = (self.nxt[0], self.nxt[1], self.nxt[2], self.nxt[3]) if dl.form == "pull" else None
+        with _no_gc(), torch.cuda.graph(graph):
+            with eng.aux_streams():
+                self.out = dl._train_iteration_dev(self.optimizer, batch_idx, src, dst, ts, eid, neg, None, ahead)
+            main = torch.cuda.current_stream(dl.device)
+            if eng.use_aux:
+                main.wait_stream(_aux_stream(dl.device))
+            main.wait_stream(eng._update_stream)
+            if dl._pull_stream is not None and dl.form == "pull":
+                main.wait_stream(dl._pull_stream)
+        dl._pending_pull = None          # (the captured iteration's pull object belongs to the graph: replays fetch into the table directly)
+        self.graph = graph
+        graph.replay()

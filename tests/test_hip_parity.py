@@ -474,7 +474,10 @@ def test_padding_rows_sum_and_finish_match_float64(hip, n):
 def ws_used(nat, n_ent, P, D):
     chunk = 16 if n_ent <= 65536 else 64          # segment.hip: short lists are cut finer (a chunk is a wave's dependent rounds of latency)
     chunks = (n_ent + chunk - 1) // chunk
-    return int(nat.load_library().lstep_segment_rows_sum_workspace(n_ent, P, D)) == chunks * 2 * (P + D) * 4 + (chunks * 4 + 15) // 16 * 16
+    up16 = lambda b: (b + 15) // 16 * 16  # noqa: E731
+    groups = chunks // 16 if chunks >= 64 else 0      # group partials of the two-level join (segment.hip: kJoinGroup, kJoinMinChunks)
+    want = up16(chunks * 2 * (P + D) * 4) + up16(chunks * 4) + up16(groups * (P + D) * 4) + up16(groups * 4)
+    return int(nat.load_library().lstep_segment_rows_sum_workspace(n_ent, P, D)) == want
 
 
 def test_large_tables_64bit_addressing_vs_oracle(hip):

@@ -139,7 +139,8 @@ def _gpu_worker(rank, world, port, q, backend="gloo", ahead=False):
             return torch.cat([cat[:, 0, :].reshape(-1), cat[:, 1, :].reshape(-1)]).cpu().numpy()
 
         pull = dl.form == "pull"
-        assert dl.form == os.environ.get("LSTEP_PHASE2", "auto").replace("auto", "replicate" if world <= 4 else "pull")
+        assert dl.form == os.environ.get("LSTEP_PHASE2", "auto").replace("auto", "replicate")
+        assert dl.device_driven == (dl.form != "allgather" and os.environ.get("LSTEP_DIST_HOST_COUNTS") != "1")
 
         poisoned = [0]
 
@@ -192,9 +193,10 @@ def _gpu_worker(rank, world, port, q, backend="gloo", ahead=False):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,phase2,ahead", [(2, "allgather", False), (2, "replicate", False), (4, "auto", False), (2, "pull", False), (2, "pull", True),
-                                                (4, "pull", True)])
-def test_distributed_engine_reproduces_golden_trace_ranks_on_one_gpu(monkeypatch, world, phase2, ahead):
+@pytest.mark.parametrize("world,phase2,ahead,host_counts", [(2, "allgather", False, False), (2, "replicate", False, False), (4, "auto", False, False),
+                                                            (2, "pull", False, False), (2, "pull", True, False), (4, "pull", True, False),
+                                                            (2, "replicate", False, True), (2, "pull", True, True)])
+def test_distributed_engine_reproduces_golden_trace_ranks_on_one_gpu(monkeypatch, world, phase2, ahead, host_counts):
     """W ranks share the one GPU of the test box (gloo staging the device tensors through the host) and must reproduce the REFERENCE's
     golden training + evaluation trace: owner-sharded history ring and FFT filter, batch slices through the gather stage, and the three
     forms of update_pe (LSTEP_PHASE2) -- incl. the owner-sharded PE table ("pull": owner-computes update, all-gather of the batch nodes'
@@ -203,6 +205,8 @@ def test_distributed_engine_reproduces_golden_trace_ranks_on_one_gpu(monkeypatch
     assert torch.cuda.is_available()
     monkeypatch.setenv("LSTEP_PHASE2", phase2)      # (inherited by the spawned ranks)
     monkeypatch.setenv("LSTEP_PULL_POISON", "1")    # "pull": rows a rank does not own are NaN unless a collective delivered them
+    if host_counts:                                 # the host-sized iterations of rounds 2-3 (A/B switch; what "allgather" always takes)
+        monkeypatch.setenv("LSTEP_DIST_HOST_COUNTS", "1")
     _run(_gpu_worker, world, "gloo", ahead)
 
 
@@ -218,6 +222,108 @@ def test_distributed_engine_on_rccl_world_size_1_reproduces_golden_trace(monkeyp
     monkeypatch.setenv("LSTEP_PHASE2", phase2)
     monkeypatch.setenv("LSTEP_PULL_POISON", "1")
     _run(_gpu_worker, 1, "nccl", phase2 == "pull")
+
+
+def _long_worker(rank, world, port, q, backend, expect_replays):
+    """tests/golden/traces_long.npz (16 consecutive training batches the REFERENCE ran) through ``DistributedLstep`` with the one-launch
+    Adam: the device-driven iteration (fixed-capacity collectives, counts on the device) and -- over RCCL -- its whole-step HIP graph
+    with the collectives captured inside."""
+    try:
+        torch.cuda.set_device(0)
+        _init(rank, world, port, backend)
+        dev = "cuda:0"
+        from helpers import LONG_BATCHES, check_long_trace_gradients, long_trace_batches
+        from lstep_amd.engine import EdgeStream, LstepEngine
+        from lstep_amd.optim import FusedAdam
+        from lstep_amd.parallel import DistributedLstep, all_gather_var
+        from lstep_amd.sampler import NeighborSampler
+        from lstep_amd.workload import build_hip_model
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "traces_long.npz"))
+        g, node_raw, edge_raw, pe0 = trace_inputs()
+        sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=g["num_nodes"], device=dev)
+        model = build_hip_model(node_raw, edge_raw, sampler, TRACE_K, TRACE_T, synth.make_state_dict(TRACE_K, TRACE_T), dev)
+        model.train()
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+        dl = DistributedLstep(LstepEngine(model[0], model[1], TRACE_K, TRACE_G, make_ring=False), opt)
+        assert dl.device_driven and dl.use_step_graph == (backend == "nccl")
+        stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], dev)
+        init = torch.from_numpy(pe0.copy()).to(dev)
+        tol = dict(rtol=0, atol=5e-5)
+        half = TRACE_B // world
+        pull = dl.form == "pull"
+
+        def global_predicts(local):
+            cat, _ = all_gather_var(local.reshape(2, half))
+            cat = cat.reshape(world, 2, half)
+            return torch.cat([cat[:, 0, :].reshape(-1), cat[:, 1, :].reshape(-1)]).cpu().numpy()
+
+        batches = long_trace_batches(g)
+        negs = [torch.from_numpy(b_[4]).to(dev) for b_ in batches]
+        worst = {"snapshot": 0.0, "loss": 0.0, "predicts": 0.0, "gradient": 0.0}
+        for b in range(LONG_BATCHES):
+            lo = TRACE_START + b * TRACE_B
+            nxt = None
+            if b + 1 < LONG_BATCHES and b != 9:           # (one step without a look-ahead: the next replay must fetch its rows itself)
+                s2, d2, t2, _ = stream.batch(lo + TRACE_B, lo + 2 * TRACE_B)
+                nxt = (s2, d2, t2, negs[b + 1])
+            res = dl.train_iteration(opt, b, *stream.batch(lo, lo + TRACE_B), negs[b], initial_pe=init, lookahead=nxt)
+            want = z[f"b{b}/snapshot"]
+            table = (dl.full_table() if pull else dl.table).cpu().numpy()
+            worst["snapshot"] = max(worst["snapshot"], float(np.abs(table - want).max()))
+            np.testing.assert_allclose(table, want, err_msg=f"b{b} table", **tol)
+            np.testing.assert_allclose(dl.ring.last().cpu().numpy(), want[rank::world], **tol)
+            if res is None:
+                continue
+            got = [float(res["lp_loss"]), float(res["pe_loss"]), float(res["loss"])]
+            np.testing.assert_allclose(got, z[f"b{b}/losses"], rtol=0, atol=2e-5, err_msg=f"b{b} losses")
+            pr = global_predicts(res["predicts"])
+            worst["loss"] = max(worst["loss"], float(np.abs(np.asarray(got) - z[f"b{b}/losses"]).max()))
+            worst["predicts"] = max(worst["predicts"], float(np.abs(pr - z[f"b{b}/predicts"]).max()))
+            np.testing.assert_allclose(pr, z[f"b{b}/predicts"], err_msg=f"b{b} predicts", **tol)
+            d, _ = check_long_trace_gradients(model, z, b, atol=2e-6, digest_atol=2e-4)
+            worst["gradient"] = max(worst["gradient"], d)
+        np.testing.assert_allclose(dl.ring.as_reference_tensor().cpu().numpy(), z["final_history"][rank::world], **tol)
+        dl.check_capacity(wait=True)
+        gs = dl._graphed.get(TRACE_B)
+        if expect_replays:
+            assert gs is not None and gs.graph is not None and gs.replays == LONG_BATCHES - 7, (gs and gs.replays)
+            assert int(dl.ring.dev_start.item()) == dl.ring.start
+        else:
+            assert gs is None
+        if rank == 0:
+            print(f"[distributed long trace, {backend} x{world}, {dl.form}, {'graph replay' if expect_replays else 'launch by launch'}] worst: "
+                  + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+        dl.close()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("phase2", ["replicate", "pull"])
+def test_distributed_graph_replay_reproduces_long_golden_trace_rccl(monkeypatch, phase2):
+    """the multi-GPU iteration is device-driven and replayed as ONE HIP graph with its RCCL collectives captured inside
+    (world size 1 with LSTEP_FORCE_COLLECTIVES=1, the only RCCL set-up a one-GPU box allows): batches 0-3 fill the T = 4 window, 4-5
+    prime, 6 is captured, 7-15 are replays -- every step's table, losses, probabilities and parameter gradients against what the
+    REFERENCE produced (tests/golden/traces_long.npz)."""
+    assert torch.cuda.is_available()
+    monkeypatch.setenv("LSTEP_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("LSTEP_PHASE2", phase2)
+    monkeypatch.setenv("LSTEP_PULL_POISON", "1")
+    _run(_long_worker, 1, "nccl", True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,phase2", [(2, "replicate"), (2, "pull"), (4, "pull")])
+def test_distributed_device_driven_long_golden_trace_ranks_on_one_gpu(monkeypatch, world, phase2):
+    """The same 16-batch reference trace on 2 / 4 ranks sharing the test box's GPU (gloo): fixed-capacity blocks with per-owner counts on the
+    device, the gradient buffer laid out by (owner, slot), poisoned caches in the owner-sharded form."""
+    assert torch.cuda.is_available()
+    monkeypatch.setenv("LSTEP_PHASE2", phase2)
+    monkeypatch.setenv("LSTEP_PULL_POISON", "1")
+    _run(_long_worker, world, "gloo", False)
 
 
 def _hub_worker(rank, world, port, q):
