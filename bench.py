@@ -75,12 +75,25 @@ def cpu_model() -> str:
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(seconds_budget: float = 25.0):
-    """Oracle train iterations on a bounded sample: same degree structure (E/N = 20), K, time_gap, T; smaller N and batch."""
+def cpu_baseline(workload: str = "synth-1M-20M", time_gap: int = 2000, batch: int = None, seconds_budget: float = 25.0):
+    """Oracle train iterations (the reference's op sequence) on this box's host cores.
+
+    The reference's own batch sizes fit the CPU oracle whole, so the enron / wikipedia / reddit lines are timed on THE SAME configuration the
+    GPU ran (nodes, edges, batch, K, time_gap, T; same synthetic generator) -- a like-for-like ratio.  The 1 M- and 4 M-node workloads do
+    not (the oracle's history tensor alone is 69 / 275 GB and one iteration takes minutes): they keep the bounded sample of earlier
+    rounds -- same degree structure (E / N = 20), K, time_gap, T; 50 k nodes, batch 512 -- and the line says so (smaller N favours the CPU:
+    its per-batch O(N T P) history cat shrinks, so the GPU / CPU ratio read from it is conservative)."""
     from lstep_amd import protocol, synth
+    from lstep_amd.workload import WORKLOADS
     from oracle.lstep_oracle import OracleNeighborSampler, build_oracle_model  # checker / baseline only
 
-    N, E, B, K, G, T = 50_000, 1_000_000, 512, 20, 2000, 100
+    n_w, e_w, b_w, k_w = WORKLOADS[workload]
+    same = n_w <= 20_000
+    if same:
+        N, E, B, K = n_w, e_w, (batch or b_w), k_w
+    else:
+        N, E, B, K = 50_000, 1_000_000, 512, k_w
+    G, T = time_gap, 100
     avail = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
@@ -99,7 +112,7 @@ def cpu_baseline(seconds_budget: float = 25.0):
     hist = 0.1 * torch.randn(N + 1, T, synth.PE_DIM, generator=torch.Generator().manual_seed(0))
     state = protocol.ProtocolState(history=hist)
     start = E // 2
-    times = []
+    times, first = [], None
     it = 0
     t_begin = time.perf_counter()
     while True:
@@ -110,15 +123,53 @@ def cpu_baseline(seconds_budget: float = 25.0):
         dt = time.perf_counter() - t0
         if it > 0:  # first iteration = warm-up
             times.append(dt)
+        else:
+            first = dt
         it += 1
-        if len(times) >= 2 and (time.perf_counter() - t_begin) > seconds_budget:
+        spent = time.perf_counter() - t_begin
+        if (len(times) >= 2 and spent > seconds_budget) or len(times) >= 8:
             break
-        if len(times) >= 8:
+        if len(times) >= 1 and spent + dt > 2 * seconds_budget:      # (Reddit shape: ~10 s per iteration -- one timed iteration after the warm-up)
             break
     per_iter = float(np.mean(times))
+    what = (f"the SAME configuration as the GPU line ({N} nodes / {E} edges, batch {B}, K={K}, time_gap={G}, T={T} history full)" if same else
+            f"a bounded SAMPLE of the workload: synthetic {N} nodes / {E} edges (same E/N as the GPU workload), batch {B}, K={K}, time_gap={G}, T={T} history full")
     return {"value": B / per_iter, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "host_cores_visible": avail,
-            "sample": f"oracle (reference op sequence) train iteration, synthetic {N} nodes / {E} edges (same E/N as the GPU workload), "
-                      f"batch {B}, K={K}, time_gap={G}, T={T} history full; {len(times)} timed iterations after 1 warm-up, {per_iter * 1e3:.0f} ms each"}
+            "same_config_as_gpu_line": bool(same),
+            "sample": f"oracle (reference op sequence) train iteration on {what}; {len(times)} timed iteration(s) after 1 warm-up ({first * 1e3:.0f} ms), "
+                      f"{per_iter * 1e3:.0f} ms each"}
+
+
+# Where the gather kernel's rows come from, by table size (MI355X_MICROARCH.md: L2 4 MiB per XCD / 32 MiB aggregate at ~34.5 TB/s; 256 MiB Infinity
+# Cache, random-row gathers from a 38 MB table at 8.6 TB/s chip-wide; HBM 8 TB/s spec).  A table of at most 4 MiB is L2-resident on every
+# XCD; one that, together with the launch's other tables, fits ~200 MiB stays in the Infinity Cache between launches; anything else is HBM.
+LEVEL_PEAK_GBS = {"l2": 34500.0, "infinity_cache": 8600.0, "hbm": HBM_PEAK_GBS}
+
+
+def table_level(nbytes: float) -> str:
+    return "l2" if nbytes <= 4 * 2 ** 20 else ("infinity_cache" if nbytes <= 200 * 2 ** 20 else "hbm")
+
+
+def gather_roofline_bound(count: torch.Tensor, K: int, G: int, num_nodes: int, num_edges: int, row_bytes: int = 688):
+    """(bound, blended peak GB/s, per-level byte split) of one gather launch: SURVEY.md 8(d)'s algorithmic bytes attributed to the table they
+    are read from -- node rows (v + 1 per row) from node_raw, edge rows (k) from edge_raw, PE rows (k + 1) from the PE table, the output
+    row and the CSR slices streamed once (HBM) -- each priced at the peak of the level that table lives in.  The blended peak is total
+    bytes / sum(bytes_level / peak_level): the rate at which a launch that ran every level at its peak would move the algorithmic bytes;
+    `bound` names the level with the largest share of that time.  For the 1 M-node workloads every table is HBM-sized: bound = hbm, peak = 8 TB/s."""
+    c = count.to(torch.int64)
+    k = c.clamp(max=K).sum().item()
+    v = c.clamp(max=G).sum().item()
+    rows = c.numel()
+    node_tab, edge_tab = (num_nodes + 1) * row_bytes, (num_edges + 1) * row_bytes
+    split = {"l2": 0.0, "infinity_cache": 0.0, "hbm": 0.0}
+    split[table_level(node_tab)] += row_bytes * (v + rows)             # neighbours' node rows + the row's own
+    split[table_level(node_tab)] += row_bytes * (k + rows)             # PE table: same shape as node_raw
+    split[table_level(edge_tab)] += row_bytes * k
+    split["hbm"] += row_bytes * rows + 24 * k + 8 * v                  # output row, CSR slices
+    total = sum(split.values())
+    t = {lv: split[lv] / LEVEL_PEAK_GBS[lv] for lv in split}
+    bound = max(t, key=t.get)
+    return bound, total / sum(t.values()), {lv: split[lv] for lv in split}
 
 
 def default_workload(gpus: int) -> str:
@@ -179,6 +230,9 @@ def main():
                          "off: every launch issued from Python")
     ap.add_argument("--mode", choices=["train", "eval"], default="train", help="eval = evaluate_model_utils.py:38-142 iteration (4x combine, no backward)")
     ap.add_argument("--zipf", type=float, default=None, help="power-law endpoint popularity exponent (hub-skew variant)")
+    ap.add_argument("--sampler", choices=["recent", "uniform", "time_interval_aware"], default="recent",
+                    help="neighbour sampling strategy (utils/utils.py:175-208).  The RNG-defined ones are drawn on the host in the reference's order "
+                         "(native replay of numpy's generator) and fed to the explicit-neighbourhood kernels: time_gap draws per row and call")
     ap.add_argument("--history", choices=["evolved", "random"], default="evolved",
                     help="state of the T-snapshot PE history when the run starts: evolved = built by the algorithm itself over the T batches "
                          "before the first one (snapshots are clones of their predecessor plus the rows the batch wrote, as in the reference); "
@@ -218,7 +272,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0, sharded=use_dist, zipf=args.zipf)
+    wl = build_workload(args.workload, dev, time_gap=args.time_gap, batch=args.batch, seed=0, sharded=use_dist, zipf=args.zipf, sampler=args.sampler)
     eng, model = wl.engine, wl.model
     model.train()
     # Adam, lr 1e-4 (reference defaults, utils/load_configs.py:45,48) through the single-kernel implementation
@@ -360,17 +414,26 @@ def main():
         # HBM traffic per launch of the gather kernel: not measurable from inside the process; taken from the committed PMC
         # passes of this same command (profiles/*pmc_traffic.json, made by tools/pmc_summary.py), default workload only
         traffic, traffic_src = None, None
-        if args.workload == "synth-1M-20M" and args.batch is None and args.time_gap == 2000 and world == 1:
+        if args.batch is None and args.time_gap == 2000 and world == 1 and not args.zipf and args.mode == "train" and args.sampler == "recent":
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+            others = [w for w in ("enron", "wikipedia", "reddit", "tiny", "synth-4M-100M") if w != args.workload]
+            pat = "*pmc_traffic.json" if args.workload == "synth-1M-20M" else f"*{args.workload}*pmc_traffic.json"
+            cands = sorted(c for c in glob.glob(os.path.join(ROOT, "profiles", pat)) if not any(o in os.path.basename(c) for o in others))
             if cands:
                 table = json.load(open(cands[-1]))
                 rec = table.get(GATHER_KERNEL) or table.get("lstep::gather_aggregate_fwd_kernel<true, true>")   # (name before the explicit-list variant)
                 if rec:
                     traffic, traffic_src = rec["traffic_bytes"], os.path.relpath(cands[-1], ROOT)
         ms, bytes_per_launch = pair_gather_launches(sink, wl.K, wl.G)
+        if args.sampler != "recent":
+            # explicit neighbourhoods (sampling with replacement): every row with history fills all K / time_gap slots; the per-row count
+            # the kernel reports is K.  Upper bound of the stage's algorithmic bytes: every slot of every row read.
+            rows = int(sink[0][2].numel())
+            bytes_per_launch = [float(rows * (688 * (2 * wl.K + wl.G + 3) + 24 * wl.K + 8 * wl.G))] * len(ms)
         avg_ms = float(np.mean(ms))
         achieved = float(np.mean(bytes_per_launch)) / (avg_ms * 1e-3) / 1e9
+        bound, peak, split = gather_roofline_bound(sink[0][2] if args.sampler == "recent" else torch.full_like(sink[0][2], wl.G), wl.K, wl.G,
+                                                   wl.num_nodes, wl.num_edges)
         line = {
             "metric": "processed edges/sec (L-STEP fwd+bwd)" if args.mode == "train" else "processed edges/sec (L-STEP eval iteration, no bwd)",
             "value": B * world * args.steps / elapsed,
@@ -398,15 +461,16 @@ def main():
                                                  "rows the next gather reads (requested one step ahead)"}[getattr(runner, "form", "replicate")])
                                        if use_dist else "single GPU"),
                        "update_form": getattr(runner, "form", None)},
-            "roofline": {"bound": "hbm", "kernel": GATHER_KERNEL if not use_dist else "lstep::gather_aggregate_fwd_kernel<true, false, false> + <false, true, false> (two launches per step)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": bound, "kernel": ("lstep::gather_aggregate_fwd_kernel<.., true> x 2 (explicit neighbour lists: edge + node channels, PE channel)" if args.sampler != "recent" else GATHER_KERNEL) if not use_dist else "lstep::gather_aggregate_fwd_kernel<true, false, false> + <false, true, false> (two launches per step)", "achieved": achieved, "peak": peak,
+                         "unit": "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "bytes_by_level": split,
                          "launch_ms": avg_ms, "launch_timing": timing_note, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
                          "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
         }
         if comm is not None:
             line["comm"] = comm
-        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and not args.zipf:
-            line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train" and not args.zipf and args.sampler == "recent":
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.time_gap, args.batch)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 32
+#define LSTEP_ABI_VERSION 33
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -479,6 +479,23 @@ int lstep_owner_partition(const int64_t* ids, int64_t capacity, const int32_t* n
 int lstep_scatter_owner_rows(const float* rows, int32_t ld_rows, const int64_t* ids_by_owner, const int32_t* counts, int32_t world,
                              int64_t block_slots, float* table, int32_t width, int32_t* slot_of, void* stream);
 int lstep_rows_by_id(const int32_t* ids, int64_t n, float* table, int32_t width, float* buf, int32_t direction, void* stream);
+/* HOST functions (plain C++, no kernel; all pointers are host memory): the RNG-defined sampling strategies 'uniform' /
+ * 'time_interval_aware' of NeighborSampler.get_historical_neighbors (utils/utils.py:175-198).  The reference draws
+ * `random_state.choice(a=cnt, size=K, p=p)` once per row, in row order, from numpy's legacy MT19937 RandomState, so the result is defined
+ * by that generator's stream: lstep_sample_random_host replays the two paths of RandomState.choice bit for bit (p == NULL: randint's masked
+ * rejection on 32-bit outputs, nothing consumed when cnt == 1; p: float64 cumsum / last, two outputs per uniform double,
+ * searchsorted side='right') over the time-sorted CSR (indptr int64 [num_rows + 1], nbr / eid int64, ts float64) for rows
+ * r = 0 .. m - 1 (node_ids[r], times[r]; cnt = entries strictly before times[r], utils/utils.py:140) and writes the K picked slots of every
+ * row with history into out_* [m, K] (int64, int64, float32(ts)) in DRAW order; rows without history are left untouched and consume
+ * nothing.  mt_key [624] / mt_pos are numpy's RandomState.get_state()[1:3], advanced in place.  p_values / p_offsets [m + 1]: row r's
+ * float32 probabilities (what torch.softmax produced, utils/utils.py:182), p_offsets[r + 1] - p_offsets[r] must equal cnt.
+ * The caller re-sorts each row by sampled time with numpy (utils/utils.py:192-196: an unstable argsort whose tie order is numpy's).
+ * lstep_count_before_host: cnt of every row (the sizes of the probability slices). */
+int lstep_count_before_host(const int64_t* indptr, const double* ts, int64_t num_rows, const int64_t* node_ids, const double* times, int64_t m,
+                            int64_t* out_count);
+int lstep_sample_random_host(const int64_t* indptr, const int64_t* nbr, const int64_t* eid, const double* ts, int64_t num_rows,
+                             const int64_t* node_ids, const double* times, int64_t m, int32_t num_neighbors, const float* p_values,
+                             const int64_t* p_offsets, uint32_t* mt_key, int32_t* mt_pos, int64_t* out_nbr, int64_t* out_eid, float* out_t);
 int lstep_update_entries_p1(const int32_t* order, int64_t num_entries, const int64_t* src, const int64_t* dst, const double* times,
                             const float* now32, int64_t batch, int32_t* ent_row, float* ent_dt, void* stream);
 int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank, int32_t* keys, void* stream);

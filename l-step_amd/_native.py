@@ -16,11 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
 SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip", "update.hip", "adam.hip",
-           "compose.hip", "shard.hip"]
+           "compose.hip", "shard.hip", "rng_sampler.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 32
+ABI_VERSION = 33
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -146,6 +146,8 @@ SIGNATURES = {
     "lstep_owner_partition": (C.c_int, [_P, _I64, _P, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_scatter_owner_rows": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _P, _I32, _P, _P]),
     "lstep_rows_by_id": (C.c_int, [_P, _I64, _P, _I32, _P, _I32, _P]),
+    "lstep_count_before_host": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _P]),
+    "lstep_sample_random_host": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "lstep_batch_prepare": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_padding_rows_finish": (C.c_int, [_P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_add_overflow": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _I32, _P]),

@@ -19,7 +19,13 @@ __device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast
 // tanh on the hardware exp2 / rcp: 1 - 2 / (1 + e^{2|x|}) for |x| >= 0.25 (both 1 ulp: absolute error <= 1.5e-7, +-1 at the ends without
 // special cases), the odd Taylor polynomial through x^7 below (truncation <= 8e-8 at 0.25).  Branch-free, 16 instructions; tanhf is ~45 with
 // two divergent branches, and update_pe evaluates 50 M of them per step at 1 M nodes -- on waves that hold a whole SIMD to themselves.
+// LSTEP_EXACT_TANH=1 (an A/B BUILD, `lstep_amd._native.build_library(defines=["LSTEP_EXACT_TANH=1"], lib_path=...)`, loaded through LSTEP_LIB):
+// libm's tanhf in every place the fast form is used -- tools/tanh_drift.py runs long training traces on both builds and reports how far the
+// PE tables drift apart (the fast form's 1.5e-7 per evaluation compounds through `pe += tanh(...)` across steps).
 __device__ __forceinline__ float tanh_fast(float x) {
+#ifdef LSTEP_EXACT_TANH
+    return tanhf(x);
+#endif
     const float ax = fabsf(x), x2 = x * x;
     const float t = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);            // e^{2|x|}
     const float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + t), x);

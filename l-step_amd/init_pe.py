@@ -19,7 +19,9 @@ leaves N - O(B) isolated nodes, i.e. one eigenvalue of multiplicity ~N, and ARPA
 depends on its random start vector -- there the output is not a function of the input; the property tests (eigen-equation, orthonormal
 columns, eigenvalue order) cover that case.
 
-Host code (scipy), like the reference: this runs once before the first batch, on <= 2 B edges.
+Host code (scipy), like the reference: this runs once before the first batch, on <= 2 B edges.  ``random_walk_pe_device`` /
+``laplacian_pe_device`` compute the same encodings on the GPU (sparse products / a dense float64 ``eigh``) for callers that keep the
+initial PE on the device; both are held to the same fixtures (``tests/test_hip_parity.py``).
 """
 from __future__ import annotations
 
@@ -80,6 +82,59 @@ def random_walk_pe(edge_index, num_nodes: int, walk_length: int) -> torch.Tensor
         out = out @ adj
         cols.append(out.diagonal())
     return torch.from_numpy(np.stack(cols, axis=-1).astype(np.float32))
+
+
+# ---- the same two encodings computed on the GPU (torch device ops: this is set-up in front of the hot path, not a kernel of it) ----------
+def random_walk_pe_device(edge_index, num_nodes: int, walk_length: int, device="cuda") -> torch.Tensor:
+    """``random_walk_pe`` on the device: the random-walk matrix as a sparse CSR tensor, ``walk_length - 1`` sparse x sparse products, the
+    diagonal of every power.  At the reference's input (<= 2 B edges of the first batch on N nodes) the powers stay sparse; the result is a
+    device tensor ``[num_nodes, walk_length]`` float32 that the engine's ``initial_pe`` can take without a host round trip."""
+    ei = edge_index.to(device=device, dtype=torch.int64) if isinstance(edge_index, torch.Tensor) else torch.as_tensor(np.asarray(edge_index), dtype=torch.int64, device=device)
+    row, col = ei[0], ei[1]
+    deg = torch.zeros(num_nodes, dtype=torch.float32, device=ei.device).index_add_(0, row, torch.ones_like(row, dtype=torch.float32)).clamp_(min=1.0)
+    adj = torch.sparse_coo_tensor(ei, 1.0 / deg[row], (num_nodes, num_nodes)).coalesce()
+
+    def diagonal(m):
+        m = m.coalesce()
+        idx, val = m.indices(), m.values()
+        on = idx[0] == idx[1]
+        return torch.zeros(num_nodes, dtype=torch.float32, device=ei.device).index_add_(0, idx[0][on], val[on])
+
+    out = adj
+    cols = [diagonal(out)]
+    for _ in range(walk_length - 1):
+        out = torch.sparse.mm(out, adj)
+        cols.append(diagonal(out))
+    return torch.stack(cols, dim=-1)
+
+
+def laplacian_pe_device(edge_index, num_nodes: int, k: int, generator: torch.Generator = None, device="cuda", dense_limit: int = 16384):
+    """``laplacian_pe`` with the eigen-decomposition on the device: the dense symmetric-normalised Laplacian (``num_nodes`` <= ``dense_limit``:
+    1 GB in float64 at 11 k nodes, the reference's real datasets) through ``torch.linalg.eigh`` in float64 -- ALL eigenpairs, of which
+    columns 1 .. k are kept, where ARPACK iterates for the k + 1 smallest.  Same definition, same sign convention (a random sign per
+    column from ``torch.randint``); larger graphs take the host path (``laplacian_pe``)."""
+    if num_nodes > dense_limit:
+        pe, ew = laplacian_pe(edge_index, num_nodes, k, generator)
+        return pe.to(device), ew.to(device)
+    if not 0 < k < num_nodes - 1:
+        raise ValueError("0 < k + 1 < num_nodes")
+    ei = edge_index.to(device=device, dtype=torch.int64) if isinstance(edge_index, torch.Tensor) else torch.as_tensor(np.asarray(edge_index), dtype=torch.int64, device=device)
+    row, col = ei[0], ei[1]
+    keep = row != col
+    row, col = row[keep], col[keep]
+    w = torch.ones(row.numel(), dtype=torch.float64, device=ei.device)
+    deg = torch.zeros(num_nodes, dtype=torch.float64, device=ei.device).index_add_(0, row, w)
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0.0
+    off = -dis[row] * w * dis[col]
+    lap = torch.eye(num_nodes, dtype=torch.float64, device=ei.device)
+    lap.index_put_((row, col), off, accumulate=True)
+    vals, vecs = torch.linalg.eigh(lap)           # ascending eigenvalues
+    pe = vecs[:, 1:k + 1].contiguous()
+    sign = -1 + 2 * torch.randint(0, 2, (k,), generator=generator)
+    pe = pe * sign.to(pe.device)
+    edge_weight = torch.cat([off.to(torch.float32), torch.ones(num_nodes, dtype=torch.float32, device=ei.device)])
+    return pe, edge_weight
 
 
 def first_batch_edge_index(src, dst) -> torch.Tensor:

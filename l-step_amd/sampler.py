@@ -78,13 +78,15 @@ class NeighborSampler:
 
     @classmethod
     def from_device_edges(cls, src: torch.Tensor, dst: torch.Tensor, eid: torch.Tensor, ts: torch.Tensor, num_nodes: int,
-                          seed: int = None):
+                          seed: int = None, sample_neighbor_strategy: str = "recent", time_scaling_factor: float = 0.0):
         """Build the CSR on the GPU from device-resident edge arrays (large graphs: the reference's Python loop over
         all edges, ``utils/utils.py:296-299``, takes minutes at 10^7-10^8 edges).  Same ordering rule as
         :func:`build_csr_arrays`: two stable sorts, by time then by owner, keep insertion order among ties."""
         nat.load_library()
         self = cls.__new__(cls)
-        self.sample_neighbor_strategy, self.time_scaling_factor, self.seed = "recent", 0.0, seed
+        if sample_neighbor_strategy not in ("recent", "uniform", "time_interval_aware"):
+            raise ValueError(f"Not implemented error for sample_neighbor_strategy {sample_neighbor_strategy}!")
+        self.sample_neighbor_strategy, self.time_scaling_factor, self.seed = sample_neighbor_strategy, time_scaling_factor, seed
         dev = src.device
         self.device = dev
         e = src.numel()
@@ -108,6 +110,11 @@ class NeighborSampler:
         self.num_rows, self.nnz = rows, int(2 * e)
         self._csr = nat.CsrStruct(self.indptr.data_ptr(), self.nbr.data_ptr(), self.eid.data_ptr(), self.ts.data_ptr(),
                                   self.num_rows, self.nnz)
+        if sample_neighbor_strategy != "recent":       # the RNG-defined strategies replay numpy's generator on the host, from a host copy of the CSR
+            self._host = (self.indptr.cpu().numpy(), self.nbr.cpu().numpy().astype(np.int64), self.eid.cpu().numpy().astype(np.int64),
+                          self.ts.cpu().numpy())
+            if seed is not None:
+                self.random_state = np.random.RandomState(seed)
         return self
 
     @property
@@ -146,8 +153,62 @@ class NeighborSampler:
         return p
 
     def _sample_random_host(self, node_ids, node_interact_times, num_neighbors):
-        """'uniform' / 'time_interval_aware' (utils/utils.py:175-198): per row, in row order, one RandomState.choice over the
-        interactions strictly before the query time, then a re-sort of the sampled slots by (float32) time."""
+        """'uniform' / 'time_interval_aware' (utils/utils.py:175-198): per row, in row order, one RandomState.choice over the interactions
+        strictly before the query time, then a re-sort of the sampled slots by (float32) time.  The draws are made by the native replay of
+        numpy's legacy generator (``lstep_sample_random_host``: the row loop, MT19937 and both paths of ``RandomState.choice`` in C++, on
+        numpy's OWN generator state, which is read before and stored back after the call -- Python-side and native draws share one
+        stream).  What stays in the interpreter is the re-sort of every sampled row by its float32 times (utils/utils.py:192-196): the reference
+        calls numpy's UNSTABLE ``argsort`` on each row, whose order among equal times is an implementation detail of numpy (introsort or a
+        SIMD sort, by version, length and CPU; a batched ``argsort(axis=1)`` runs a different code path, measured 4 x slower), so the same
+        1-D call is made per row -- ~3 us a row, against ~17 us for the whole reference loop body.
+        LSTEP_PY_RNG_SAMPLER=1: the interpreter loop of rounds 1-3 (A/B)."""
+        import os
+        if os.environ.get("LSTEP_PY_RNG_SAMPLER") == "1":
+            return self._sample_random_python(node_ids, node_interact_times, num_neighbors)
+        import ctypes
+        indptr, nbrs, eids, tss = self._host
+        rows = len(node_ids)
+        K = int(num_neighbors)
+        m = min(rows, len(node_interact_times))          # (the reference zips the two arrays: utils/utils.py:169)
+        out_n = np.zeros((rows, K), dtype=np.longlong)
+        out_e = np.zeros((rows, K), dtype=np.longlong)
+        out_t = np.zeros((rows, K), dtype=np.float32)
+        if m == 0:
+            return out_n, out_e, out_t
+        ids = np.ascontiguousarray(np.asarray(node_ids)[:m], dtype=np.int64)
+        ts = np.ascontiguousarray(np.asarray(node_interact_times)[:m], dtype=np.float64)
+        lib = nat.load_library()
+        vp = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+        p_vals = p_off = None
+        cnt = np.empty(m, dtype=np.int64)
+        nat.check(lib.lstep_count_before_host(vp(indptr), vp(tss), self.num_rows, vp(ids), vp(ts), m, vp(cnt)))
+        if self.sample_neighbor_strategy == "time_interval_aware":
+            # the probabilities are torch.softmax's float32 output (utils/utils.py:182), row by row as the reference computes them: their
+            # last bits depend on torch's vectorised exp, which only torch reproduces; everything behind them is replayed natively
+            parts = []
+            for r in np.nonzero(cnt)[0]:
+                lo, hi = indptr[ids[r]], indptr[ids[r] + 1]
+                parts.append(torch.softmax(torch.from_numpy(self._sampled_probabilities(tss[lo:hi])[:cnt[r]]).float(), dim=0).numpy())
+            p_vals = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros(0), dtype=np.float32)
+            p_off = np.zeros(m + 1, dtype=np.int64)
+            np.cumsum(cnt, out=p_off[1:])
+            if p_vals.size and (np.isnan(p_vals).any() or (p_vals < 0).any()):
+                raise ValueError("probabilities contain NaN" if np.isnan(p_vals).any() else "probabilities are not non-negative")
+        owner = np.random if self.seed is None else self.random_state
+        kind, key, pos, has_gauss, cached = owner.get_state()
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        cpos = ctypes.c_int32(int(pos))
+        nat.check(lib.lstep_sample_random_host(vp(indptr), vp(nbrs), vp(eids), vp(tss), self.num_rows, vp(ids), vp(ts), m, K,
+                                               None if p_vals is None else vp(p_vals), None if p_off is None else vp(p_off), vp(key),
+                                               ctypes.byref(cpos), vp(out_n), vp(out_e), vp(out_t)))
+        owner.set_state((kind, key, int(cpos.value), has_gauss, cached))
+        for r in np.nonzero(cnt)[0]:                      # (rows without history stay all zeros)
+            order = out_t[r].argsort()
+            out_n[r], out_e[r], out_t[r] = out_n[r][order], out_e[r][order], out_t[r][order]
+        return out_n, out_e, out_t
+
+    def _sample_random_python(self, node_ids, node_interact_times, num_neighbors):
+        """The same as an interpreter loop around ``RandomState.choice`` itself (rounds 1-3; kept as the A/B reference of the native replay)."""
         indptr, nbrs, eids, tss = self._host
         rows = len(node_ids)
         out_n = np.zeros((rows, num_neighbors), dtype=np.longlong)

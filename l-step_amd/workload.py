@@ -42,7 +42,8 @@ class Workload:
 
     def describe(self) -> str:
         return (f"synthetic temporal graph {self.num_nodes} nodes / {self.num_edges} edges / feat_dim={synth.FEAT_DIM}, "
-                f"batch_size={self.batch}, num_neighbors={self.K}, time_gap={self.G}, num_fft_batches={self.T}, recent sampling")
+                f"batch_size={self.batch}, num_neighbors={self.K}, time_gap={self.G}, num_fft_batches={self.T}, "
+                f"{getattr(self.sampler, 'sample_neighbor_strategy', 'recent')} sampling")
 
 
 def build_hip_model(node_raw, edge_raw, sampler, K, T, state_dict=None, device="cuda"):
@@ -58,7 +59,7 @@ def build_hip_model(node_raw, edge_raw, sampler, K, T, state_dict=None, device="
 
 
 def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int = 100, seed: int = 0, batch: int = None,
-                   sharded: bool = False, zipf: float = None) -> Workload:
+                   sharded: bool = False, zipf: float = None, sampler: str = "recent") -> Workload:
     """``sharded=True`` (multi-GPU): no full history ring is allocated; ``prefill_distributed`` fills the owner shards."""
     n, e, b, k = WORKLOADS[name]
     if batch is not None:
@@ -78,7 +79,9 @@ def build_workload(name: str, device, time_gap: int = 2000, num_fft_batches: int
     span = 1e6 * e / 1e5
     ts = torch.sort(torch.rand(e, dtype=torch.float64, generator=gen, device=dev) * span).values
     eid = torch.arange(1, e + 1, device=dev)
-    sampler = NeighborSampler.from_device_edges(src, dst, eid, ts, n)
+    strategy = sampler
+    sampler = NeighborSampler.from_device_edges(src, dst, eid, ts, n, seed=0 if strategy != "recent" else None, sample_neighbor_strategy=strategy,
+                                                time_scaling_factor=1e-6 if strategy == "time_interval_aware" else 0.0)
     node_raw = torch.randn((n + 1, synth.FEAT_DIM), generator=gen, device=dev)
     node_raw[0] = 0
     edge_raw = torch.randn((e + 1, synth.FEAT_DIM), generator=gen, device=dev)

@@ -1745,6 +1745,26 @@ def test_captured_graphs_have_an_explicit_lifetime(hip):
     assert M.drain_dead_graphs() == 3 and M.live_graph_count() == base
 
 
+def test_initial_pe_on_the_device_golden(hip, golden):
+    """the initial positional encodings (utils/PositionalEncoding.py:42-62,69-91, called once at
+    train_LSTEP_link_prediction.py:168-189) computed on the GPU -- sparse powers of the random-walk matrix, a dense float64 ``eigh`` of the
+    normalised Laplacian -- against what the reference file produced (tests/golden/init_pe.npz): RWPE entry for entry, the LapPE columns up
+    to their random sign, ``edge_weight`` entry for entry."""
+    from lstep_amd import init_pe
+    z = golden("init_pe")
+    ei, n = z["edge_index"], 40
+    k, walk = z["lappe_abs"].shape[1], z["rwpe"].shape[1]
+    rw = init_pe.random_walk_pe_device(ei, n, walk, device=DEV)
+    assert rw.is_cuda and rw.dtype == torch.float32 and tuple(rw.shape) == (n, walk)
+    np.testing.assert_allclose(rw.cpu().numpy(), z["rwpe"], rtol=0, atol=1e-6)
+    pe, ew = init_pe.laplacian_pe_device(ei, n, k, generator=torch.Generator().manual_seed(1), device=DEV)
+    assert pe.is_cuda and pe.dtype == torch.float64 and tuple(pe.shape) == (n, k)
+    np.testing.assert_allclose(np.abs(pe.cpu().numpy()), z["lappe_abs"], rtol=0, atol=5e-6)      # (the fixture is ARPACK's answer: 1e-6 from a dense solver's)
+    np.testing.assert_allclose(ew.cpu().numpy(), z["lappe_edge_weight"], rtol=0, atol=1e-6)
+    host, _ = init_pe.laplacian_pe(ei, n, k, generator=torch.Generator().manual_seed(1))
+    np.testing.assert_allclose(np.abs(pe.cpu().numpy()), np.abs(host.numpy()), rtol=0, atol=5e-6)
+
+
 def test_weighted_sum_ablation_golden(hip, golden):
     """`--ablation weighted_sum` (models/LSTEP.py:190-206) inside the gather kernel's node channel, 'recent' sampling, tied neighbour
     times included (scatter_mean's float32 sum / count is emulated per run of equal times): HIP == reference."""

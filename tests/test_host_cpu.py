@@ -38,7 +38,7 @@ def test_abi_exports_every_declared_symbol(lib):
         assert hasattr(raw, n), f"{n} declared in include/lstep_hip.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes prototype"
     assert sorted(nat.SIGNATURES) == names
-    assert lib.lstep_abi_version() == nat.ABI_VERSION == 32
+    assert lib.lstep_abi_version() == nat.ABI_VERSION == 33
 
 
 def test_abi_argument_validation_without_gpu(lib):
@@ -130,6 +130,36 @@ def test_rng_defined_sampling_replays_the_reference(golden, strategy, tsf):
             np.testing.assert_array_equal(nt.view(np.uint32), z[f"{strategy}/call{call}/k{k}/nt"].view(np.uint32))
     s.reset_random_state()
     np.testing.assert_array_equal(s.get_historical_neighbors(z["ids"], z["ts"], 3)[0], z[f"{strategy}/reset/k3/nbr"])
+
+
+@pytest.mark.parametrize("strategy,tsf", [("uniform", 0.0), ("time_interval_aware", 1e-3), ("time_interval_aware", 0.0)])
+@pytest.mark.parametrize("seed", [7, None])
+def test_native_rng_replay_equals_the_numpy_loop(monkeypatch, strategy, tsf, seed):
+    """``lstep_sample_random_host`` (C++ replay of numpy's legacy ``RandomState.choice``: MT19937, randint's masked rejection, the cdf path)
+    against the interpreter loop around numpy's own ``choice`` (LSTEP_PY_RNG_SAMPLER=1, rounds 1-3) -- every sampled id / edge / float32 time
+    identical and the generator left in the SAME state (the next numpy draw agrees) -- for K = 1 (a one-entry history consumes nothing) to
+    2000 (time_gap), tied timestamps, rows without history, M != M' and the module-level generator (seed None, utils/utils.py:184)."""
+    from lstep_amd.sampler import NeighborSampler
+    for gkw in (dict(num_nodes=50, num_edges=3000, seed=3), dict(num_nodes=30, num_edges=20000, seed=4, time_span=500.0, tie_quantum=5.0)):
+        g = synth.make_temporal_graph(**gkw)
+        mk = lambda: NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], sample_neighbor_strategy=strategy, time_scaling_factor=tsf, seed=seed,  # noqa: E731
+                                     device="cpu")
+        a, b = mk(), mk()
+        rng = np.random.RandomState(1)
+        for K in (1, 5, 20, 64, 2000):
+            n = 200 if K < 2000 else 24
+            ids = rng.randint(0, g["num_nodes"] + 1, n)
+            ts = rng.uniform(g["ts"].min() - 1, g["ts"].max() + 1, n if K != 5 else n - 40)
+            res, after = [], []
+            for smp, py in ((a, "1"), (b, "0")):
+                monkeypatch.setenv("LSTEP_PY_RNG_SAMPLER", py)
+                if seed is None:
+                    np.random.seed(11)
+                res.append(smp.get_historical_neighbors(ids, ts, K))
+                after.append((np.random if seed is None else smp.random_state).randint(0, 1 << 30))
+            for x, y in zip(*res):
+                np.testing.assert_array_equal(x, y)
+            assert after[0] == after[1], "the generator state diverged"
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -317,3 +347,15 @@ def test_initial_positional_encodings_match_the_reference(golden):
     assert pe.dtype == torch.float64 and tuple(pe.shape) == (n, k)
     np.testing.assert_allclose(np.abs(pe.numpy()), z["lappe_abs"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(ew.numpy(), z["lappe_edge_weight"], rtol=0, atol=1e-6)
+    # A SECOND, independent statement of what the fixture's Laplacian must be (half of LapPE's arithmetic sat in the builder-written
+    # get_laplacian shim): the textbook I - D^-1/2 A D^-1/2 assembled densely with numpy from the raw edge list -- A counts parallel edges,
+    # self-loops dropped, isolated nodes keep a lone 1 on the diagonal -- and its eigenvectors from a dense symmetric solver instead of ARPACK.
+    a = np.zeros((n, n))
+    np.add.at(a, (ei[0][ei[0] != ei[1]], ei[1][ei[0] != ei[1]]), 1.0)
+    d = a.sum(1)
+    dis = np.where(d > 0, 1.0 / np.sqrt(np.maximum(d, 1e-300)), 0.0)
+    textbook = np.eye(n) - dis[:, None] * a * dis[None, :]
+    np.testing.assert_allclose(z["laplacian"], textbook, rtol=0, atol=1e-6)          # what the reference file produced through the shim
+    evals, evecs = np.linalg.eigh(textbook)
+    np.testing.assert_allclose(np.abs(evecs[:, 1:k + 1]), z["lappe_abs"], rtol=0, atol=1e-6)
+    assert np.all(np.diff(evals[:k + 2]) > 1e-3)

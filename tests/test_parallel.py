@@ -466,7 +466,9 @@ def test_bench_single_gpu_line_keeps_the_contract():
     roof = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "algorithmic_bytes_per_launch"):
         assert key in roof, key
-    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and roof["launch_ms"] > 0
+    # (the 2000-node "tiny" tables are cache-resident: the bound is the cache level its rows come from, bench.gather_roofline_bound)
+    assert roof["bound"] in ("l2", "infinity_cache") and roof["unit"] == "GB/s" and 8000.0 <= roof["peak"] <= 34500.0 and roof["launch_ms"] > 0
+    assert abs(sum(roof["bytes_by_level"].values()) - roof["algorithmic_bytes_per_launch"]) <= 1e-6 * roof["algorithmic_bytes_per_launch"]
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9) <= 1e-6 * roof["achieved"]
 
@@ -478,3 +480,11 @@ def test_bench_default_workload_by_gpu_count():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert [mod.default_workload(n) for n in (1, 2, 4, 8)] == ["synth-1M-20M"] * 3 + ["synth-4M-100M"]
+    # the roofline bound follows the level the gathered tables live in: HBM (8 TB/s) at the 1 M-node shape, the caches at the reference's own
+    count = torch.tensor([0, 3, 20, 40, 2500], dtype=torch.int32)
+    bound, peak, split = mod.gather_roofline_bound(count, 20, 2000, 1_000_000, 20_000_000)
+    assert bound == "hbm" and abs(peak - 8000.0) < 1e-6 and split["l2"] == split["infinity_cache"] == 0.0
+    assert abs(sum(split.values()) - mod.gather_algorithmic_bytes(count, 20, 2000)) < 1e-6
+    bound, peak, split = mod.gather_roofline_bound(count, 20, 2000, 184, 125_235)         # Enron shape: node / PE tables in L2, edge rows in the Infinity Cache
+    assert bound in ("l2", "infinity_cache") and 8000.0 < peak < 34500.0 and split["l2"] > split["infinity_cache"] > 0
+    assert abs(sum(split.values()) - mod.gather_algorithmic_bytes(count, 20, 2000)) < 1e-6
