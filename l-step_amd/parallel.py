@@ -228,8 +228,11 @@ def exchange_rows(send: torch.Tensor, send_counts, recv_counts, group=None, asyn
     out_shape = (sum(recv_counts),) + tuple(send.shape[1:])
     if dist.get_backend(group) != "gloo":
         out = torch.empty(out_shape, dtype=send.dtype, device=send.device)
-        work = dist.all_to_all_single(out, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group,
-                                      async_op=True)
+        if len(set(send_counts) | set(recv_counts)) == 1:      # equal blocks (the device-driven pull): the plain equal-split exchange
+            work = dist.all_to_all_single(out, send, group=group, async_op=True)
+        else:
+            work = dist.all_to_all_single(out, send, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group,
+                                          async_op=True)
 
         class _Pending:
             def wait(self_inner):
@@ -1365,7 +1368,12 @@ class DistributedLstep:
         nxt = None
         ps = self._pull_stream
         ahead = lookahead if (pull_form and lookahead is not None and len(lookahead) >= 4) else None
-        if ahead is not None:       # the next batch's requests: independent of everything this iteration computes
+        # A captured iteration issues the pull's two all-to-all exchanges from the CAPTURING stream, last: torch 2.10 / RCCL 2.26 fault when
+        # all_to_all_single is captured from a side stream that joined the capture (all_gather / reduce_scatter / all_reduce are fine there:
+        # tools/rccl_capture_probe.py, profiles/r04_rccl_capture_probe.txt).  Launch by launch the requests go out beside the forward pass
+        # and the rows travel underneath the backward pass, on the pull's own stream and communicator.
+        pull_last = capturing and ahead is not None
+        if ahead is not None and not pull_last:       # the next batch's requests: independent of everything this iteration computes
             if ps is not None:
                 ps.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
@@ -1421,8 +1429,11 @@ class DistributedLstep:
             # backward pass's reduce-scatter / all-reduce never queue behind it
             fetch_next(updated)
         main.wait_event(updated)         # the optimiser may only step once update_pe has read its weights; the ring shard is appended
-        if nxt is not None and ps is not None and capturing:
-            main.wait_stream(ps)         # (a capture must end with every stream joined)
+        if pull_last:
+            nxt = RowPullDev(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]))
+            self._poison_foreign_rows()
+            nxt.fetch()
+            self._pending_pull = nxt
         optimizer.step()
         self.slot_of.index_fill_(0, bn_cap, -1)      # (the dead tail is node 0, whose entry is -1 anyway)
         ring.tick()

@@ -100,7 +100,20 @@ def _run(worker, world, *args):
     procs = [ctx.Process(target=worker, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    import queue
+    import time
+    res, deadline = [], time.time() + 600
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=5))
+        except queue.Empty:
+            # a rank that died without reporting (a fault inside a native call) must fail the test at once, not after the queue's timeout
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f"ranks died without a report (rank, exit code): {dead}" if dead else "ranks timed out")
     for p in procs:
         p.join(timeout=60)
     for r, msg in res:

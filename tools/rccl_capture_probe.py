@@ -39,7 +39,20 @@ def main():
         z = out + y
         dist.reduce_scatter_tensor(rs, z)
         dist.all_reduce(rs)
-        if second_comm:
+        variant = os.environ.get("PROBE_VARIANT", "")
+        if second_comm and variant == "comm2_main_stream":           # second communicator, but issued from the capturing stream itself
+            dist.all_to_all_single(a2a, rs, group=g2)
+        elif second_comm and variant == "comm1_side_stream":         # main communicator, issued from a side stream that joined the capture
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.all_to_all_single(a2a, rs)
+            torch.cuda.current_stream().wait_stream(side)
+        elif second_comm and variant == "comm1_side_stream_allgather":
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(a2a, rs)
+            torch.cuda.current_stream().wait_stream(side)
+        elif second_comm:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 dist.all_to_all_single(a2a, rs, group=g2)
@@ -103,8 +116,10 @@ if __name__ == "__main__":
         # parent: never touches the GPU; one child per case
         import subprocess
         import sys
-        for i, case in enumerate(("0,0", "0,1", "1,0", "1,1")):
-            env = dict(os.environ, PROBE_CASE=case, MASTER_PORT=str(29577 + i))
+        cases = [("0,0", ""), ("0,1", ""), ("1,0", ""), ("0,1", "comm2_main_stream"), ("0,1", "comm1_side_stream"), ("0,1", "comm1_side_stream_allgather")]
+        for i, (case, variant) in enumerate(cases):
+            env = dict(os.environ, PROBE_CASE=case, PROBE_VARIANT=variant, MASTER_PORT=str(29577 + i))
+            print(f"[probe] ---- variant '{variant}'")
             r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=240)
             lines = [ln for ln in (r.stdout + r.stderr).splitlines() if "[probe]" in ln or "Error" in ln or "error" in ln]
             print(f"[probe] case async,second_comm={case}: exit code {r.returncode}")
