@@ -50,17 +50,21 @@ __device__ __forceinline__ void zero_tail(float* row, int width, int ld, int lan
 
 constexpr int kRowsInFlight = 8;      // edge rows + PE rows per group (2 x 8 loads in flight per wave)
 constexpr int kNodeRowsInFlight = 8;  // node rows per group
+constexpr int kCoopMin = 256;         // node-channel rows longer than this are summed by the whole workgroup (LSTEP_GATHER_COOP_MIN build knob)
 
 template <bool kEdgeNode, bool kPe, bool kExplicit = false>
 __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherParams p) {
     const int lane = lane_id();
-    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
-    if (row >= p.batch) return;
+    const int wv = wave_in_block();
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+    // (no early return: the node channel of a LONG row is shared by the workgroup's four waves below, through barriers every wave must reach;
+    // a wave past the end of the batch works on row 0's inputs and writes nothing)
+    const bool active = row < p.batch;
     const int F = p.F, P = p.P, D = p.D, K = p.K;
     const bool fa = lane < (F >> 2);  // lane owns a float4 of a feature row
     const bool pa = lane < (P >> 2);
-    const int64_t node = p.node_ids[row];
-    const double t = p.times[row];
+    const int64_t node = active ? p.node_ids[row] : -1;
+    const double t = active ? p.times[row] : 0.0;
     int64_t lo = 0, cnt = 0;
     const bool in_range = node >= 0 && node < p.csr.num_rows;
     if (in_range && !kExplicit) {
@@ -68,8 +72,8 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         cnt = wave_count_before(p.csr.ts, lo, p.csr.indptr[node + 1], t, lane);
     }
     // explicit lists: every slot is given (padding slots carry neighbour id 0 and gather row 0 like any other id)
-    const int k = kExplicit ? K : (int)(cnt < K ? cnt : K);
-    const int npad = K - k;
+    const int k = !active ? 0 : (kExplicit ? K : (int)(cnt < K ? cnt : K));
+    const int npad = active ? K - k : 0;
     const int64_t kfirst = lo + cnt - k;
 
     const float w0 = lane < D ? p.time_w[lane] : 0.0f, b0 = lane < D ? p.time_b[lane] : 0.0f;
@@ -155,15 +159,33 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
     }
 
     if (kEdgeNode) {
-        float* oe = p.out_edge + row * (int64_t)p.ld_edge;
-        if (lane < D) oe[lane] = xt0;
-        if (lane + kWave < D) oe[lane + kWave] = xt1;
-        if (fa) st4(oe + D + lane * 4, accE);
-        zero_tail(oe, D + F, p.ld_edge, lane);
+        if (active) {
+            float* oe = p.out_edge + row * (int64_t)p.ld_edge;
+            if (lane < D) oe[lane] = xt0;
+            if (lane + kWave < D) oe[lane + kWave] = xt1;
+            if (fa) st4(oe + D + lane * 4, accE);
+            zero_tail(oe, D + F, p.ld_edge, lane);
+        }
 
         // node channel: the last v = min(cnt, G) interactions; score 1/valid on ids > 0, then mean over G slots
-        const int64_t v = kExplicit ? (int64_t)p.G : (cnt < p.G ? cnt : p.G);
-        const int64_t vfirst = lo + cnt - v;
+        const int64_t v_all = !active ? 0 : (kExplicit ? (int64_t)p.G : (cnt < p.G ? cnt : p.G));
+        const int64_t vfirst = kExplicit ? row * (int64_t)p.G : lo + cnt - v_all;       // first slot: CSR position / position in the explicit list
+        // LONG rows (more than kCoopMin slots: hub nodes of a power-law graph, every row of the reference's small dense datasets, every row of
+        // an explicit time_gap-slot list) are summed by the whole workgroup: one wave walks a 2000-slot row in 250 dependent rounds of 8 row
+        // loads while the other three idle -- 73 us for the 600 rows of an Enron-shaped batch, 2.2 ms of the Zipf-1.2 c4 step (round 4).  Each
+        // wave takes every fourth 64-slot chunk; the four partial sums meet in LDS and are added in wave order (a fixed order: the result is a
+        // function of the inputs).  Short rows stay with their own wave, as before.
+        __shared__ long long sh_first[kWavesPerBlock];
+        __shared__ int sh_v[kWavesPerBlock];
+        __shared__ float4 sh_acc[kWavesPerBlock][kMaxRowVec];
+        __shared__ int sh_valid[kWavesPerBlock];
+        const bool coop_row = v_all > kCoopMin && !p.weighted_sum;
+        if (lane == 0) {
+            sh_v[wv] = coop_row ? (int)v_all : 0;
+            sh_first[wv] = vfirst;
+        }
+        __syncthreads();
+        const int64_t v = coop_row ? 0 : v_all;          // what this wave sums alone
         // weighted_sum (models/LSTEP.py:190-206): every slot's node row is also scaled by w = clamp(e(time) / sum of e over the row's
         // DISTINCT non-zero neighbour times, 0, 1), e(x) = exp(-(t - x)) in float64; x is what scatter_mean makes of the slot's float32 time
         // (the sequential float32 sum of the c slots that share it, divided by c).  First pass: the denominator.
@@ -230,7 +252,53 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
                 }
             }
         }
-        if (fa) {
+        for (int r = 0; r < kWavesPerBlock; ++r) {
+            const int vr = sh_v[r];
+            if (vr == 0) continue;                       // (block-uniform)
+            const int64_t first = sh_first[r];
+            float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+            int pvalid = 0;
+            for (int64_t c0 = (int64_t)wv * kWave; c0 < vr; c0 += (int64_t)kWave * kWavesPerBlock) {
+                const int m = (int)((vr - c0) < kWave ? (vr - c0) : kWave);
+                const int idx = lane < m ? (kExplicit ? (int)p.ex_nbr_g[first + c0 + lane] : p.csr.nbr[first + c0 + lane]) : 0;
+                pvalid += __popcll(__ballot(idx > 0));
+                settle(idx);
+                for (int j = 0; j < m; j += kNodeRowsInFlight) {
+                    int64_t nj[kNodeRowsInFlight];
+                    float lj[kNodeRowsInFlight];
+#pragma unroll
+                    for (int u = 0; u < kNodeRowsInFlight; ++u) {
+                        const bool live = (j + u) < m;
+                        const int rr = bcast_i32(idx, live ? (j + u) : (m - 1));
+                        nj[u] = rr > 0 ? rr : 0;
+                        lj[u] = (live && rr > 0) ? 1.f : 0.f;
+                    }
+                    if (fa) {
+                        float4 rn[kNodeRowsInFlight];
+#pragma unroll
+                        for (int u = 0; u < kNodeRowsInFlight; ++u) rn[u] = ld4(p.node_raw + nj[u] * F + lane * 4);
+#pragma unroll
+                        for (int u = 0; u < kNodeRowsInFlight; ++u) fma4(part, lj[u], rn[u]);
+                    }
+                }
+            }
+            if (fa) sh_acc[wv][lane] = part;
+            if (lane == 0) sh_valid[wv] = pvalid;
+            __syncthreads();
+            if (wv == r) {
+                if (fa) {
+#pragma unroll
+                    for (int w2 = 0; w2 < kWavesPerBlock; ++w2) {
+                        const float4 q = sh_acc[w2][lane];
+                        accN.x += q.x; accN.y += q.y; accN.z += q.z; accN.w += q.w;
+                    }
+                }
+#pragma unroll
+                for (int w2 = 0; w2 < kWavesPerBlock; ++w2) valid += sh_valid[w2];
+            }
+            __syncthreads();
+        }
+        if (fa && active) {
             const float invG = 1.0f / (float)p.G;
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid > 0) {
@@ -244,9 +312,9 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             if (in_range) self = ld4(p.node_raw + node * F + lane * 4);
             st4(p.out_node + row * (int64_t)p.ld_node + lane * 4, make_float4(r0.x + self.x, r0.y + self.y, r0.z + self.z, r0.w + self.w));
         }
-        zero_tail(p.out_node + row * (int64_t)p.ld_node, F, p.ld_node, lane);
+        if (active) zero_tail(p.out_node + row * (int64_t)p.ld_node, F, p.ld_node, lane);
     }
-    if (kPe) {
+    if (kPe && active) {
         float* op = p.out_pe + row * (int64_t)p.ld_pe;
         if (pa) st4(op + lane * 4, accP);
         if (lane < D) op[P + lane] = pt0;
@@ -255,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         zero_tail(op, P + D, p.ld_pe, lane);
         zero_tail(p.out_self + row * (int64_t)p.ld_self, P, p.ld_self, lane);
     }
-    if (p.out_count != nullptr && lane == 0) p.out_count[row] = kExplicit ? K : (int32_t)cnt;
+    if (active && p.out_count != nullptr && lane == 0) p.out_count[row] = kExplicit ? K : (int32_t)cnt;
 }
 
 struct GatherBwdParams {

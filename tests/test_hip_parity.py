@@ -438,7 +438,9 @@ def test_segment_rows_sum_hub_segments_are_deterministic(hip, monkeypatch, n_ent
     out = torch.zeros((n_rows, P + D), device=DEV)
     nat.check(lib.lstep_segment_rows_sum(nat.ptr(table), P, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(seg), nat.ptr(row), nat.ptr(dt), n_ent,
                                          nat.ptr(out), P + D, 0, None, None, 0, nat.current_stream()))
-    assert float(((out - run(0, False, False)).abs() / out.abs().clamp(min=1.0)).max()) <= 1e-4
+    # (the float-atomic form adds a segment's chunk partials one by one into the growing row: at 300 000 entries per segment that is 4700
+    # fp32 additions into a sum of ~1e5, an order of magnitude less accurate than the two-level tree it is compared with)
+    assert float(((out - run(0, False, False)).abs() / out.abs().clamp(min=1.0)).max()) <= (1e-4 if n_ent // n_rows < 50000 else 1e-3)
 
 
 @pytest.mark.parametrize("n", [1, 70, 1000, 32768])

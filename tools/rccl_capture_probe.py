@@ -47,6 +47,24 @@ def main():
             with torch.cuda.stream(side):
                 dist.all_to_all_single(a2a, rs)
             torch.cuda.current_stream().wait_stream(side)
+        elif second_comm and variant == "a2a_async_main":            # asynchronous all-to-all issued from the capturing stream, waited for later
+            w = dist.all_to_all_single(a2a, rs, async_op=True)
+            y2 = rs + 1.0
+            w.wait()
+            a2a.add_(y2 * 0.0)
+        elif second_comm and variant == "a2a_twice_main":            # two exchanges in a row (the pull: requests, then rows), a kernel in between
+            w = dist.all_to_all_single(a2a, rs, async_op=True)
+            mid = w.wait() if False else None
+            w.wait()
+            tmp = a2a * 1.0
+            w2 = dist.all_to_all_single(a2a, tmp, async_op=True)
+            w2.wait()
+        elif second_comm and variant == "allgather_async_side":      # asynchronous all-gather from a side stream (update_pe's phase-1 rows)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                w = dist.all_gather_into_tensor(a2a, rs, async_op=True)
+                w.wait()
+            torch.cuda.current_stream().wait_stream(side)
         elif second_comm and variant == "comm1_side_stream_allgather":
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -116,7 +134,10 @@ if __name__ == "__main__":
         # parent: never touches the GPU; one child per case
         import subprocess
         import sys
-        cases = [("0,0", ""), ("0,1", ""), ("1,0", ""), ("0,1", "comm2_main_stream"), ("0,1", "comm1_side_stream"), ("0,1", "comm1_side_stream_allgather")]
+        cases = [("0,0", ""), ("0,1", ""), ("1,0", ""), ("0,1", "comm2_main_stream"), ("0,1", "comm1_side_stream"), ("0,1", "comm1_side_stream_allgather"),
+                 ("0,1", "a2a_async_main"), ("0,1", "a2a_twice_main"), ("0,1", "allgather_async_side")]
+        if os.environ.get("PROBE_ONLY"):
+            cases = [c for c in cases if c[1] in os.environ["PROBE_ONLY"].split(",")]
         for i, (case, variant) in enumerate(cases):
             env = dict(os.environ, PROBE_CASE=case, PROBE_VARIANT=variant, MASTER_PORT=str(29577 + i))
             print(f"[probe] ---- variant '{variant}'")
