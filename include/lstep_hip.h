@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 33
+#define LSTEP_ABI_VERSION 34
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -42,6 +42,8 @@ typedef struct lstep_csr {
     const double* ts;      /* device, [nnz] interaction time, non-decreasing inside a row */
     int64_t num_rows;      /* max node id + 1 */
     int64_t nnz;           /* 2 * number of edges */
+    int64_t max_degree;    /* longest adjacency row (0 = unknown).  lstep_gather_aggregate_fwd shares node-channel rows of more than 256
+                            * slots among a workgroup's waves; when no row can be that long the kernel skips the workgroup barriers of that path */
 } lstep_csr_t;
 
 /* A slot of the device-resident PE history ring whose index lives ON THE DEVICE: slot = (*start + add) % slots.  Entry points that take a

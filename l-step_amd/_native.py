@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 33
+ABI_VERSION = 34
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -31,7 +31,7 @@ class LstepNativeError(RuntimeError):
 class CsrStruct(C.Structure):
     """``lstep_csr_t``"""
     _fields_ = [("indptr", C.c_void_p), ("nbr", C.c_void_p), ("eid", C.c_void_p), ("ts", C.c_void_p),
-                ("num_rows", C.c_int64), ("nnz", C.c_int64)]
+                ("num_rows", C.c_int64), ("nnz", C.c_int64), ("max_degree", C.c_int64)]
 
 
 class RingRef(C.Structure):

@@ -312,6 +312,157 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const Wgrad
     }
 }
 
+
+// ---- The same product with BOTH operands staged through LDS and shared by the workgroup (round 4).
+// The register-only kernels above give every WAVE its own operand stream: a 6 x 4-tile wave reads (96 + 64) columns per row for 24 MFMAs,
+// 20 FLOP per byte -- at the matrix cores' 157 TFLOP/s that is 8 TB/s of L2 -> CU traffic, and the six products of a training step re-read
+// their operands 4x (2 GB for 32 GFLOP).  They ran at 80 TFLOP/s alone and at 37 inside the step, where update_pe's and the tail's kernels
+// pull on the same L2 -> CU path.  Here a workgroup of four waves owns [kWlNT n-tiles] x [4 waves x KTW k-tiles] of the output over its row
+// slice; dY[rows, 16 kWlNT columns] and X[rows, 64 KTW columns] are fetched ONCE per workgroup (16-byte loads, 16 rows a stage, double
+// buffered through registers into two LDS stages, one barrier per stage), and every wave takes its MFMA operands from LDS: lane
+// (kk = l >> 4, c = l & 15) reads A[4 t + kk][16 a + c] and B[4 t + kk][16 (KTW w + b) + c] -- one ds_read_b32 per tile per 4-row step,
+// conflict-free because the LDS row strides are = 16 or 48 (mod 64) banks, so the four rows of a step land in four different
+// 16-bank groups.  Operand traffic from global memory: (96 + 64 KTW) columns per row per WORKGROUP for 4 x 6 x KTW MFMAs: 47-58 FLOP per
+// byte.  <= 200 registers per wave: two workgroups per CU, so a workgroup's barrier waits and LDS fills hide under the other's MFMAs, and
+// waves of other kernels still fit beside it.  Partials and the reduction as above (deterministic).
+constexpr int kWlRows = 16;     // rows per LDS stage (4 MFMA steps)
+constexpr int kWlNT = 6;        // n-tiles per workgroup (all four waves share them)
+constexpr int kWlLda = 16 * kWlNT + 16;      // 112 floats: = 48 (mod 64)
+
+template <int KTW>
+__global__ __launch_bounds__(kBlock, 2) void wgrad_lds_kernel(const WgradParams p) {
+    constexpr int kBCols = 64 * KTW;                 // X columns per workgroup
+    constexpr int kLdb = kBCols + 16;                // 208 / 336 floats: = 16 (mod 64)
+    constexpr int kA4 = kWlRows * (4 * kWlNT);       // float4 per A stage (384)
+    constexpr int kB4 = kWlRows * (kBCols / 4);      // float4 per B stage
+    constexpr int kAPer = (kA4 + kBlock - 1) / kBlock, kBPer = kB4 / kBlock;
+    static_assert(kB4 % kBlock == 0, "B stage must divide over the workgroup");
+    __shared__ __attribute__((aligned(16))) float sA[2][kWlRows * kWlLda];
+    __shared__ __attribute__((aligned(16))) float sB[2][kWlRows * kLdb];
+
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int kk = lane >> 4, c = lane & 15;
+    // blockIdx.x = (slice * n_blocks + n-block) * k_blocks + k-block
+    const int kblock = blockIdx.x % p.k_blocks;
+    const int nb_total = p.tasks / p.k_blocks;
+    const int nblock = (blockIdx.x / p.k_blocks) % nb_total;
+    const int slice = blockIdx.x / p.tasks;
+    const int n0 = nblock * (16 * kWlNT);
+    const int k0 = kblock * kBCols;                  // first X column of the workgroup
+    const int kw0 = k0 + wave * (16 * KTW);          // first X column of this wave's tiles
+    const int64_t r_begin = (int64_t)slice * p.rows_per_wg;
+    int64_t r_end = r_begin + p.rows_per_wg;
+    if (r_end > p.m) r_end = p.m;
+
+    // global -> register staging of one stage: thread -> (row, float4 column); columns past N / K are clamped into the matrix (whole float4s:
+    // n and k are multiples of 4) and feed tiles that are never stored; rows past the slice read its last row and are ZEROED in A (so the
+    // products vanish) -- B keeps finite values
+    f32x4 ga[kAPer], gb[kBPer];
+    auto fetch = [&](int64_t r0) {
+#pragma unroll
+        for (int j = 0; j < kAPer; ++j) {
+            const int idx = tid + kBlock * j;
+            if (idx < kA4) {
+                const int row = idx / (4 * kWlNT), c4 = idx % (4 * kWlNT);
+                int64_t r = r0 + row;
+                const bool live = r < r_end;
+                if (!live) r = r_end - 1;
+                const int col = min(n0 + 4 * c4, p.n - 4);
+                ga[j] = *reinterpret_cast<const f32x4*>(p.dy + r * p.ldy + col);
+                if (!live) ga[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kBPer; ++j) {
+            const int idx = tid + kBlock * j;
+            const int row = idx / (kBCols / 4), c4 = idx % (kBCols / 4);
+            int64_t r = r0 + row;
+            if (r > r_end - 1) r = r_end - 1;
+            const int col = min(k0 + 4 * c4, p.k - 4);
+            gb[j] = *reinterpret_cast<const f32x4*>(p.x + r * p.ldx + col);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < kAPer; ++j) {
+            const int idx = tid + kBlock * j;
+            if (idx < kA4) *reinterpret_cast<f32x4*>(&sA[buf][(idx / (4 * kWlNT)) * kWlLda + 4 * (idx % (4 * kWlNT))]) = ga[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kBPer; ++j) {
+            const int idx = tid + kBlock * j;
+            *reinterpret_cast<f32x4*>(&sB[buf][(idx / (kBCols / 4)) * kLdb + 4 * (idx % (kBCols / 4))]) = gb[j];
+        }
+    };
+
+    f32x4 acc[kWlNT][KTW];
+    float bsum[kWlNT];
+#pragma unroll
+    for (int a = 0; a < kWlNT; ++a) {
+        bsum[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < KTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t stages = (r_end - r_begin + kWlRows - 1) / kWlRows;
+    fetch(r_begin);
+    stash(0);
+    __syncthreads();
+    for (int64_t st = 0; st < stages; ++st) {
+        const int buf = (int)(st & 1);
+        if (st + 1 < stages) fetch(r_begin + (st + 1) * kWlRows);      // in flight under this stage's MFMAs
+        const float* a_l = &sA[buf][kk * kWlLda + c];
+        const float* b_l = &sB[buf][kk * kLdb + wave * (16 * KTW) + c];
+        float va[2][kWlNT], vb[2][KTW];
+#pragma unroll
+        for (int a = 0; a < kWlNT; ++a) va[0][a] = a_l[16 * a];
+#pragma unroll
+        for (int b = 0; b < KTW; ++b) vb[0][b] = b_l[16 * b];
+#pragma unroll
+        for (int t = 0; t < kWlRows / 4; ++t) {
+            const int cur = t & 1, nxt = cur ^ 1;
+            if (t + 1 < kWlRows / 4) {           // the next step's operands: LDS reads under this step's MFMAs
+#pragma unroll
+                for (int a = 0; a < kWlNT; ++a) va[nxt][a] = a_l[(4 * (t + 1)) * kWlLda + 16 * a];
+#pragma unroll
+                for (int b = 0; b < KTW; ++b) vb[nxt][b] = b_l[(4 * (t + 1)) * kLdb + 16 * b];
+            }
+#pragma unroll
+            for (int a = 0; a < kWlNT; ++a) {
+                bsum[a] += va[cur][a];
+#pragma unroll
+                for (int b = 0; b < KTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[cur][a], vb[cur][b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (st + 1 < stages) stash(buf ^ 1);     // (the other buffer: nobody reads it during this stage)
+        __syncthreads();
+    }
+
+    // C/D layout of the 16x16 forms: lane l, register q -> tile row 4 * (l >> 4) + q, tile column l & 15
+    float* out = p.part + (int64_t)slice * p.part_stride;
+#pragma unroll
+    for (int a = 0; a < kWlNT; ++a) {
+#pragma unroll
+        for (int b = 0; b < KTW; ++b) {
+            const int k = kw0 + 16 * b + c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 16 * a + 4 * kk + q;
+                if (n < p.n && k < p.k && 16 * (KTW * wave + b) < kBCols) out[(int64_t)n * p.k + k] = acc[a][b][q];
+            }
+        }
+    }
+    if (kblock == 0 && wave == 0) {
+#pragma unroll
+        for (int a = 0; a < kWlNT; ++a) {
+            float t = bsum[a];
+            t += __shfl_xor(t, 16, kWave);
+            t += __shfl_xor(t, 32, kWave);
+            const int n = n0 + 16 * a + c;
+            if (kk == 0 && n < p.n) out[p.bias_off + n] = t;
+        }
+    }
+}
+
 // out = sum over the S partial blocks: 16 float4 columns x 16 partial groups per workgroup (every thread has S / 16 independent
 // 16-byte loads in flight; the first version gave each thread S / 4 and launched a quarter of the workgroups, 33 us per call for 48 MB
 // that sit in the Infinity Cache), groups added in a fixed order: deterministic
@@ -352,6 +503,7 @@ static inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * 
 
 struct WgradPlan {
     int nt, ktw;          // template instance
+    int lds;              // 1: wgrad_lds_kernel<ktw> (operands staged through LDS, shared by the workgroup)
     int small;            // 1: 6 x 4 tiles per wave (<= 256 registers: leaves half of every SIMD's register file to other kernels)
     int k_blocks, tasks;  // small: flattened (slice, n-block, k-block) wave numbering
     int gy, gz, splits;   // grid
@@ -370,8 +522,31 @@ static WgradPlan wgrad_plan(int64_t m, int32_t n, int32_t k, bool allow_small = 
     WgradPlan pl;
     const int ntiles = (n + 15) / 16, ktiles = (k + 15) / 16;
     static const bool force_big = getenv("LSTEP_WGRAD_BIG") != nullptr;
-    pl.small = 0;
+    static const bool no_lds = getenv("LSTEP_WGRAD_NO_LDS") != nullptr;      // A/B switch: the register-only kernels of rounds 1-3
+    pl.small = pl.lds = 0;
     pl.k_blocks = pl.tasks = 0;
+    if (allow_small && !force_big && !no_lds && n % 4 == 0 && k % 4 == 0 && n >= 4 && k >= 4) {
+        // k-tiles are dealt out evenly: workgroups of 4 waves x KTW tiles, KTW = 3 or 5 whichever wastes fewer tile slots
+        pl.lds = 1;
+        pl.nt = kWlNT;
+        const int slots3 = (ktiles + 11) / 12 * 12, slots5 = (ktiles + 19) / 20 * 20;
+        pl.ktw = (slots3 <= slots5) ? 3 : 5;
+        const int n_blocks = (ntiles + kWlNT - 1) / kWlNT;
+        pl.k_blocks = (ktiles + 4 * pl.ktw - 1) / (4 * pl.ktw);
+        pl.tasks = n_blocks * pl.k_blocks;
+        pl.gz = pl.gy = 1;
+        const char* wgs_env = getenv("LSTEP_WGRAD_WGS");       // tuning: workgroups per launch (default 512: two per CU)
+        const int wgs = (wgs_env && atoi(wgs_env) > 0) ? atoi(wgs_env) : 512;
+        int splits = wgs / pl.tasks;
+        if (splits < 1) splits = 1;
+        pl.rows_per_wg = round_up((m + splits - 1) / splits, kWlRows);
+        if (pl.rows_per_wg < kWlRows) pl.rows_per_wg = kWlRows;
+        pl.splits = (int)((m + pl.rows_per_wg - 1) / pl.rows_per_wg);
+        if (pl.splits < 1) pl.splits = 1;
+        pl.bias_off = (int32_t)round_up((int64_t)n * k, 4);
+        pl.part_stride = pl.bias_off + round_up(n, 4);
+        return pl;
+    }
     if (allow_small && !force_big && n % 4 == 0 && k % 4 == 0 && n >= 4 && k >= 4) {
         pl.small = 1;
         pl.nt = 6;
@@ -438,9 +613,13 @@ extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, 
     p.dy = dy; p.x = x; p.part = (float*)workspace;
     p.m = m; p.rows_per_wg = pl.rows_per_wg; p.part_stride = pl.part_stride;
     p.ldy = ldy; p.ldx = ldx; p.n = n; p.k = k; p.bias_off = pl.bias_off; p.k_blocks = pl.k_blocks;
-    p.tasks = pl.small ? pl.tasks : 0; p.slices = pl.splits;
+    p.tasks = (pl.small || pl.lds) ? pl.tasks : 0; p.slices = pl.splits;
     const dim3 grid((unsigned)pl.splits, (unsigned)pl.gy, (unsigned)pl.gz), block(kBlock);
-    if (pl.small) {
+    if (pl.lds) {
+        const dim3 lgrid((unsigned)((int64_t)pl.splits * pl.tasks));
+        if (pl.ktw == 3) hipLaunchKernelGGL((wgrad_lds_kernel<3>), lgrid, block, 0, s, p);
+        else hipLaunchKernelGGL((wgrad_lds_kernel<5>), lgrid, block, 0, s, p);
+    } else if (pl.small) {
         const dim3 flat((unsigned)(((int64_t)pl.splits * pl.tasks + kWavesPerBlock - 1) / kWavesPerBlock));
         hipLaunchKernelGGL((wgrad_partial_v2_kernel<1, 2, 1, 0, 5>), flat, block, 0, s, p);
     } else if (wide) {

@@ -50,6 +50,7 @@ __device__ __forceinline__ void zero_tail(float* row, int width, int ld, int lan
 
 constexpr int kRowsInFlight = 8;      // edge rows + PE rows per group (2 x 8 loads in flight per wave)
 constexpr int kNodeRowsInFlight = 8;  // node rows per group
+constexpr int kCoopRowsInFlight = 16; // rows in flight per wave on a long row (a long row's waves have nothing else to overlap with)
 constexpr int kCoopMin = 256;         // node-channel rows longer than this are summed by the whole workgroup (LSTEP_GATHER_COOP_MIN build knob)
 
 template <bool kEdgeNode, bool kPe, bool kExplicit = false>
@@ -179,12 +180,16 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         __shared__ int sh_v[kWavesPerBlock];
         __shared__ float4 sh_acc[kWavesPerBlock][kMaxRowVec];
         __shared__ int sh_valid[kWavesPerBlock];
-        const bool coop_row = v_all > kCoopMin && !p.weighted_sum;
-        if (lane == 0) {
-            sh_v[wv] = coop_row ? (int)v_all : 0;
-            sh_first[wv] = vfirst;
+        // (launch-uniform: no row of this graph / slot list can be long -> none of the barriers below is executed)
+        const bool coop_on = !p.weighted_sum && (kExplicit ? p.G > kCoopMin : (p.csr.max_degree == 0 || p.csr.max_degree > kCoopMin));
+        const bool coop_row = coop_on && v_all > kCoopMin;
+        if (coop_on) {
+            if (lane == 0) {
+                sh_v[wv] = coop_row ? (int)v_all : 0;
+                sh_first[wv] = vfirst;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         const int64_t v = coop_row ? 0 : v_all;          // what this wave sums alone
         // weighted_sum (models/LSTEP.py:190-206): every slot's node row is also scaled by w = clamp(e(time) / sum of e over the row's
         // DISTINCT non-zero neighbour times, 0, 1), e(x) = exp(-(t - x)) in float64; x is what scatter_mean makes of the slot's float32 time
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
                 }
             }
         }
-        for (int r = 0; r < kWavesPerBlock; ++r) {
+        for (int r = 0; coop_on && r < kWavesPerBlock; ++r) {
             const int vr = sh_v[r];
             if (vr == 0) continue;                       // (block-uniform)
             const int64_t first = sh_first[r];
@@ -263,22 +268,22 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
                 const int idx = lane < m ? (kExplicit ? (int)p.ex_nbr_g[first + c0 + lane] : p.csr.nbr[first + c0 + lane]) : 0;
                 pvalid += __popcll(__ballot(idx > 0));
                 settle(idx);
-                for (int j = 0; j < m; j += kNodeRowsInFlight) {
-                    int64_t nj[kNodeRowsInFlight];
-                    float lj[kNodeRowsInFlight];
+                for (int j = 0; j < m; j += kCoopRowsInFlight) {
+                    int64_t nj[kCoopRowsInFlight];
+                    float lj[kCoopRowsInFlight];
 #pragma unroll
-                    for (int u = 0; u < kNodeRowsInFlight; ++u) {
+                    for (int u = 0; u < kCoopRowsInFlight; ++u) {
                         const bool live = (j + u) < m;
                         const int rr = bcast_i32(idx, live ? (j + u) : (m - 1));
                         nj[u] = rr > 0 ? rr : 0;
                         lj[u] = (live && rr > 0) ? 1.f : 0.f;
                     }
                     if (fa) {
-                        float4 rn[kNodeRowsInFlight];
+                        float4 rn[kCoopRowsInFlight];
 #pragma unroll
-                        for (int u = 0; u < kNodeRowsInFlight; ++u) rn[u] = ld4(p.node_raw + nj[u] * F + lane * 4);
+                        for (int u = 0; u < kCoopRowsInFlight; ++u) rn[u] = ld4(p.node_raw + nj[u] * F + lane * 4);
 #pragma unroll
-                        for (int u = 0; u < kNodeRowsInFlight; ++u) fma4(part, lj[u], rn[u]);
+                        for (int u = 0; u < kCoopRowsInFlight; ++u) fma4(part, lj[u], rn[u]);
                     }
                 }
             }
@@ -587,7 +592,7 @@ extern "C" int lstep_gather_explicit_fwd(const float* node_raw, const float* edg
     if (ld_pe == 0) ld_pe = pe_dim + time_dim;
     if (ld_self == 0) ld_self = pe_dim;
     if (int rc = check_ld("lstep_gather_explicit_fwd", ld_edge, time_dim + feat_dim, ld_node, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
-    lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0};   // (only num_rows is read: the bound of the self-row lookups)
+    lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0, 0};   // (only num_rows is read: the bound of the self-row lookups)
     GatherParams p{none, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
                    batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, nullptr, ld_edge, ld_node, ld_pe, ld_self,
                    nbr, eid, nt, nbr_gap, nt_gap, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0};
@@ -643,7 +648,7 @@ extern "C" int lstep_gather_explicit_bwd(const float* edge_raw, int32_t feat_dim
     if (ld_pe == 0) ld_pe = pe_dim + time_dim;
     if (ld_self == 0) ld_self = pe_dim;
     if (int rc = check_ld("lstep_gather_explicit_bwd", ld_edge, time_dim + feat_dim, feat_dim, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
-    lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0};
+    lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0, 0};
     GatherBwdParams p{none, edge_raw, feat_dim, pe_dim, time_dim, time_w, time_b, node_ids, times, nullptr, batch, num_neighbors,
                       grad_edge, grad_pe_agg, grad_self, slot_of, out_slot_dot, grad_pe_rows, out_hits, ld_edge, ld_pe, ld_self, nbr, eid, nt};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);

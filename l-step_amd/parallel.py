@@ -95,7 +95,10 @@ class PendingGather:
     ranks concatenated in rank order.  ``counts`` (rows per rank) may be passed when every rank can derive it locally: that saves the
     size exchange and its host sync."""
 
-    def __init__(self, t: torch.Tensor, group=None, counts=None):
+    def __init__(self, t: torch.Tensor, group=None, counts=None, sync: bool = False):
+        """``sync``: issue the collective synchronously (the current stream waits for it at once).  Needed inside a graph capture on a SIDE
+        stream: an asynchronous collective captured there faults in torch 2.10 / RCCL 2.26 (tools/rccl_capture_probe.py); on the capturing
+        stream itself the asynchronous all-gather captures fine."""
         self.done, self.work = None, None
         w = dist.get_world_size(group)
         self.counts = counts if counts is not None else exchange_counts(t.shape[0], t.device, group)
@@ -109,11 +112,15 @@ class PendingGather:
             pad = pad.cpu()
         self.pad = pad                                   # (kept alive until the collective has finished)
         self.out = torch.empty((w * self.mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=pad.device)
-        self.work = dist.all_gather_into_tensor(self.out, pad, group=group, async_op=True)
+        if sync:
+            dist.all_gather_into_tensor(self.out, pad, group=group)
+        else:
+            self.work = dist.all_gather_into_tensor(self.out, pad, group=group, async_op=True)
 
     def wait(self) -> torch.Tensor:
         if self.done is None:
-            self.work.wait()
+            if self.work is not None:
+                self.work.wait()
             out = _unpad_blocks(self.out, self.counts, self.mx)
             self.done = out.to(self.dev) if self.staged else out
             self.pad = self.out = self.work = None
@@ -122,7 +129,7 @@ class PendingGather:
 
 def all_gather_var(t: torch.Tensor, group=None, counts=None):
     """Blocking form of ``PendingGather``.  Returns (concatenated rows in rank order, counts list)."""
-    g = PendingGather(t, group, counts)
+    g = PendingGather(t, group, counts, sync=t.is_cuda and torch.cuda.is_current_stream_capturing())
     return g.wait(), g.counts
 
 
@@ -228,6 +235,12 @@ def exchange_rows(send: torch.Tensor, send_counts, recv_counts, group=None, asyn
     out_shape = (sum(recv_counts),) + tuple(send.shape[1:])
     if dist.get_backend(group) != "gloo":
         out = torch.empty(out_shape, dtype=send.dtype, device=send.device)
+        if send.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a graph capture: synchronous, and only ever issued from the capturing stream itself (an asynchronous all-to-all, or one
+            # issued from a side stream that joined the capture, faults in torch 2.10 / RCCL 2.26: tools/rccl_capture_probe.py)
+            assert len(set(send_counts) | set(recv_counts)) == 1, "captured exchanges move equal blocks"
+            dist.all_to_all_single(out, send, group=group)
+            return _Done(out) if async_op else out
         if len(set(send_counts) | set(recv_counts)) == 1:      # equal blocks (the device-driven pull): the plain equal-split exchange
             work = dist.all_to_all_single(out, send, group=group, async_op=True)
         else:

@@ -73,8 +73,9 @@ class NeighborSampler:
             self.nbr = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.eid = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.ts = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.max_degree = int(np.diff(indptr).max()) if len(indptr) > 1 else 0
         self._csr = nat.CsrStruct(self.indptr.data_ptr(), self.nbr.data_ptr(), self.eid.data_ptr(), self.ts.data_ptr(),
-                                  self.num_rows, self.nnz)
+                                  self.num_rows, self.nnz, self.max_degree)
 
     @classmethod
     def from_device_edges(cls, src: torch.Tensor, dst: torch.Tensor, eid: torch.Tensor, ts: torch.Tensor, num_nodes: int,
@@ -108,8 +109,9 @@ class NeighborSampler:
         self.eid = eids[o2].to(torch.int32).contiguous()
         self.ts = tss[o2].contiguous()
         self.num_rows, self.nnz = rows, int(2 * e)
+        self.max_degree = int(counts.max().item()) if e else 0          # (set-up time: the one host read of the build)
         self._csr = nat.CsrStruct(self.indptr.data_ptr(), self.nbr.data_ptr(), self.eid.data_ptr(), self.ts.data_ptr(),
-                                  self.num_rows, self.nnz)
+                                  self.num_rows, self.nnz, self.max_degree)
         if sample_neighbor_strategy != "recent":       # the RNG-defined strategies replay numpy's generator on the host, from a host copy of the CSR
             self._host = (self.indptr.cpu().numpy(), self.nbr.cpu().numpy().astype(np.int64), self.eid.cpu().numpy().astype(np.int64),
                           self.ts.cpu().numpy())

@@ -38,7 +38,7 @@ def test_abi_exports_every_declared_symbol(lib):
         assert hasattr(raw, n), f"{n} declared in include/lstep_hip.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes prototype"
     assert sorted(nat.SIGNATURES) == names
-    assert lib.lstep_abi_version() == nat.ABI_VERSION == 33
+    assert lib.lstep_abi_version() == nat.ABI_VERSION == 34
 
 
 def test_abi_argument_validation_without_gpu(lib):
@@ -47,7 +47,7 @@ def test_abi_argument_validation_without_gpu(lib):
     assert rc == nat.LSTEP_EINVAL and b"greater than 0" in lib.lstep_last_error()
     with pytest.raises(AssertionError):
         nat.check(rc)
-    csr = nat.CsrStruct(0, 0, 0, 0, 0, 0)
+    csr = nat.CsrStruct(0, 0, 0, 0, 0, 0, 0)
     assert lib.lstep_sample_recent(ctypes.byref(csr), None, 4, None, 4, 5, None, None, None, None, None) == nat.LSTEP_EINVAL
     assert lib.lstep_gather_aggregate_fwd(ctypes.byref(csr), None, None, None, 170, 172, None, None, 100, None, None, None, 4, 5, 8, 3,
                                           None, None, None, None, 0, 0, 0, 0, None, None) == nat.LSTEP_EINVAL
