@@ -522,7 +522,9 @@ static WgradPlan wgrad_plan(int64_t m, int32_t n, int32_t k, bool allow_small = 
     WgradPlan pl;
     const int ntiles = (n + 15) / 16, ktiles = (k + 15) / 16;
     static const bool force_big = getenv("LSTEP_WGRAD_BIG") != nullptr;
-    static const bool no_lds = getenv("LSTEP_WGRAD_NO_LDS") != nullptr;      // A/B switch: the register-only kernels of rounds 1-3
+    // LSTEP_WGRAD_LDS=1 selects the LDS-staged kernel (round 4: measured and NOT kept as the default -- 59-79 TFLOP/s alone against 61-80 for the
+    // register-only 6 x 4 tiling, 3.18 vs 3.17 ms per c4 step: operand delivery from L2 is not what limits these products)
+    static const bool no_lds = getenv("LSTEP_WGRAD_LDS") == nullptr;
     pl.small = pl.lds = 0;
     pl.k_blocks = pl.tasks = 0;
     if (allow_small && !force_big && !no_lds && n % 4 == 0 && k % 4 == 0 && n >= 4 && k >= 4) {

@@ -1642,7 +1642,11 @@ class GraphedDistStep:
         self.hyper = self._hyper()
         src, dst, ts, eid, neg = self.cur
         ahead = (self.nxt[0], self.nxt[1], self.nxt[2], self.nxt[3]) if dl.form == "pull" else None
-        with _no_gc(), torch.cuda.graph(graph):
+        # thread_local: the process group's watchdog thread polls the events of collectives issued launch by launch BEFORE the capture
+        # (hipEventQuery); in the default "global" mode that call from another thread is an error that kills the capture
+        # ("operation not permitted when stream is capturing" out of ProcessGroupNCCL's watchdog -- seen once the bench's eager iterations
+        # ran right in front of the capture).  The autograd thread's launches are captured in either mode.
+        with _no_gc(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             with eng.aux_streams():
                 self.out = dl._train_iteration_dev(self.optimizer, batch_idx, src, dst, ts, eid, neg, None, ahead)
             main = torch.cuda.current_stream(dl.device)
