@@ -768,12 +768,35 @@ class DistributedLstep:
         return min(n, -(-want // 1024) * 1024)
 
     def _pull_capacity_dev(self, n: int) -> int:
-        """Id slots per owner of the device-driven pull (``RowPullDev``): LSTEP_PULL_SLACK (default 1.25) x an even split of the n candidate
-        ids -- the rows travel in blocks of this size too, so the slack is paid in bytes -- never more than n.  An overflow is detected on the
-        device and reported by ``check_capacity``."""
-        even = -(-n // self.W)
-        want = int(even * float(os.environ.get("LSTEP_PULL_SLACK", "1.25"))) + 256
-        return min(n, -(-want // 256) * 256)
+        """Id slots per owner of the device-driven pull (``RowPullDev``).  The rows travel in blocks of this size too, so every slot is paid
+        in bytes: the capacity follows the LARGEST request list seen so far (the per-owner counts of every request travel to the host
+        asynchronously, ``_note_pull_counts``; never waited for) times LSTEP_PULL_SLACK (default 1.25), in steps of 4096.  Until a count has
+        arrived: an even split of the n candidate ids (an upper bound of the distinct ones).  An overflow is detected on the device and
+        reported by ``check_capacity``; a captured iteration whose capacity has become too small for what was seen since is captured again
+        (``GraphedDistStep.step``)."""
+        slack = float(os.environ.get("LSTEP_PULL_SLACK", "1.25"))
+        seen = self._pull_seen_max()
+        if seen is None:
+            want = int(-(-n // self.W) * slack) + 256
+        else:
+            want = int(seen * slack) + 1024
+        return max(4096, min(n, -(-want // 4096) * 4096))
+
+    def _pull_seen_max(self):
+        from .model import _LiveCount
+        tr = self.__dict__.setdefault("_pull_track", _LiveCount())
+        got = tr.poll()
+        if got is not None:
+            self._pull_seen = max(self.__dict__.get("_pull_seen", 0), int(got))
+        return self.__dict__.get("_pull_seen")
+
+    def _note_pull_counts(self, cnt_max: torch.Tensor):
+        """Send the largest per-owner request count of one pull to the host (asynchronously; not inside a capture)."""
+        from .model import _LiveCount
+        if cnt_max.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self.__dict__.setdefault("_pull_track", _LiveCount()).send(cnt_max)
+        elif not cnt_max.is_cuda:
+            self._pull_seen = max(self.__dict__.get("_pull_seen", 0), int(cnt_max))
 
     def _pull_now(self, blocks, ts):
         """No look-ahead had the rows fetched: request and fetch on the current stream (two host waits)."""
@@ -1294,8 +1317,8 @@ class DistributedLstep:
         g_rows = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
         with self._log("reduce_scatter row gradient", W * C * P * 4):
             g_mine = reduce_scatter_var(g_rows, [C] * W, self.group)
-        if W > 1:
-            g_mine = g_mine * (1.0 / W)                  # global mean = mean of the rank means (the local backward was seeded with 1)
+        # g_mine is the SUM over the ranks of their local gradients (each seeded with 1): the filter's parameter gradients computed from it are
+        # this OWNER's share of W x the global-mean gradient; the bucket below adds the owners' shares and scales everything by 1 / W once
         rows_mine.backward(g_mine)                       # -> fft_filter / fft_agg through this rank's history shard (dead slots: zero gradient)
         self.bb.join_aux_stream()
         extra = torch.stack([out["lp_loss"], out["pe_loss"], out["loss"]])
@@ -1539,6 +1562,8 @@ class RowPullDev:
         with torch.cuda.device(dev):
             nat.check(lib.lstep_pull_blocks(nat.ptr(uniq), nat.ptr(summary), W, rows, C, nat.ptr(self.req), nat.ptr(cnt), nat.current_stream()))
         dl._overflow.bitwise_or_((cnt > C).any().to(torch.int32))
+        self.cnt_max = cnt.max().reshape(1)            # (kept: a replayed graph rewrites it in place, GraphedDistStep reads it back)
+        dl._note_pull_counts(self.cnt_max)
         with dl._log("all_to_all pull requests", W * C * 4):
             self.asked = exchange_rows(self.req.reshape(W * C), [C] * W, [C] * W, dl.pull_group, async_op=True)     # block p = what rank p wants from me
             if dl.comm_log is not None:
@@ -1587,6 +1612,7 @@ class GraphedDistStep:
         self.nxt = (i64(), i64(), f64(), i64())                 # src, dst, ts, neg of the look-ahead batch ("pull")
         self.graph, self.out, self.replays, self.hyper = None, None, 0, None
         self._ahead_key = None
+        self._pull_cap, self._cnt_max = None, None      # ("pull") block size the captured requests use / their largest count, on the device
 
     def _hyper(self):
         o = self.optimizer
@@ -1622,12 +1648,19 @@ class GraphedDistStep:
         dl._pending_pull = None
         if self.graph is not None and self.hyper != self._hyper():
             self.close()
+        if self.graph is not None and pull and self._pull_cap is not None:
+            # the request lists have grown towards the blocks the graph was captured with: capture again with larger ones BEFORE one overflows
+            seen = dl._pull_seen_max()
+            if seen is not None and seen * 1.1 > self._pull_cap:
+                self.close()
         if self.graph is None:
             self._capture(batch_idx)
         else:
             self.graph.replay()
             self.replays += 1
             dl._ring.replay_tick()
+            if pull and self._cnt_max is not None:
+                dl._note_pull_counts(self._cnt_max)
         return self.out
 
     def _capture(self, batch_idx):
@@ -1655,6 +1688,8 @@ class GraphedDistStep:
             main.wait_stream(eng._update_stream)
             if dl._pull_stream is not None and dl.form == "pull":
                 main.wait_stream(dl._pull_stream)
+        if dl._pending_pull is not None:
+            self._pull_cap, self._cnt_max = dl._pending_pull.C, dl._pending_pull.cnt_max
         dl._pending_pull = None          # (the captured iteration's pull object belongs to the graph: replays fetch into the table directly)
         self.graph = graph
         graph.replay()
