@@ -785,7 +785,8 @@ class DistributedLstep:
     def _pull_seen_max(self):
         from .model import _LiveCount
         tr = self.__dict__.setdefault("_pull_track", _LiveCount())
-        got = tr.poll()
+        # (no event query while this thread captures: hipEventQuery is one of the calls a capture forbids)
+        got = None if (self.table.is_cuda and torch.cuda.is_current_stream_capturing()) else tr.poll()
         if got is not None:
             self._pull_seen = max(self.__dict__.get("_pull_seen", 0), int(got))
         return self.__dict__.get("_pull_seen")
