@@ -1747,6 +1747,69 @@ def test_captured_graphs_have_an_explicit_lifetime(hip):
     assert M.drain_dead_graphs() == 3 and M.live_graph_count() == base
 
 
+@pytest.mark.parametrize("cap,world,live_frac", [(70000, 3, 0.9), (32768, 8, 1.0), (5000, 1, 0.5), (262144, 8, 0.88), (1000, 16, 0.7)])
+def test_owner_partition_scatter_and_rows_by_id_match_framework_ops(hip, cap, world, live_frac):
+    """csrc/shard.hip (the device-driven multi-GPU iteration): ``lstep_owner_partition`` against a stable partition by id % world made
+    with torch ops -- blocks sorted by id, per-owner counts, positions, zero-filled dead slots, the sticky overflow flag when a block is
+    too small --, ``lstep_scatter_owner_rows`` against index_copy_ / the slot numbering, ``lstep_rows_by_id`` both ways with holes."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    g = torch.Generator(device=DEV).manual_seed(cap + world)
+    n_live = int(cap * live_frac)
+    num_rows = 4 * cap
+    ids = torch.sort(torch.randperm(num_rows - 1, generator=g, device=DEV)[:n_live] + 1).values
+    bn = torch.zeros(cap, dtype=torch.int64, device=DEV)
+    bn[:n_live] = ids
+    live = torch.tensor([n_live], dtype=torch.int32, device=DEV)
+    owner = ids % world
+    want_counts = torch.bincount(owner, minlength=world)
+    for C, expect_overflow in ((int(want_counts.max()) + 7, False), (max(1, int(want_counts.max()) - 3), True)):
+        out_ids = torch.full((world * C,), -7, dtype=torch.int64, device=DEV)
+        out_pos = torch.full((world * C,), -7, dtype=torch.int32, device=DEV)
+        counts = torch.full((world,), -7, dtype=torch.int32, device=DEV)
+        overflow = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ws = torch.empty(int(lib.lstep_owner_partition_workspace(cap, world)), dtype=torch.uint8, device=DEV)
+        nat.check(lib.lstep_owner_partition(nat.ptr(bn), cap, nat.ptr(live), world, C, nat.ptr(ws), ws.numel(), nat.ptr(out_ids), nat.ptr(out_pos),
+                                            nat.ptr(counts), nat.ptr(overflow), nat.current_stream()))
+        assert bool(overflow.item()) == expect_overflow
+        assert torch.equal(counts.long(), want_counts.clamp(max=C))
+        for p in range(world):
+            mine = ids[owner == p][:C]
+            pos = torch.nonzero(owner == p).reshape(-1)[:C]
+            blk = slice(p * C, p * C + mine.numel())
+            assert torch.equal(out_ids[blk], mine) and torch.equal(out_pos[blk].long(), pos)
+            assert int(out_ids[p * C + mine.numel():(p + 1) * C].abs().sum()) == 0 and int(out_pos[p * C + mine.numel():(p + 1) * C].abs().sum()) == 0
+        if expect_overflow:
+            continue
+        # the all-gathered blocks -> table rows + slot numbers
+        P = 172
+        rows = torch.randn(world * C, 176, device=DEV)
+        table = torch.zeros(num_rows, P, device=DEV)
+        slot_of = torch.full((num_rows,), -1, dtype=torch.int32, device=DEV)
+        nat.check(lib.lstep_scatter_owner_rows(nat.ptr(rows), 176, nat.ptr(out_ids), nat.ptr(counts), world, C, nat.ptr(table), P, nat.ptr(slot_of),
+                                               nat.current_stream()))
+        want_table = torch.zeros_like(table)
+        want_slot = torch.full_like(slot_of, -1)
+        for p in range(world):
+            c = int(counts[p])
+            want_table[out_ids[p * C:p * C + c]] = rows[p * C:p * C + c, :P]
+            want_slot[out_ids[p * C:p * C + c]] = torch.arange(p * C, p * C + c, dtype=torch.int32, device=DEV)
+        assert torch.equal(table, want_table) and torch.equal(slot_of, want_slot)
+        # rows through an id list with holes, both directions
+        req = out_ids.to(torch.int32)
+        req[::5] = -1
+        req[out_ids == 0] = -1          # (dead slots all name node 0: duplicates would race in the scatter direction)
+        buf = torch.full((world * C, P), 3.0, device=DEV)
+        nat.check(lib.lstep_rows_by_id(nat.ptr(req), world * C, nat.ptr(table), P, nat.ptr(buf), 0, nat.current_stream()))
+        keep = req >= 0
+        assert torch.equal(buf[keep], table[req[keep].long()]) and bool((buf[~keep] == 3.0).all())
+        t2 = torch.zeros_like(table)
+        nat.check(lib.lstep_rows_by_id(nat.ptr(req), world * C, nat.ptr(t2), P, nat.ptr(buf), 1, nat.current_stream()))
+        want2 = torch.zeros_like(table)
+        want2[req[keep].long()] = buf[keep]
+        assert torch.equal(t2, want2)
+
+
 def test_initial_pe_on_the_device_golden(hip, golden):
     """the initial positional encodings (utils/PositionalEncoding.py:42-62,69-91, called once at
     train_LSTEP_link_prediction.py:168-189) computed on the GPU -- sparse powers of the random-walk matrix, a dense float64 ``eigh`` of the
