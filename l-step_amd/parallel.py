@@ -1410,11 +1410,13 @@ class DistributedLstep:
         # tools/rccl_capture_probe.py, profiles/r04_rccl_capture_probe.txt).  Launch by launch the requests go out beside the forward pass
         # and the rows travel underneath the backward pass, on the pull's own stream and communicator.
         pull_last = capturing and ahead is not None
-        if ahead is not None and not pull_last:       # the next batch's requests: independent of everything this iteration computes
+        if ahead is not None:       # the next batch's requests: independent of everything this iteration computes
             if ps is not None:
                 ps.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(ps) if ps is not None else contextlib.nullcontext():
-                nxt = RowPullDev(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]))
+                # (captured: the request lists are built here, beside the forward pass; their exchange goes out from the capturing stream, last)
+                nxt = RowPullDev(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]),
+                                 defer_exchange=pull_last)
 
         def update_and_append():
             base, ref = ring.building_ref()
@@ -1460,14 +1462,15 @@ class DistributedLstep:
         _backward_unit(loss)
         v = self._reduce_gradients_dev(leaf, rows_mine, part, out)
         ring.apply_advance()             # the backward pass is enqueued: the window's oldest snapshot may move on behind it
-        if nxt is not None:
+        if nxt is not None and not pull_last:
             # the rows of the NEXT gather: behind update_pe (the owners' rows are final there).  Launch by launch with a communicator of its
             # own the exchange runs underneath the backward pass; on the main communicator (captured iterations) it is issued LAST, so the
             # backward pass's reduce-scatter / all-reduce never queue behind it
             fetch_next(updated)
         main.wait_event(updated)         # the optimiser may only step once update_pe has read its weights; the ring shard is appended
         if pull_last:
-            nxt = RowPullDev(self, *self._slice_rows((ahead[0], ahead[1], ahead[3]), ahead[2]), key=TensorsKey(ahead[0], ahead[1], ahead[2], ahead[3]))
+            main.wait_stream(ps)         # the request blocks are ready (built on the pull stream beside the forward pass)
+            nxt.send_requests()
             self._poison_foreign_rows()
             nxt.fetch()
             self._pending_pull = nxt
@@ -1544,7 +1547,9 @@ class RowPullDev:
     (``lstep_rows_by_id``), ONE all_to_all_single of equal blocks moves them, and the requester writes the rows of its own id blocks into
     its table.  A list that does not fit its block sets the engine's sticky overflow flag (``DistributedLstep.check_capacity``)."""
 
-    def __init__(self, dl: "DistributedLstep", ids: torch.Tensor, times: torch.Tensor, key: TensorsKey = None):
+    def __init__(self, dl: "DistributedLstep", ids: torch.Tensor, times: torch.Tensor, key: TensorsKey = None, defer_exchange: bool = False):
+        """``defer_exchange``: only build the request blocks (kernels: they may run on a side stream of a capture); the caller issues
+        ``send_requests()`` later, from the stream the exchange must be issued on."""
         from . import _native as nat
         self.dl, self.key = dl, key
         W, rank, dev, rows = dl.W, dl.rank, dl.device, dl.num_rows
@@ -1565,11 +1570,16 @@ class RowPullDev:
         dl._overflow.bitwise_or_((cnt > C).any().to(torch.int32))
         self.cnt_max = cnt.max().reshape(1)            # (kept: a replayed graph rewrites it in place, GraphedDistStep reads it back)
         dl._note_pull_counts(self.cnt_max)
+        self.done, self.asked = None, None
+        if not defer_exchange:
+            self.send_requests()
+
+    def send_requests(self):
+        dl, W, C = self.dl, self.dl.W, self.C
         with dl._log("all_to_all pull requests", W * C * 4):
             self.asked = exchange_rows(self.req.reshape(W * C), [C] * W, [C] * W, dl.pull_group, async_op=True)     # block p = what rank p wants from me
             if dl.comm_log is not None:
                 self.asked.wait()                     # (being timed: not left in flight)
-        self.done = None
 
     def fetch(self):
         """Serve and receive (call when the owned rows are final on the current stream)."""

@@ -52,17 +52,25 @@ def main():
     nat.build_library(defines=["LSTEP_EXACT_TANH=1"], lib_path=exact)
     nat.build_library()
     outs = {}
-    for name, lib in (("fast", nat.LIB_PATH), ("exact", exact)):
+    # controls: the SAME library run twice (run-to-run noise: the few float atomics left in the step), and the exact-tanh library with another
+    # -- equally valid -- summation order of the segment sums (LSTEP_SEGMENT_ATOMICS=1): how far do two trajectories drift apart under ANY
+    # rounding-level perturbation?  (Adam's updates are +-lr per step almost regardless of the gradient's size: a perturbed sign is a
+    # 1e-4 step, and training is a chaotic map of its rounding errors.)
+    runs = (("fast", nat.LIB_PATH, {}), ("exact", exact, {}), ("fast_again", nat.LIB_PATH, {}), ("exact_other_sum_order", exact, {"LSTEP_SEGMENT_ATOMICS": "1"}))
+    for name, lib, extra in runs:
         outs[name] = f"/tmp/tanh_drift_{name}.pt"
-        env = dict(os.environ, TANH_DRIFT_CHILD=outs[name], LSTEP_LIB=lib)
+        env = dict(os.environ, TANH_DRIFT_CHILD=outs[name], LSTEP_LIB=lib, **extra)
         subprocess.run([sys.executable, os.path.abspath(__file__), str(steps), workload], env=env, check=True)
     import torch
-    a, b = torch.load(outs["fast"]), torch.load(outs["exact"])
-    for m in sorted(a):
-        dt = float((a[m]["table"] - b[m]["table"]).abs().max())
-        dw = float((a[m]["weights"] - b[m]["weights"]).abs().max())
-        print(json.dumps({"steps": m, "workload": workload, "max_abs_table_diff": dt, "max_abs_weight_diff": dw,
-                          "loss_fast": a[m]["loss"], "loss_exact": b[m]["loss"], "table_abs_max": float(a[m]["table"].abs().max())}))
+    res = {k: torch.load(v) for k, v in outs.items()}
+    for what, (x, y) in (("tanh_fast vs tanhf", ("fast", "exact")), ("control: tanh_fast vs tanh_fast (second run)", ("fast", "fast_again")),
+                         ("control: tanhf vs tanhf with float-atomic segment joins", ("exact", "exact_other_sum_order"))):
+        a, b = res[x], res[y]
+        for m in sorted(a):
+            dt = float((a[m]["table"] - b[m]["table"]).abs().max())
+            dw = float((a[m]["weights"] - b[m]["weights"]).abs().max())
+            print(json.dumps({"pair": what, "steps": m, "workload": workload, "max_abs_table_diff": dt, "max_abs_weight_diff": dw,
+                              "loss_a": a[m]["loss"], "loss_b": b[m]["loss"], "table_abs_max": float(a[m]["table"].abs().max())}))
 
 
 if __name__ == "__main__":
