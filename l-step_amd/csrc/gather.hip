@@ -50,17 +50,24 @@ __device__ __forceinline__ void zero_tail(float* row, int width, int ld, int lan
 
 constexpr int kRowsInFlight = 8;      // edge rows + PE rows per group (2 x 8 loads in flight per wave)
 constexpr int kNodeRowsInFlight = 8;  // node rows per group
-constexpr int kCoopRowsInFlight = 16; // rows in flight per wave on a long row (a long row's waves have nothing else to overlap with)
+constexpr int kCoopRowsInFlight = 12; // rows in flight per wave on a long row (16 would cost the fourth resident wave per SIMD: 129 registers)
 constexpr int kCoopMin = 256;         // node-channel rows longer than this are summed by the whole workgroup (LSTEP_GATHER_COOP_MIN build knob)
 
-template <bool kEdgeNode, bool kPe, bool kExplicit = false>
+// kCoop: the instantiation for graphs / slot lists that CAN hold long node-channel rows (the host decides from lstep_csr_t.max_degree or the
+// explicit list's time_gap).  It is a template parameter, not a launch-uniform branch: the shared-row path costs registers (16 rows in flight),
+// scalar spills and LDS whether it runs or not, and the plain instantiation is the roofline kernel of the uniform workloads (0.43 ms per
+// 49 152 rows; with the path compiled in: 0.48).
+template <bool kEdgeNode, bool kPe, bool kExplicit = false, bool kCoop = false>
 __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherParams p) {
     const int lane = lane_id();
     const int wv = wave_in_block();
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wv;
-    // (no early return: the node channel of a LONG row is shared by the workgroup's four waves below, through barriers every wave must reach;
-    // a wave past the end of the batch works on row 0's inputs and writes nothing)
-    const bool active = row < p.batch;
+    if constexpr (!kCoop) {
+        if (row >= p.batch) return;
+    }
+    // (kCoop: no early return -- the node channel of a LONG row is shared by the workgroup's four waves below, through barriers every wave
+    // must reach; a wave past the end of the batch works on row 0's inputs and writes nothing)
+    const bool active = !kCoop || row < p.batch;
     const int F = p.F, P = p.P, D = p.D, K = p.K;
     const bool fa = lane < (F >> 2);  // lane owns a float4 of a feature row
     const bool pa = lane < (P >> 2);
@@ -176,14 +183,13 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         // loads while the other three idle -- 73 us for the 600 rows of an Enron-shaped batch, 2.2 ms of the Zipf-1.2 c4 step (round 4).  Each
         // wave takes every fourth 64-slot chunk; the four partial sums meet in LDS and are added in wave order (a fixed order: the result is a
         // function of the inputs).  Short rows stay with their own wave, as before.
-        __shared__ long long sh_first[kWavesPerBlock];
-        __shared__ int sh_v[kWavesPerBlock];
-        __shared__ float4 sh_acc[kWavesPerBlock][kMaxRowVec];
-        __shared__ int sh_valid[kWavesPerBlock];
-        // (launch-uniform: no row of this graph / slot list can be long -> none of the barriers below is executed)
-        const bool coop_on = !p.weighted_sum && (kExplicit ? p.G > kCoopMin : (p.csr.max_degree == 0 || p.csr.max_degree > kCoopMin));
+        __shared__ long long sh_first[kCoop ? kWavesPerBlock : 1];
+        __shared__ int sh_v[kCoop ? kWavesPerBlock : 1];
+        __shared__ float4 sh_acc[kCoop ? kWavesPerBlock : 1][kCoop ? kMaxRowVec : 1];
+        __shared__ int sh_valid[kCoop ? kWavesPerBlock : 1];
+        constexpr bool coop_on = kCoop;
         const bool coop_row = coop_on && v_all > kCoopMin;
-        if (coop_on) {
+        if constexpr (coop_on) {
             if (lane == 0) {
                 sh_v[wv] = coop_row ? (int)v_all : 0;
                 sh_first[wv] = vfirst;
@@ -257,7 +263,8 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
                 }
             }
         }
-        for (int r = 0; coop_on && r < kWavesPerBlock; ++r) {
+        if constexpr (coop_on)
+        for (int r = 0; r < kWavesPerBlock; ++r) {
             const int vr = sh_v[r];
             if (vr == 0) continue;                       // (block-uniform)
             const int64_t first = sh_first[r];
@@ -561,9 +568,15 @@ extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* n
                    nullptr, nullptr, nullptr, nullptr, nullptr, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
-    if (en && pb) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true>), grid, block, 0, s, p);
-    else if (en) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true>), grid, block, 0, s, p);
+    // long node-channel rows possible?  (max_degree 0 = unknown: assume yes)
+    const bool coop = en && !(branches & LSTEP_WEIGHTED_SUM) && (csr->max_degree == 0 || csr->max_degree > kCoopMin) && time_gap > kCoopMin;
+    if (en && pb) {
+        if (coop) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true>), grid, block, 0, s, p);
+    } else if (en) {
+        if (coop) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false>), grid, block, 0, s, p);
+    } else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true>), grid, block, 0, s, p);
     return check_launch("gather_aggregate_fwd_kernel");
 }
 
@@ -597,7 +610,9 @@ extern "C" int lstep_gather_explicit_fwd(const float* node_raw, const float* edg
                    batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, nullptr, ld_edge, ld_node, ld_pe, ld_self,
                    nbr, eid, nt, nbr_gap, nt_gap, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
-    if (en) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, p);
+    if (en && time_gap > kCoopMin && !(branches & LSTEP_WEIGHTED_SUM))
+        hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, true, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (en) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true, true>), grid, block, 0, (hipStream_t)stream, p);
     return check_launch("gather_aggregate_fwd_kernel<explicit>");
 }
