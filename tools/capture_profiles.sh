@@ -13,10 +13,10 @@ rm -rf /tmp/p1 /tmp/p2 /tmp/p3
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r --output-format csv -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline $ARGS > /dev/null 2>&1
 echo "[capture] kernel trace done"
 cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-# iterations in the trace: T = 100 evaluation pre-roll + 12 set-up training iterations (2 launch-by-launch, 1 capture, the rest replays) + 3 warm-up,
-# then the 10 timed graph replays, then 10 launch-by-launch iterations that time the gather kernel: summarise the timed replays
-python $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) --top 70 --skip 115 --count 10 > $OUT/${TAG}_kernel_trace_per_iter.txt
-python $ROOT/tools/prof_timeline.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) --iter 120 --all > $OUT/${TAG}_timeline.txt 2>&1 || true
+# iterations in the trace: the evaluation pre-roll (up to T = 100 batches), 12 set-up training iterations (2 launch-by-launch, 1 capture, the rest replays), 3 warm-up,
+# then the 10 timed graph replays, then 10 launch-by-launch iterations that time the gather kernel: the summary takes the 10 timed replays (--last 20 --count 10)
+python $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) --top 70 --last 20 --count 10 > $OUT/${TAG}_kernel_trace_per_iter.txt
+python $ROOT/tools/prof_timeline.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) --iter -15 --all > $OUT/${TAG}_timeline.txt 2>&1 || true
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o f --output-format csv -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline $ARGS > /dev/null 2>&1
 echo "[capture] FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o w --output-format csv -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline $ARGS > /dev/null 2>&1
