@@ -50,7 +50,7 @@ __device__ __forceinline__ void zero_tail(float* row, int width, int ld, int lan
 
 constexpr int kRowsInFlight = 8;      // edge rows + PE rows per group (2 x 8 loads in flight per wave)
 constexpr int kNodeRowsInFlight = 8;  // node rows per group
-constexpr int kCoopRowsInFlight = 12; // rows in flight per wave on a long row (16 would cost the fourth resident wave per SIMD: 129 registers)
+constexpr int kCoopRowsInFlight = 16; // rows in flight per wave on a long row (129 registers: three waves per SIMD in this instantiation; measured better on the Zipf workload than 12 in flight at four waves: 4.17 vs 4.39 ms per step)
 constexpr int kCoopMin = 256;         // node-channel rows longer than this are summed by the whole workgroup (LSTEP_GATHER_COOP_MIN build knob)
 
 // kCoop: the instantiation for graphs / slot lists that CAN hold long node-channel rows (the host decides from lstep_csr_t.max_degree or the

@@ -635,19 +635,15 @@ constexpr int kTd = 112, kTt = kTd / 16;     // padded time width of the pre-mul
 // W1b sum time features, and every message's pe row is one of the U batch-node rows: the caller multiplies those U rows by W1a once
 // (a [U, 172] x [172, 172] product instead of 172 x 172 multiply-adds for each of the ~9 U touched rows), the segment sums run over the
 // products, and agg = [sum W1a pe (176) | sum time features (time_dim)].  Here: h = relu(agg[:176] + W1b agg[176:] + b1), w1 = W1b [176, 112].
-template <int S, bool kPre = false, bool kSelf = false>
-__global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) {
+// One task = S slabs of 16 rows, start to finish (see update_rows_kernel).  `w2` / `ldw2`: the second layer's weights -- global memory
+// [176, 176], or the workgroup's LDS copy with a padded row stride (update_rows_lds_kernel).  `p.n` is already clamped to the live count and
+// `p.mirror` already points at the slot.
+template <int S, bool kPre, bool kSelf>
+__device__ __forceinline__ void update_rows_task(const UpdateParams& p, int64_t task, const float* w2, int ldw2) {
     static_assert(!(kPre && kSelf), "the pre-multiplied form is phase 2: no self term");
     const int lane = lane_id();
     const int i = lane & 15, g = lane >> 4;
-    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     const int64_t r0 = task * (16 * S);
-    if (p.live) {
-        const int64_t live = *p.live;
-        if (live < p.n) p.n = live;
-    }
-    if (r0 >= p.n) return;   // no barriers in this kernel
-    if (p.ring_start && p.mirror) p.mirror += (int64_t)((*p.ring_start + p.ring_add) % p.ring_slots) * p.ring_stride;
     bool live[S];
     const float* agg_l[S];
     int64_t id[S];
@@ -716,7 +712,7 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
             for (int v = 0; v < 4; ++v) h[t][s][v] = fmaxf(h[t][s][v], 0.f);
         }
     }
-    mma_wr<kTp, S, kTp>(z, wlane(p.w2, kPp), kPp, h);
+    mma_wr<kTp, S, kTp>(z, wlane(w2, ldw2), ldw2, h);
     if constexpr (kSelf) {
         // own rows straight from the table: pe_dim = 172 columns, so the last lane group of the last chunk would read past the row: masked
         // (the padded weight columns it would meet are zero)
@@ -748,6 +744,124 @@ __global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) 
             }
         }
     }
+}
+
+template <int S, bool kPre = false, bool kSelf = false>
+__global__ __launch_bounds__(kBlock, 1) void update_rows_kernel(UpdateParams p) {
+    const int64_t task = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
+    if (p.live) {
+        const int64_t live = *p.live;
+        if (live < p.n) p.n = live;
+    }
+    if (task * (16 * S) >= p.n) return;   // no barriers in this kernel
+    if (p.ring_start && p.mirror) p.mirror += (int64_t)((*p.ring_start + p.ring_add) % p.ring_slots) * p.ring_stride;
+    update_rows_task<S, kPre, kSelf>(p, task, p.w2, kPp);
+}
+
+// The pre-multiplied form for MANY rows (update_pe phase 2: 290 k rows per c4 step) as a persistent kernel with the second layer's weights
+// resident in LDS (round 4).  update_rows_kernel<3, true> spends 187 us in MFMA phases and 185 us moving rows, one
+// after the other: its waves own all 512 registers of their SIMD, so nothing runs beside them, and every wave of the launch is in the same
+// phase at the same time.  Here: ONE slab per wave (<= 256 registers), EIGHT waves per workgroup = two per SIMD, one
+// workgroup per CU; W2 [176, 176] (124 KB of the 203 KB of weights) is copied into LDS once per workgroup (row stride 196 floats = 4 mod
+// 64 banks: the 16 lanes of a quarter-wave read 16 consecutive rows at the same column without a bank conflict) and read from there by
+// every task; only W1b [176, 112] (79 KB) still streams from L2 per slab -- 2.6x less L2 -> CU traffic than one slab per wave used to cost
+// (that form saturated the L2 -> CU path: 510 vs 367 us, appendix A).  Waves take slabs round-robin and never meet at a barrier after the
+// copy, so they drift apart and one wave's row loads / stores run under its SIMD partner's MFMAs.
+// The task body of that kernel: update_rows_task<1, true, false> with both layers' output tiles processed in two halves (6 + 5 tiles), so
+// that accumulators, operand buffers and the old rows of ONE half are alive at a time: <= 256 registers without spills (the whole-width body
+// needs 400).  Same products in the same order per output element: bit-identical to update_rows_kernel<1, true>.
+template <int T>
+__device__ __forceinline__ void update_pre_layer1_half(const UpdateParams& p, const float* agg_l, int t0, int i, int g, f32x4 (*h)[1]) {
+    f32x4 acc[T][1];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t][0] = ldv4(agg_l + 16 * (t0 + t)) + ldv4(p.b1 + 16 * (t0 + t) + 4 * g);
+    const float* tf_l[1] = {agg_l + kPp};
+    mma_wx_masked<T, 1>(acc, p.w1 + (size_t)(16 * t0 + i) * kTd + 4 * g, kTd, kTt, tf_l, p.time_dim, g);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) h[t0 + t][0][v] = fmaxf(acc[t][0][v], 0.f);
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void update_pre_layer2_half(const UpdateParams& p, const float* w2, int ldw2, int t0, int i, int g, const f32x4 (*h)[1],
+                                                       float* own_row, float* mir_row, bool live) {
+    f32x4 z[T][1];
+#pragma unroll
+    for (int t = 0; t < T; ++t) z[t][0] = ldv4(p.b2 + 16 * (t0 + t) + 4 * g);
+    mma_wr<T, 1, kTp>(z, w2 + (size_t)(16 * t0 + i) * ldw2 + 4 * g, ldw2, h);
+    f32x4 rows[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int f = 16 * (t0 + t) + 4 * g;
+        rows[t] = ldv4(f + 4 <= p.pe_dim ? own_row + f : own_row);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int f = 16 * (t0 + t) + 4 * g;
+        if (f + 4 <= p.pe_dim && live) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rows[t][v] += tanh_fast(z[t][0][v]);
+            *reinterpret_cast<f32x4*>(own_row + f) = rows[t];
+            if (mir_row) *reinterpret_cast<f32x4*>(mir_row + f) = rows[t];
+        }
+    }
+}
+
+__device__ __forceinline__ void update_rows_pre_task_halves(const UpdateParams& p, int64_t task, const float* w2, int ldw2) {
+    const int lane = lane_id();
+    const int i = lane & 15, g = lane >> 4;
+    int64_t r = task * 16 + i;
+    const bool live = r < p.n;
+    if (!live) r = p.n - 1;
+    const float* agg_l = p.agg + r * p.ld_agg + 4 * g;
+    const int64_t id = p.ids[r];
+    float* own_row = p.table + id * p.pe_dim;
+    float* mir_row = nullptr;
+    if (p.mirror) {
+        if (p.mirror_world > 1) {
+            if (id % p.mirror_world == p.mirror_rank) mir_row = p.mirror + (id / p.mirror_world) * p.pe_dim;
+        } else {
+            mir_row = p.mirror + id * p.pe_dim;
+        }
+    }
+    constexpr int kHalf = 6;
+    f32x4 h[kTp][1];
+    // (the weight bases are made opaque per task: otherwise the ~100 tile addresses are hoisted out of the persistent kernel's task loop as
+    // loop invariants and the body spills)
+    UpdateParams q = p;
+    int64_t zero = 0;
+    asm volatile("" : "+s"(zero));       // (an opaque offset, not an opaque pointer: the loads stay global_load, not flat_load)
+    q.w1 = p.w1 + zero;
+    q.b1 = p.b1 + zero;
+    q.b2 = p.b2 + zero;
+    update_pre_layer1_half<kHalf>(q, agg_l, 0, i, g, h);
+    update_pre_layer1_half<kTp - kHalf>(q, agg_l, kHalf, i, g, h);
+    update_pre_layer2_half<kHalf>(q, w2, ldw2, 0, i, g, h, own_row, mir_row, live);
+    update_pre_layer2_half<kTp - kHalf>(q, w2, ldw2, kHalf, i, g, h, own_row, mir_row, live);
+}
+
+constexpr int kUpdLdsLd = 196;                       // LDS row stride of W2 (floats)
+constexpr int kUpdLdsBytes = kPp * kUpdLdsLd * 4;    // 137 984 B
+template <int kUpdLdsWaves>
+__global__ __launch_bounds__(kUpdLdsWaves * kWave, 1) void update_rows_lds_kernel(UpdateParams p) {
+    extern __shared__ __attribute__((aligned(16))) float s_w2[];
+    for (int e = threadIdx.x; e < kPp * (kPp / 4); e += kUpdLdsWaves * kWave) {
+        const int r = e / (kPp / 4), c4 = e % (kPp / 4);
+        *reinterpret_cast<f32x4*>(&s_w2[r * kUpdLdsLd + 4 * c4]) = ldv4(p.w2 + (size_t)r * kPp + 4 * c4);
+    }
+    __syncthreads();
+    if (p.live) {
+        const int64_t live = *p.live;
+        if (live < p.n) p.n = live;
+    }
+    if (p.ring_start && p.mirror) p.mirror += (int64_t)((*p.ring_start + p.ring_add) % p.ring_slots) * p.ring_stride;
+    const int64_t slabs = (p.n + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * kUpdLdsWaves;
+    for (int64_t task = (int64_t)blockIdx.x * kUpdLdsWaves + wave_in_block(); task < slabs; task += stride)
+        update_rows_pre_task_halves(p, task, s_w2, kUpdLdsLd);
 }
 
 // update_pe for few rows: one slab per workgroup, the 11 output tiles of both layers dealt out to its four waves (as tail_fwd_split_kernel
@@ -980,6 +1094,27 @@ extern "C" int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int
     if (update_split(n)) {
         hipLaunchKernelGGL(update_rows_split_kernel<true>, dim3((unsigned)((n + 15) / 16)), dim3(kBlock), 0, s, p);
         return check_launch("lstep_update_rows_pre<split>");
+    }
+    {
+        // many rows: the persistent LDS-resident form (LSTEP_UPDATE_LDS=0 switches it off, =1 forces it; default: from 64 k rows on)
+        const char* lds = getenv("LSTEP_UPDATE_LDS");
+        const bool force_on = lds && lds[0] == '1', force_off = lds && lds[0] == '0';
+        if (!force_off && (force_on || n >= 65536)) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)update_rows_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kUpdLdsBytes) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)update_rows_lds_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, kUpdLdsBytes) != hipSuccess)
+                    return set_error(LSTEP_EHIP, "lstep_update_rows_pre: cannot reserve %d bytes of LDS", kUpdLdsBytes);
+                attr_set = true;
+            }
+            const char* wv = getenv("LSTEP_UPDATE_LDS_WAVES");      // tuning: 8 (two waves per SIMD) or 12 (three)
+            const int waves = (wv && atoi(wv) == 8) ? 8 : 12;
+            const int64_t slabs = (n + 15) / 16;
+            const unsigned wgs = (unsigned)(slabs < 256 * (int64_t)waves ? (slabs + waves - 1) / waves : 256);
+            if (waves == 8) hipLaunchKernelGGL(update_rows_lds_kernel<8>, dim3(wgs), dim3(8 * kWave), kUpdLdsBytes, s, p);
+            else hipLaunchKernelGGL(update_rows_lds_kernel<12>, dim3(wgs), dim3(12 * kWave), kUpdLdsBytes, s, p);
+            return check_launch("lstep_update_rows_pre<lds>");
+        }
     }
     const int S = update_slabs_per_wave(n);
     const int64_t tasks = ((n + 15) / 16 + S - 1) / S;

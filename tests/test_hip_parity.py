@@ -937,6 +937,60 @@ def test_update_rows_split_kernels_match_whole_slab_kernels_and_float64(hip, mon
     assert float((got[True] - got[False]).abs().max()) <= 2e-6     # same products in the same order per output element
 
 
+@pytest.mark.parametrize("n,waves", [(70001, "12"), (70001, "8"), (290000, "12"), (5000, "12")])
+def test_update_rows_persistent_lds_kernel_matches_slab_chain_kernel_and_float64(hip, monkeypatch, n, waves):
+    """lstep_update_rows_pre for many rows (round 4): the persistent kernel with pe_mlp_2's weights resident in LDS, one slab per wave, two or
+    three waves per SIMD (``update_rows_lds_kernel<8 | 12>``, taken from 65 536 rows on; LSTEP_UPDATE_LDS=1 forces it, =0 switches it off) against
+    the slab-chain kernel and float64 (models/LSTEP.py:327-339), with a device-resident live count, an owner-sharded mirror slot addressed
+    through a device-resident ring position, rows outside ``ids[:live]`` untouched.  Same products in the same order per output element:
+    the two kernels must agree to rounding of the shared ``tanh``."""
+    from lstep_amd import _native as nat
+    import ctypes
+    lib = nat.load_library()
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    rnd = lambda *sh, s=1.0: s * torch.randn(*sh, device=DEV, generator=gen)  # noqa: E731
+    N, P, TD, W, R = n + n // 3 + 40, 172, 100, 3, 1
+    live_n = n - 777
+    table0 = rnd(N, P, s=0.3)
+    ids = torch.randperm(N, device=DEV, generator=gen)[:n].contiguous()
+    pad = lambda w, r, c: torch.nn.functional.pad(w, (0, c - w.shape[1], 0, r - w.shape[0])).contiguous()  # noqa: E731
+    w1, b1, w2, b2 = rnd(P, P + TD, s=0.07), rnd(P, s=0.1), rnd(P, P, s=0.07), rnd(P, s=0.1)
+    pe_sum, tf_sum = rnd(n, P), rnd(n, TD)
+    d = lambda t: t.double()  # noqa: E731
+    z = torch.relu(torch.cat([d(pe_sum), d(tf_sum)], 1) @ d(w1).t() + d(b1)) @ d(w2).t() + d(b2)
+    want = d(table0).clone()
+    want[ids[:live_n]] += torch.tanh(z[:live_n])
+    b1p, b2p = (torch.nn.functional.pad(b, (0, 4)).contiguous() for b in (b1, b2))
+    w1b, w2p = pad(w1[:, P:], 176, 112), pad(w2, 176, 176)
+    live = torch.tensor([live_n], dtype=torch.int32, device=DEV)
+    agg = torch.zeros(n, 176 + TD, device=DEV)
+    agg[:, :P] = (d(pe_sum) @ d(w1[:, :P]).t()).float()
+    agg[:, 176:] = tf_sum
+    rows_m = (N + W - 1) // W
+    slots, start = 5, torch.tensor([3], dtype=torch.int32, device=DEV)
+    ref = nat.RingRef(start.data_ptr(), 4, slots, rows_m * P)           # slot (3 + 4) % 5 = 2
+    got = {}
+    monkeypatch.setenv("LSTEP_UPDATE_LDS_WAVES", waves)
+    for lds in ("1", "0"):
+        monkeypatch.setenv("LSTEP_UPDATE_LDS", lds)
+        table = table0.clone()
+        ring = torch.full((slots, rows_m, P), float("nan"), device=DEV)
+        nat.check(lib.lstep_update_rows_pre(nat.ptr(agg), 176 + TD, nat.ptr(ids), n, nat.ptr(w1b), nat.ptr(b1p), nat.ptr(w2p), nat.ptr(b2p),
+                                            nat.ptr(table), nat.ptr(ring), P, TD, nat.ptr(live), ctypes.byref(ref), W, R, nat.current_stream()))
+        torch.cuda.synchronize()
+        got[lds] = table
+        assert float((table.double() - want).abs().max()) <= 2e-5, lds
+        untouched = torch.ones(N, dtype=torch.bool, device=DEV)
+        untouched[ids[:live_n]] = False
+        assert torch.equal(table[untouched], table0[untouched])
+        mine = ids[:live_n][ids[:live_n] % W == R]
+        assert torch.equal(ring[2][mine // W], table[mine])
+        others = torch.ones(rows_m, dtype=torch.bool, device=DEV)
+        others[mine // W] = False
+        assert bool(torch.isnan(ring[2][others]).all()) and bool(torch.isnan(ring[[0, 1, 3, 4]]).all())
+    assert float((got["1"] - got["0"]).abs().max()) <= 2e-6
+
+
 @pytest.mark.parametrize("n", [1, 200, 601, 8192])
 def test_link_predictor_split_kernels_match_whole_slab_kernels_and_float64(hip, monkeypatch, n):
     """lstep_head_fwd / _bwd: the one-slab-per-workgroup kernels (up to 512 slabs of 16 edges) and the one-slab-per-wave kernels
