@@ -1096,10 +1096,10 @@ extern "C" int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int
         return check_launch("lstep_update_rows_pre<split>");
     }
     {
-        // many rows: the persistent LDS-resident form (LSTEP_UPDATE_LDS=0 switches it off, =1 forces it; default: from 64 k rows on)
+        // the persistent LDS-resident form: LSTEP_UPDATE_LDS=1 selects it.  Measured and NOT kept as the default (round 4): 449 us against 485 for
+        // the slab chain at 290 k rows alone (-7 %), but 3.23-3.26 against 3.20 ms per c4 step
         const char* lds = getenv("LSTEP_UPDATE_LDS");
-        const bool force_on = lds && lds[0] == '1', force_off = lds && lds[0] == '0';
-        if (!force_off && (force_on || n >= 65536)) {
+        if (lds && lds[0] == '1') {
             static bool attr_set = false;
             if (!attr_set) {
                 if (hipFuncSetAttribute((const void*)update_rows_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kUpdLdsBytes) != hipSuccess ||
@@ -1107,8 +1107,8 @@ extern "C" int lstep_update_rows_pre(const float* agg, int32_t ld_agg, const int
                     return set_error(LSTEP_EHIP, "lstep_update_rows_pre: cannot reserve %d bytes of LDS", kUpdLdsBytes);
                 attr_set = true;
             }
-            const char* wv = getenv("LSTEP_UPDATE_LDS_WAVES");      // tuning: 8 (two waves per SIMD) or 12 (three)
-            const int waves = (wv && atoi(wv) == 8) ? 8 : 12;
+            const char* wv = getenv("LSTEP_UPDATE_LDS_WAVES");      // tuning: 8 (two waves per SIMD, the faster one) or 12 (three)
+            const int waves = (wv && atoi(wv) == 12) ? 12 : 8;
             const int64_t slabs = (n + 15) / 16;
             const unsigned wgs = (unsigned)(slabs < 256 * (int64_t)waves ? (slabs + waves - 1) / waves : 256);
             if (waves == 8) hipLaunchKernelGGL(update_rows_lds_kernel<8>, dim3(wgs), dim3(8 * kWave), kUpdLdsBytes, s, p);

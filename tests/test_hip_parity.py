@@ -940,7 +940,7 @@ def test_update_rows_split_kernels_match_whole_slab_kernels_and_float64(hip, mon
 @pytest.mark.parametrize("n,waves", [(70001, "12"), (70001, "8"), (290000, "12"), (5000, "12")])
 def test_update_rows_persistent_lds_kernel_matches_slab_chain_kernel_and_float64(hip, monkeypatch, n, waves):
     """lstep_update_rows_pre for many rows (round 4): the persistent kernel with pe_mlp_2's weights resident in LDS, one slab per wave, two or
-    three waves per SIMD (``update_rows_lds_kernel<8 | 12>``, taken from 65 536 rows on; LSTEP_UPDATE_LDS=1 forces it, =0 switches it off) against
+    three waves per SIMD (``update_rows_lds_kernel<8 | 12>``; opt-in through LSTEP_UPDATE_LDS=1: measured, not faster inside the step) against
     the slab-chain kernel and float64 (models/LSTEP.py:327-339), with a device-resident live count, an owner-sharded mirror slot addressed
     through a device-resident ring position, rows outside ``ids[:live]`` untouched.  Same products in the same order per output element:
     the two kernels must agree to rounding of the shared ``tanh``."""
