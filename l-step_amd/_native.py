@@ -246,14 +246,26 @@ _WORKSPACES = {}
 
 
 def _workspace(dev, need: int):
-    """Device scratch, one buffer per (device, stream), grown on demand: the engine runs update_pe on a side stream (its own host
-    thread) while the backward pass works on the main stream."""
+    """Device scratch, one buffer per (device, stream, HOST THREAD), grown on demand: the engine runs update_pe on a side stream (its own
+    host thread) while the backward pass works on the main stream.
+
+    The thread is part of the key because a scratch buffer lives across the launches of ONE native call sequence (partial sums and their
+    reduction, a sort's passes, chunk flags and their join), and PyTorch hands out streams from a pool of 32 per device: in a process that
+    has created more than that, the engine's update stream can be the SAME queue as the auxiliary stream of the backward pass.  Two host
+    threads then interleave their launch sequences on one queue -- harmless for stream order, fatal for a scratch buffer shared by both
+    (a clobbered chunk-flag word is an out-of-range read in the join kernel).  Seen once as a wrong gradient and once as a GPU fault, only
+    behind ~130 other tests (round 4).  Python threads are keyed by name (the engine's per-iteration worker threads share one), the
+    autograd engine's device thread by its ident."""
+    import threading
+
     import torch
 
     if torch.cuda.is_current_stream_capturing():
         # inside a graph capture the scratch belongs to the graph's private pool: never cached, never shared with eager launches
         return torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
-    wkey = (dev, _raw_stream(dev.index if hasattr(dev, "index") and dev.index is not None else None))
+    th = threading.current_thread()
+    who = th.ident if isinstance(th, threading._DummyThread) else th.name
+    wkey = (dev, _raw_stream(dev.index if hasattr(dev, "index") and dev.index is not None else None), who)
     ws = _WORKSPACES.get(wkey)
     if ws is None or ws.numel() < need:
         ws = _WORKSPACES[wkey] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)

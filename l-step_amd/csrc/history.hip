@@ -580,6 +580,10 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
 static int runs_bwd_nodes_per_chunk(int64_t num_ids, int32_t t_len) {
     const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
     int per = kBwdNodesPerChunk;
+    if (const char* e = getenv("LSTEP_RUNS_BWD_CHUNK")) {      // tuning knob (tools/history_bench.py)
+        const int v = atoi(e);
+        if (v >= 4 && v <= 1024) per = v;
+    }
     while (per > 4 && ((num_ids + per - 1) / per) * groups < 1024) per >>= 1;
     return per;
 }

@@ -1933,10 +1933,7 @@ def test_rng_strategies_feed_the_fused_path_golden(hip, golden, strategy, tsf, w
     np.testing.assert_allclose(bb.edge_mlp_1.weight.grad.cpu().numpy()[::GRAD_ROW_STRIDE], z[f"{tag}/grad_edge_mlp_1"], rtol=0, atol=5e-5)
 
 
-@pytest.mark.parametrize("strategy", ["uniform", "time_interval_aware"])
-def test_engine_with_rng_sampler_vs_oracle_protocol(hip, strategy):
-    """The device engine (one merged launch for src | dst | negatives) driven by an RNG-defined sampler draws block by block in the
-    reference's order, so three training iterations reproduce the oracle protocol running on the same seed draw for draw."""
+def _rng_engine_scenario(hip, strategy, tweak=None):
     from oracle.lstep_oracle import build_oracle_model
     N, E, K, T, B, G = 120, 6000, 6, 4, 32, 9
     g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=95)
@@ -1951,6 +1948,8 @@ def test_engine_with_rng_sampler_vs_oracle_protocol(hip, strategy):
     st = protocol.ProtocolState(history=torch.zeros(N + 1, 0, 172), initial_pe=torch.from_numpy(pe0.copy()))
     eng = hip.LstepEngine(hm[0], hm[1], K, G)
     assert not eng.device_counts
+    if tweak is not None:
+        tweak(eng)
     stream = hip.EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
     init = torch.from_numpy(pe0.copy()).to(DEV)
     for b in range(4):
@@ -1963,3 +1962,25 @@ def test_engine_with_rng_sampler_vs_oracle_protocol(hip, strategy):
         if ro is not None:
             np.testing.assert_allclose(rh["predicts"].cpu().numpy(), ro["predicts"], **TOL)
             np.testing.assert_allclose(float(rh["loss"]), ro["loss"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("strategy", ["uniform", "time_interval_aware"])
+def test_engine_with_rng_sampler_vs_oracle_protocol(hip, strategy):
+    """The device engine (one merged launch for src | dst | negatives) driven by an RNG-defined sampler draws block by block in the
+    reference's order, so three training iterations reproduce the oracle protocol running on the same seed draw for draw."""
+    _rng_engine_scenario(hip, strategy)
+
+
+@pytest.mark.parametrize("which", ["auxiliary", "side"])
+def test_update_thread_sharing_a_queue_with_the_backward_pass(hip, which):
+    """PyTorch hands out streams from a pool of 32 per device: in a process that has created more, the engine's update stream can BE the
+    queue the backward pass puts its weight-gradient products (or its edge re-gather) on, and update_pe's host thread then interleaves its
+    launch sequences with the autograd thread's on one queue.  Forced here by handing the engine that very stream: the iteration must not
+    depend on it (native scratch buffers are per host thread: lstep_amd._native._workspace).  Round 4 saw the unforced case twice behind
+    the whole suite, once as a wrong gradient, once as a GPU fault in the segment join."""
+    from lstep_amd import model as lm
+
+    def share(eng):
+        eng._update_stream = (lm._aux_stream if which == "auxiliary" else lm._side_stream)(torch.device(DEV))
+    for _ in range(3):
+        _rng_engine_scenario(hip, "time_interval_aware", tweak=share)
