@@ -217,6 +217,35 @@ def launch_ranks(gpus: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def rccl_graph_probe(world: int, rank: int, local_rank: int):
+    """Multi-rank runs replay ONE captured graph per step with the RCCL collectives inside (``parallel.GraphedDistStep``) -- something a
+    one-GPU box can only rehearse with a single rank.  Before this rank touches its GPU, a child process per rank captures and replays
+    the same kinds of collectives across the N ranks (tools/rccl_graph_probe.py).  Returns (ok, note): on anything but a clean exit the
+    bench keeps the device-driven iteration but issues it launch by launch, instead of failing the run on a capture it could never try."""
+    import subprocess
+    if world <= 1 and os.environ.get("LSTEP_FORCE_GRAPH_PROBE") != "1":
+        return True, "skipped (one rank)"
+    if os.environ.get("LSTEP_DIST_GRAPH", "1") == "0":
+        return False, "skipped (LSTEP_DIST_GRAPH=0)"
+    if os.environ.get("LSTEP_SKIP_GRAPH_PROBE") == "1" or os.environ.get("LSTEP_DIST_BACKEND", "nccl") != "nccl":
+        return True, "skipped"
+    env = dict(os.environ)
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 23))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
+        env.pop(k, None)       # (the child is a plain env:// rendezvous on its own port, not a member of the parent's elastic job)
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "rccl_graph_probe.py")]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("LSTEP_GRAPH_PROBE_TIMEOUT", "240")))
+    except subprocess.TimeoutExpired:
+        return False, "timeout"
+    if r.returncode == 0:
+        return True, "ok"
+    tail = (r.stderr or r.stdout or "").strip().splitlines()
+    return False, f"exit code {r.returncode}" + (f": {tail[-1][:160]}" if tail else "")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,6 +284,7 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {args.gpus}` (it starts its own ranks) "
                          f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    probe_ok, probe_note = rccl_graph_probe(world, rank, local_rank)      # (a child process: before THIS process initialises HIP)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if os.environ.get("LSTEP_SINGLE_DEVICE") == "1":   # rehearsal of the N > 1 plumbing on a one-GPU box (with LSTEP_DIST_BACKEND=gloo)
         local_rank = 0
@@ -287,6 +317,15 @@ def main():
     else:
         from lstep_amd.workload import prefill_distributed
         runner = DistributedLstep(eng, opt)
+        if world > 1:       # every rank takes the same path: the graph only if every rank's probe came back clean
+            flag = torch.tensor([1 if probe_ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and probe_ok:
+                probe_ok, probe_note = False, "another rank's probe failed"
+        if not probe_ok:
+            runner.use_step_graph = False
+            if rank == 0:
+                print(f"bench.py: captured-collective probe: {probe_note}: the multi-GPU iteration is issued launch by launch", file=sys.stderr)
         prefill_distributed(runner, seed=0)
     B = wl.batch
     need = (args.warmup + args.steps + 10) * B * world      # (+10: the launch-by-launch iterations that time the gather kernel in graph mode)
@@ -409,6 +448,7 @@ def main():
                                          for k, v in agg.items()},
                 "timing": "HIP events around every collective of the launch-by-launch iterations run after the timed region (rank 0)"}
         comm["timed_steps_are_graph_replays"] = bool(getattr(runner, "use_step_graph", False)) and args.mode == "train"
+        comm["captured_collective_probe"] = probe_note
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

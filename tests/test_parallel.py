@@ -608,3 +608,49 @@ def test_bench_default_workload_by_gpu_count():
     bound, peak, split = mod.gather_roofline_bound(count, 20, 2000, 184, 125_235)         # Enron shape: node / PE tables in L2, edge rows in the Infinity Cache
     assert bound in ("l2", "infinity_cache") and 8000.0 < peak < 34500.0 and split["l2"] > split["infinity_cache"] > 0
     assert abs(sum(split.values()) - mod.gather_algorithmic_bytes(count, 20, 2000)) < 1e-6
+
+
+def test_bench_captured_collective_probe_decisions(monkeypatch, tmp_path):
+    """``bench.py --gpus N`` decides between the whole-step graph and the launch-by-launch iteration from a child-process probe
+    (tools/rccl_graph_probe.py); the decision logic without a GPU: one rank skips it, an opt-out skips it, a child that fails or never
+    answers turns the graph off instead of failing the run."""
+    import importlib.util
+    import subprocess
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    spec = importlib.util.spec_from_file_location("lstep_bench_probe", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for k in ("LSTEP_FORCE_GRAPH_PROBE", "LSTEP_DIST_GRAPH", "LSTEP_SKIP_GRAPH_PROBE", "LSTEP_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    assert mod.rccl_graph_probe(1, 0, 0) == (True, "skipped (one rank)")
+    monkeypatch.setenv("LSTEP_DIST_GRAPH", "0")
+    assert mod.rccl_graph_probe(2, 0, 0)[0] is False
+    monkeypatch.delenv("LSTEP_DIST_GRAPH")
+    monkeypatch.setenv("LSTEP_SKIP_GRAPH_PROBE", "1")
+    assert mod.rccl_graph_probe(2, 0, 0) == (True, "skipped")
+    monkeypatch.delenv("LSTEP_SKIP_GRAPH_PROBE")
+    seen = {}
+
+    class Done:
+        def __init__(self, rc, err=""):
+            self.returncode, self.stdout, self.stderr = rc, "", err
+
+    def fake_run(cmd, env=None, **kw):
+        seen["env"] = env
+        seen["cmd"] = cmd
+        return Done(seen["rc"], seen.get("err", ""))
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("MASTER_PORT", "29700")
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    seen["rc"] = 0
+    assert mod.rccl_graph_probe(4, 3, 3) == (True, "ok")
+    assert seen["env"]["RANK"] == "3" and seen["env"]["WORLD_SIZE"] == "4" and seen["env"]["MASTER_PORT"] == "29723"
+    assert "TORCHELASTIC_USE_AGENT_STORE" not in seen["env"] and seen["cmd"][-1].endswith(os.path.join("tools", "rccl_graph_probe.py"))
+    seen["rc"], seen["err"] = 3, "rccl_graph_probe: rank 3: wrong values in replay 1\n"
+    ok, note = mod.rccl_graph_probe(4, 3, 3)
+    assert ok is False and "exit code 3" in note and "wrong values" in note
+
+    def hang(cmd, env=None, timeout=None, **kw):
+        raise subprocess.TimeoutExpired(cmd, timeout)
+    monkeypatch.setattr(subprocess, "run", hang)
+    assert mod.rccl_graph_probe(4, 0, 0) == (False, "timeout")

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Does this torch / RCCL replay collectives from a HIP graph ACROSS RANKS?  ``bench.py --gpus N`` (N > 1) runs this as a child process of
+every rank BEFORE the rank touches its GPU: the multi-GPU iteration is one captured graph with its RCCL collectives inside
+(``lstep_amd.parallel.GraphedDistStep``), which this pool could only ever rehearse with ONE rank (tools/rccl_capture_probe.py), where RCCL
+short-cuts every collective into a copy.  The probe captures the same kinds of calls the step makes -- all_gather_into_tensor,
+reduce_scatter_tensor, all_reduce and a synchronous all_to_all_single on the capturing stream, a synchronous all_gather on a forked side
+stream, ``capture_error_mode="thread_local"`` -- replays the graph three times on changing inputs and checks every result.  Exit code 0 =
+safe to capture the step; anything else (a wrong value, an exception, a crash, the parent's timeout) makes the bench fall back to the
+launch-by-launch device-driven iteration instead of failing the run.
+
+env: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT (the parent passes its own port + an offset)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+
+def main() -> int:
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if os.environ.get("LSTEP_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)
+    n, m = 1 << 16, 1 << 10
+    base = torch.zeros(1, dtype=torch.float32, device=dev)
+    x = torch.empty(n, dtype=torch.float32, device=dev)
+    out = torch.zeros(world * n, dtype=torch.float32, device=dev)
+    rs = torch.zeros(n, dtype=torch.float32, device=dev)
+    ar = torch.zeros(n, dtype=torch.float32, device=dev)
+    a_in = torch.empty(world * m, dtype=torch.float32, device=dev)
+    a_out = torch.zeros(world * m, dtype=torch.float32, device=dev)
+    side_out = torch.zeros(world * n, dtype=torch.float32, device=dev)
+    blocks = torch.arange(world, dtype=torch.float32, device=dev).repeat_interleave(m)
+    side = torch.cuda.Stream(device=dev)
+
+    def body():
+        x.copy_((base + rank).expand(n))
+        dist.all_gather_into_tensor(out, x)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                     # (a synchronous all_gather on a side stream that joined the capture)
+            dist.all_gather_into_tensor(side_out, x * 3.0)
+        z = out * 2.0
+        dist.reduce_scatter_tensor(rs, z)
+        ar.copy_(rs)
+        dist.all_reduce(ar)
+        a_in.copy_(blocks + (rank * world) + base)
+        dist.all_to_all_single(a_out, a_in)
+        torch.cuda.current_stream().wait_stream(side)
+
+    # the collectives once launch by launch (communicator set-up), then captured
+    body()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        body()
+    ranks = torch.arange(world, dtype=torch.float32, device=dev)
+    for it in range(3):
+        b = float(10 * it + 1)
+        base.fill_(b)
+        for t in (out, rs, ar, a_out, side_out):
+            t.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        ok = bool((out.view(world, n) == (ranks + b)[:, None]).all())
+        ok &= bool((side_out.view(world, n) == 3.0 * (ranks + b)[:, None]).all())
+        ok &= bool((rs == 2.0 * world * (b + rank)).all())
+        ok &= bool((ar == 2.0 * world * (world * b + world * (world - 1) / 2.0)).all())
+        ok &= bool((a_out.view(world, m) == (ranks * world + rank + b)[:, None]).all())
+        if not ok:
+            print(f"rccl_graph_probe: rank {rank}: wrong values in replay {it}", file=sys.stderr)
+            return 3
+    dist.barrier()
+    if rank == 0:
+        print(f"rccl_graph_probe: {world} rank(s): captured collectives replay correctly")
+    sys.stdout.flush()
+    os._exit(0)        # (no communicator teardown: it can block behind the watchdog thread; the process has nothing left to do)
+
+
+if __name__ == "__main__":
+    try:
+        code = main()
+    except Exception as e:  # noqa: BLE001
+        print(f"rccl_graph_probe: {type(e).__name__}: {e}", file=sys.stderr)
+        code = 2
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code)
