@@ -498,6 +498,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "host_ms_per_step": host_s / args.steps * 1e3,      # this rank's Python thread issuing one timed step (graph replay: input copies + one launch)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

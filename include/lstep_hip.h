@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 34
+#define LSTEP_ABI_VERSION 35
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -267,6 +267,22 @@ int lstep_group_by_key(const int32_t* keys, int64_t n, int32_t key_bits, int32_t
 int64_t lstep_linear_wgrad_workspace(int64_t m, int32_t n, int32_t k);
 int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t m, int32_t n, int32_t k, float* dw,
                        int32_t ld_dw, float* db, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The same for several layers at once: ONE partial launch and ONE reduction launch for up to 8 products (the four of the dense tail, the
+ * two of the link predictor: models/LSTEP.py:56-72, models/modules.py:52-68), instead of a dependent launch pair per product.  Results are
+ * those of lstep_linear_wgrad product by product (same tiling, same summation order); products whose operands do not allow the 16-byte
+ * loads of the batched kernel are launched on their own inside the call.  workspace: lstep_linear_wgrad_batch_workspace(count, descs)
+ * bytes, 16-byte aligned. */
+typedef struct lstep_wgrad_desc {
+    const float* dy;   /* [m, n], row stride ldy */
+    const float* x;    /* [m, k], row stride ldx */
+    float* dw;         /* [n, k], row stride ld_dw */
+    float* db;         /* [n] or NULL */
+    int64_t m;
+    int32_t n, k, ldy, ldx, ld_dw, reserved;
+} lstep_wgrad_desc_t;
+int64_t lstep_linear_wgrad_batch_workspace(int32_t count, const lstep_wgrad_desc_t* descs);
+int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t* descs, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* A / N / C / O -- every dense layer after the gather stage in one launch (fp32 matrix cores), for the model's default widths
  * (feature / PE dim 172, time dim 100: 16-aligned channels 272 / 176 / 176).  Inputs: x_edge [m, ld_edge], x_pe [m, ld_pe] (gather

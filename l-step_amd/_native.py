@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 34
+ABI_VERSION = 35
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -32,6 +32,12 @@ class CsrStruct(C.Structure):
     """``lstep_csr_t``"""
     _fields_ = [("indptr", C.c_void_p), ("nbr", C.c_void_p), ("eid", C.c_void_p), ("ts", C.c_void_p),
                 ("num_rows", C.c_int64), ("nnz", C.c_int64), ("max_degree", C.c_int64)]
+
+
+class WgradDesc(C.Structure):
+    """``lstep_wgrad_desc_t`` (include/lstep_hip.h): one product of ``lstep_linear_wgrad_batch``."""
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("m", C.c_int64), ("n", C.c_int32),
+                ("k", C.c_int32), ("ldy", C.c_int32), ("ldx", C.c_int32), ("ld_dw", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RingRef(C.Structure):
@@ -176,6 +182,8 @@ SIGNATURES = {
     "lstep_sort_live": (C.c_int, [_P, _I64, _I32, _P, _I64, _P, _P, C.POINTER(C.c_int64), _P]),
     "lstep_linear_wgrad_workspace": (_I64, [_I64, _I32, _I32]),
     "lstep_linear_wgrad": (C.c_int, [_P, _I32, _P, _I32, _I64, _I32, _I32, _P, _I32, _P, _P, _I64, _P]),
+    "lstep_linear_wgrad_batch_workspace": (_I64, [_I32, C.POINTER(WgradDesc)]),
+    "lstep_linear_wgrad_batch": (C.c_int, [_I32, C.POINTER(WgradDesc), _P, _I64, _P]),
     "lstep_small_gemm": (C.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, C.c_float, C.c_float, _P]),
     "lstep_tail_weights_pack": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lstep_tail_weights_unpack": (C.c_int, [_P, _P, _P, _P, _P, _P]),
@@ -363,6 +371,43 @@ def linear_wgrad(dy, x, want_bias: bool = True, out=None):
         check(lib.lstep_linear_wgrad(ptr(dy), dy.stride(0), ptr(x), x.stride(0), m, n, k, ptr(dw), k, ptr(db), ptr(ws), ws.numel(),
                                      current_stream()))
     return dw, db
+
+
+def linear_wgrad_batch(items):
+    """``lstep_linear_wgrad_batch``: ``items`` = [(dy, x, want_bias, out)] with the conventions of :func:`linear_wgrad` (``out`` = (dw, db)
+    destination tensors or None); returns [(dw, db)].  One partial launch and one reduction launch for all products."""
+    import torch
+
+    lib = load_library()
+    if not items:
+        return []
+    if len(items) > 8:
+        return linear_wgrad_batch(items[:8]) + linear_wgrad_batch(items[8:])
+    dev = items[0][0].device
+    descs = (WgradDesc * len(items))()
+    outs, keep = [], []
+    for i, (dy, x, want_bias, out) in enumerate(items):
+        m, n = dy.shape
+        k = x.shape[1]
+        if dy.stride(1) != 1 or x.stride(1) != 1 or x.shape[0] != m or dy.dtype != torch.float32 or x.dtype != torch.float32:
+            raise ValueError("linear_wgrad_batch: fp32 [m, n] / [m, k] operands with unit column stride expected")
+        dw = out[0] if out is not None and out[0] is not None else torch.empty((n, k), dtype=torch.float32, device=dev)
+        db = (out[1] if out is not None and out[1] is not None else torch.empty(n, dtype=torch.float32, device=dev)) if want_bias else None
+        if tuple(dw.shape) != (n, k) or not dw.is_contiguous() or (db is not None and (db.numel() != n or not db.is_contiguous())):
+            raise ValueError("linear_wgrad_batch: destination tensors must be contiguous [n, k] / [n]")
+        if m == 0:
+            dw.zero_()
+            if db is not None:
+                db.zero_()
+        descs[i] = WgradDesc(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, m, n, k,
+                             dy.stride(0) if m else n, x.stride(0) if m else k, k, 0)
+        outs.append((dw, db))
+        keep.append((dy, x))
+    need = int(lib.lstep_linear_wgrad_batch_workspace(len(items), descs))
+    ws = _workspace(dev, need)
+    with torch.cuda.device(dev):
+        check(lib.lstep_linear_wgrad_batch(len(items), descs, ptr(ws), ws.numel(), current_stream()))
+    return outs
 
 
 class PendingCounts:

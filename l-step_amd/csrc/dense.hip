@@ -138,21 +138,23 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const WgradPar
 // What that buys is depth: a wave tracks at most 63 vector-memory instructions in flight (vmcnt), and the dword pipeline above spends 16
 // of them per 4-row step.  Here a step costs 5-8 load instructions, so two blocks of 4 steps fit (see the loop below).
 // Slices that are not a multiple of 64 columns keep dword loads for their last 1-3 tiles (NR / KR), so no tile slot is wasted.
+// (the body is a device function: the one-product kernel and the batched kernel -- several products of one backward pass in ONE launch,
+// lstep_linear_wgrad_batch -- share it; `gid` is the wave's flat (slice, task) number inside its product, `bx / by / bz` the grid mapping
+// of the un-flattened plans)
 template <int NG, int NR, int KG, int KR, int DEPTH>
-__global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_partial_v2_body(const WgradParams& p, int gid, int bx, int by, int bz) {
     constexpr int NT = 4 * NG + NR, KTW = 4 * KG + KR;
     struct Operands { f32x4 a4[NG > 0 ? NG : 1]; float a1[NR > 0 ? NR : 1]; f32x4 b4[KG > 0 ? KG : 1]; float b1[KR > 0 ? KR : 1]; };
 
     const int lane = lane_id(), wave = wave_in_block();
     const int kk = lane >> 4, c = lane & 15;
-    int task = blockIdx.y * kWavesPerBlock + wave, slice = blockIdx.x;
+    int task = by * kWavesPerBlock + wave, slice = bx;
     if (p.k_blocks) {      // flattened: 4 consecutive (slice, task) pairs per workgroup
-        const int gid = blockIdx.x * kWavesPerBlock + wave;
         slice = gid / p.tasks;
         task = gid - slice * p.tasks;
         if (slice >= p.slices) return;
     }
-    const int nblock = p.k_blocks ? task / p.k_blocks : (int)blockIdx.z;
+    const int nblock = p.k_blocks ? task / p.k_blocks : bz;
     const int kblock = p.k_blocks ? task % p.k_blocks : task;
     const int n0 = nblock * (NT * 16);
     const int k0 = kblock * (KTW * 16);
@@ -312,6 +314,32 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const Wgrad
     }
 }
 
+template <int NG, int NR, int KG, int KR, int DEPTH>
+__global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_kernel(const WgradParams p) {
+    wgrad_partial_v2_body<NG, NR, KG, KR, DEPTH>(p, (int)blockIdx.x * kWavesPerBlock + wave_in_block(), (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several products in one launch (the 6 x 4-tile plan only): the waves of all products are numbered in one flat range, product i owns
+// [first_wave[i], first_wave[i + 1]).  A training step's six weight gradients are six dependent (partial, reduce) launch pairs otherwise --
+// twelve graph nodes of ~4 us dispatch latency each on the critical chain of the small-batch step, and six kernels whose tails cannot
+// overlap at the large one.
+constexpr int kWgradBatchMax = 8;
+struct WgradBatch {
+    WgradParams p[kWgradBatchMax];
+    int32_t first_wave[kWgradBatchMax + 1];
+    int32_t count;
+};
+__global__ __launch_bounds__(kBlock, 1) void wgrad_partial_v2_batch_kernel(const WgradBatch b) {
+    const int gid = (int)blockIdx.x * kWavesPerBlock + wave_in_block();
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < kWgradBatchMax; ++j)
+        if (j < b.count && gid >= b.first_wave[j]) i = j;
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (gid >= b.first_wave[b.count]) return;
+    wgrad_partial_v2_body<1, 2, 1, 0, 5>(b.p[i], gid - b.first_wave[i], 0, 0, 0);
+}
+
 
 // ---- The same product with BOTH operands staged through LDS and shared by the workgroup (round 4).
 // The register-only kernels above give every WAVE its own operand stream: a 6 x 4-tile wave reads (96 + 64) columns per row for 24 MFMAs,
@@ -466,12 +494,11 @@ __global__ __launch_bounds__(kBlock, 2) void wgrad_lds_kernel(const WgradParams 
 // out = sum over the S partial blocks: 16 float4 columns x 16 partial groups per workgroup (every thread has S / 16 independent
 // 16-byte loads in flight; the first version gave each thread S / 4 and launched a quarter of the workgroups, 33 us per call for 48 MB
 // that sit in the Infinity Cache), groups added in a fixed order: deterministic
-__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t part_stride, int32_t num_part, int32_t n,
-                                                              int32_t k, int32_t bias_off, float* __restrict__ dw, int32_t ld_dw,
-                                                              float* __restrict__ db) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, int64_t part_stride, int32_t num_part, int32_t n, int32_t k,
+                                                  int32_t bias_off, float* __restrict__ dw, int32_t ld_dw, float* __restrict__ db, int64_t block) {
     __shared__ float4 sh[kBlock];
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int64_t e = ((int64_t)blockIdx.x * 16 + col) * 4;
+    const int64_t e = (block * 16 + col) * 4;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < part_stride) {
         const float* src = part + e;
@@ -497,6 +524,36 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __res
         if (i < nk) dw[(i / k) * ld_dw + (i % k)] = vals[j];
         else if (db != nullptr && i >= bias_off && i < bias_off + n) db[i - bias_off] = vals[j];
     }
+}
+
+__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part, int64_t part_stride, int32_t num_part, int32_t n,
+                                                              int32_t k, int32_t bias_off, float* __restrict__ dw, int32_t ld_dw,
+                                                              float* __restrict__ db) {
+    wgrad_reduce_body(part, part_stride, num_part, n, k, bias_off, dw, ld_dw, db, (int64_t)blockIdx.x);
+}
+
+// the reductions of a batched launch (lstep_linear_wgrad_batch): product i owns the workgroups [first_block[i], first_block[i + 1])
+constexpr int kWgradReduceBatchMax = 8;
+struct WgradReduceItem {
+    const float* part;
+    float* dw;
+    float* db;
+    int64_t part_stride;
+    int32_t num_part, n, k, bias_off, ld_dw;
+};
+struct WgradReduceBatch {
+    WgradReduceItem it[kWgradReduceBatchMax];
+    int32_t first_block[kWgradReduceBatchMax + 1];
+    int32_t count;
+};
+__global__ __launch_bounds__(kBlock) void wgrad_reduce_batch_kernel(const WgradReduceBatch b) {
+    const int blk = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < kWgradReduceBatchMax; ++j)
+        if (j < b.count && blk >= b.first_block[j]) i = j;
+    const WgradReduceItem& r = b.it[i];
+    wgrad_reduce_body(r.part, r.part_stride, r.num_part, r.n, r.k, r.bias_off, r.dw, r.ld_dw, r.db, (int64_t)(blk - b.first_block[i]));
 }
 
 static inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
@@ -558,7 +615,12 @@ static WgradPlan wgrad_plan(int64_t m, int32_t n, int32_t k, bool allow_small = 
         const int tasks = n_blocks * pl.k_blocks;
         pl.tasks = tasks;
         pl.gz = pl.gy = 1;
-        int splits = 1024 / tasks;       // one wave per SIMD, no idle slot: waves are numbered over (slice, task)
+        static const int target_waves = [] {       // tuning knob (tools/wgrad_bench.py): waves per launch, default one per SIMD
+            const char* e = getenv("LSTEP_WGRAD_WAVES");
+            const int v = e ? atoi(e) : 0;
+            return v >= 256 && v <= 8192 ? v : 1024;
+        }();
+        int splits = target_waves / tasks;       // one wave per SIMD, no idle slot: waves are numbered over (slice, task)
         if (splits < 1) splits = 1;
         pl.rows_per_wg = round_up((m + splits - 1) / splits, 40);   // whole ping-pong rounds (2 blocks x 5 steps x 4 rows)
         if (pl.rows_per_wg < 40) pl.rows_per_wg = 40;
@@ -637,6 +699,63 @@ extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), block, 0, s, (const float*)workspace, pl.part_stride, (int32_t)pl.splits, n, k,
                        pl.bias_off, dw, ld_dw, db);
     return check_launch("lstep_linear_wgrad");
+}
+
+static inline int64_t align256f(int64_t bytes) { return (bytes + 255) / 256 * 256; }
+
+extern "C" int64_t lstep_linear_wgrad_batch_workspace(int32_t count, const lstep_wgrad_desc_t* descs) {
+    if (count <= 0 || !descs) return 0;
+    int64_t total = 0;
+    for (int i = 0; i < count; ++i) total += align256f(lstep_linear_wgrad_workspace(descs[i].m, descs[i].n, descs[i].k));
+    return total;
+}
+
+extern "C" int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t* descs, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (count < 0 || count > kWgradBatchMax) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad_batch: 0 .. %d products per call", kWgradBatchMax);
+    if (count == 0) return LSTEP_OK;
+    if (!descs || !workspace) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad_batch: NULL pointer");
+    if (((uintptr_t)workspace & 15) != 0) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad_batch: workspace must be 16-byte aligned");
+    if (workspace_bytes < lstep_linear_wgrad_batch_workspace(count, descs)) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad_batch: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    static const bool no_wide = getenv("LSTEP_WGRAD_DWORD") != nullptr;
+    static const bool no_batch = getenv("LSTEP_WGRAD_NO_BATCH") != nullptr;      // A/B switch: one (partial, reduce) launch pair per product
+    WgradBatch pb;
+    WgradReduceBatch rb;
+    pb.count = rb.count = 0;
+    pb.first_wave[0] = rb.first_block[0] = 0;
+    char* ws = (char*)workspace;
+    for (int i = 0; i < count; ++i) {
+        const lstep_wgrad_desc_t& d = descs[i];
+        const int64_t bytes = align256f(lstep_linear_wgrad_workspace(d.m, d.n, d.k));
+        if (d.m < 0 || d.n <= 0 || d.k <= 0 || d.ldy < d.n || d.ldx < d.k || d.ld_dw < d.k) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad_batch: bad sizes in product %d", i);
+        if (!d.dw || (d.m > 0 && (!d.dy || !d.x))) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad_batch: NULL pointer in product %d", i);
+        const bool wide = !no_wide && d.n % 4 == 0 && d.k % 4 == 0 && d.n >= 4 && d.k >= 4 && d.ldy % 4 == 0 && d.ldx % 4 == 0 &&
+                          ((uintptr_t)d.dy & 15) == 0 && ((uintptr_t)d.x & 15) == 0;
+        const WgradPlan pl = wgrad_plan(d.m, d.n, d.k, wide);
+        if (no_batch || !pl.small || d.m == 0) {      // plans the batched kernel does not cover: their own launches, same stream, same result
+            if (int rc = lstep_linear_wgrad(d.dy, d.ldy, d.x, d.ldx, d.m, d.n, d.k, d.dw, d.ld_dw, d.db, ws, bytes, stream)) return rc;
+        } else {
+            WgradParams& p = pb.p[pb.count];
+            p.dy = d.dy; p.x = d.x; p.part = (float*)ws;
+            p.m = d.m; p.rows_per_wg = pl.rows_per_wg; p.part_stride = pl.part_stride;
+            p.ldy = d.ldy; p.ldx = d.ldx; p.n = d.n; p.k = d.k; p.bias_off = pl.bias_off; p.k_blocks = pl.k_blocks;
+            p.tasks = pl.tasks; p.slices = pl.splits;
+            pb.first_wave[pb.count + 1] = pb.first_wave[pb.count] + pl.splits * pl.tasks;
+            ++pb.count;
+            WgradReduceItem& r = rb.it[rb.count];
+            r.part = (const float*)ws; r.dw = d.dw; r.db = d.db; r.part_stride = pl.part_stride;
+            r.num_part = pl.splits; r.n = d.n; r.k = d.k; r.bias_off = pl.bias_off; r.ld_dw = d.ld_dw;
+            rb.first_block[rb.count + 1] = rb.first_block[rb.count] + (int32_t)((pl.part_stride / 4 + 15) / 16);
+            ++rb.count;
+        }
+        ws += bytes;
+    }
+    if (pb.count > 0) {
+        const unsigned waves = (unsigned)pb.first_wave[pb.count];
+        hipLaunchKernelGGL(wgrad_partial_v2_batch_kernel, dim3((waves + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, pb);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)rb.first_block[rb.count]), dim3(kBlock), 0, s, rb);
+    }
+    return check_launch("lstep_linear_wgrad_batch");
 }
 
 // ---- small dense products between weight-sized matrices (<= a few hundred rows / columns): the weight composition of the dense

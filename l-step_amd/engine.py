@@ -557,6 +557,9 @@ class GraphedTrainStep:
         from .model import _no_gc, new_graph
         graph = new_graph(self)
         self.hyper = self._hyper()
+        dot = os.environ.get("LSTEP_GRAPH_DOT")       # diagnostics: the captured graph's nodes and edges as a DOT file (tools/graph_dot_summary.py)
+        if dot:
+            graph.enable_debug_mode()
         with _no_gc(), torch.cuda.graph(graph):
             with eng.aux_streams():
                 self.out = eng._train_iteration(self.optimizer, batch_idx, self.src, self.dst, self.ts, self.eid, self.neg, None, None)
@@ -564,6 +567,8 @@ class GraphedTrainStep:
             if eng.use_aux:
                 main.wait_stream(_aux_stream(eng.device))      # (the backward pass's side stream was joined by join_aux_stream already)
             main.wait_stream(eng._update_stream)
+        if dot:
+            graph.debug_dump(dot)
         self.graph = graph
         graph.replay()      # capturing records the launches without running them: this replay IS the iteration
 

@@ -542,6 +542,7 @@ def wait_aux_param_update(dev):
         torch.cuda.current_stream(dev).wait_event(ev)
 
 
+_PENDING_HEAD_WGRADS = {}   # device -> (items, results): the link predictor's two weight-gradient products waiting for the dense tail's batched launch
 _DEFERRED = {}     # device -> callables: auxiliary-stream work whose launch is postponed until the critical kernels are out
 
 
@@ -602,10 +603,15 @@ class _FusedTail(torch.autograd.Function):
         gb = ctx.grad_buffers or [None] * 8
 
         def weight_gradients():
-            gW1, gb1 = nat.linear_wgrad(d_h1, x_edge[:, :w1t.shape[0]], out=(gb[0], gb[1]))
-            gWn1, gbn1 = nat.linear_wgrad(d_p1, x_pe[:, :Cp], out=(gb[2], gb[3]))
-            gWq, gbq = nat.linear_wgrad(d_z, cat2, out=(gb[4], gb[5]))
-            gWall, gconst = nat.linear_wgrad(g_out, cat1, out=(gb[6], gb[7]))
+            # the four products in ONE (partial, reduce) launch pair (lstep_linear_wgrad_batch); a link predictor that ran its backward just
+            # before (``_Head.backward``, engine mode) has left its two products here to ride along
+            riders = _PENDING_HEAD_WGRADS.pop(dev, None)
+            items = [(d_h1, x_edge[:, :w1t.shape[0]], True, (gb[0], gb[1])), (d_p1, x_pe[:, :Cp], True, (gb[2], gb[3])),
+                     (d_z, cat2, True, (gb[4], gb[5])), (g_out, cat1, True, (gb[6], gb[7]))]
+            res = nat.linear_wgrad_batch(items + (riders[0] if riders else []))
+            if riders:
+                riders[1].extend(res[4:])
+            (gW1, gb1), (gWn1, gbn1), (gWq, gbq), (gWall, gconst) = res[:4]
             return gW1, gb1, gWn1, gbn1, gWq, gbq, gWall, gconst
 
         if ctx.aux is not None:
@@ -686,9 +692,11 @@ class _Head(torch.autograd.Function):
         with torch.cuda.device(dev):
             nat.check(lib.lstep_head_bwd(nat.ptr(d_logits), nat.ptr(h), n, nat.ptr(wt), nat.ptr(w2p), nat.ptr(d_emb), nat.ptr(d_h),
                                          nat.ptr(d_hsum), nat.ptr(dw2_part), nat.current_stream()))
+        head_items = [(d_hsum, emb[:n], False, None), (d_h, emb[n:3 * n], True, None)]
+        done = []        # filled by the dense tail's batched launch when it takes the two products along (engine mode)
+
         def parameter_gradients():
-            g_first, _ = nat.linear_wgrad(d_hsum, emb[:n], want_bias=False)
-            g_second, g_b1 = nat.linear_wgrad(d_h, emb[n:3 * n])
+            (g_first, _), (g_second, g_b1) = done if done else nat.linear_wgrad_batch(head_items)
             g_fc1 = torch.cat([g_first[:half, :half], g_second[:half, :half]], dim=1)
             col = dw2_part.sum(dim=0)                        # [:172] d fc2.weight, [172] d fc2.bias (lstep_head_bwd)
             return g_fc1, g_b1[:half].contiguous(), col[:half].reshape(1, half), col[half:half + 1]
@@ -703,6 +711,9 @@ class _Head(torch.autograd.Function):
         params = ctx.params
 
         def on_aux():
+            pend = _PENDING_HEAD_WGRADS.get(torch.device(dev))
+            if pend is not None and pend[1] is done:      # (no dense tail took the products along: they are launched here)
+                _PENDING_HEAD_WGRADS.pop(torch.device(dev))
             with torch.cuda.stream(aux):
                 aux.wait_event(ready)
                 for p, g in zip(params, parameter_gradients()):
@@ -710,6 +721,10 @@ class _Head(torch.autograd.Function):
             for t in (d_h, d_hsum, emb, h, d_logits, dw2_part):
                 t.record_stream(aux)
 
+        if os.environ.get("LSTEP_WGRAD_NO_RIDE") != "1":
+            # the dense tail's backward runs next on this stream and launches its four products on the auxiliary stream behind an event
+            # recorded after ITS kernel, i.e. after this one too: the two products here join that launch (one graph node instead of three)
+            _PENDING_HEAD_WGRADS[torch.device(dev)] = (head_items, done)
         _defer(dev, on_aux)
         return d_emb, None, None, None, None, None, None, None
 

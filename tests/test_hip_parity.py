@@ -773,6 +773,33 @@ def test_linear_wgrad_vs_float64(hip, m, n, k):
     assert float((dw2.double() - wide_y[:, 16:16 + n].double().t() @ wide_x[:, :k].double()).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("m", [600, 4096, 49152])
+def test_linear_wgrad_batch_is_the_products_one_by_one(hip, m):
+    """lstep_linear_wgrad_batch (the four products of the dense tail and the two of the link predictor in ONE partial launch and ONE
+    reduction launch) returns, product by product, the bits of lstep_linear_wgrad -- same tiling, same slices, same order of summation --
+    including a product that falls back to its own launches inside the call (operands that rule out 16-byte loads) and destination buffers
+    handed in by the caller."""
+    from lstep_amd import _native as nat
+    g = torch.Generator().manual_seed(m)
+    shapes = [(272, 272, True), (176, 272, True), (176, 352, True), (176, 624, True), (176, 176, False), (176, 352, True), (64, 50, True)]
+    items, alone = [], []
+    for i, (n, k, bias) in enumerate(shapes):
+        rows = m if i != 4 else m // 3
+        dy = torch.randn(rows, n, generator=g).to(DEV)
+        x = torch.randn(rows, k + 16, generator=g).to(DEV)[:, :k]        # (a column block of a wider matrix)
+        out = (torch.full((n, k), float("nan"), device=DEV), torch.full((n,), float("nan"), device=DEV)) if i == 1 else None
+        items.append((dy, x, bias, out))
+        alone.append(nat.linear_wgrad(dy, x, want_bias=bias))
+    got = nat.linear_wgrad_batch(items)
+    assert got[1][0] is items[1][3][0] and got[1][1] is items[1][3][1]
+    for (dw, db), (rw, rb), (n, k, bias) in zip(got, alone, shapes):
+        assert torch.equal(dw, rw), (n, k)
+        assert (db is None and rb is None) if not bias else torch.equal(db, rb)
+    assert nat.linear_wgrad_batch([]) == []
+    nine = nat.linear_wgrad_batch(items[:3] * 3)                          # more than eight products: split into calls of eight
+    assert len(nine) == 9 and all(torch.equal(nine[i][0], alone[i % 3][0]) for i in range(9))
+
+
 def test_fused_dense_kernels_match_library_path(hip, monkeypatch):
     """The single-launch dense tail / predictor / update_pe kernels (lstep_tail_fwd/bwd, lstep_head_fwd/bwd, lstep_update_rows,
     lstep_link_loss) against the same model run through the library-GEMM path (LSTEP_TORCH_* switches): outputs, every

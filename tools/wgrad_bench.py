@@ -38,3 +38,20 @@ for (m, n, k) in ((49152, 176, 272), (49152, 272, 272), (49152, 176, 352), (4915
     us_t = timeit(lambda: (torch.bmm(dy.view(c, m // c, -1).transpose(1, 2), x.view(c, m // c, -1)).sum(0), dy.sum(0)))
     fl = 2.0 * m * n * k
     print(f"m={m:6d} n={n:4d} k={k:4d}  max|err| {err:.2e} (torch {err_t:.2e}) bias {errb:.2e} | lstep {us:7.1f} us {fl / us / 1e6:6.1f} TF/s | torch bmm+sum {us_t:7.1f} us {fl / us_t / 1e6:6.1f} TF/s")
+
+# ---- the six products of a training step: one (partial, reduce) launch pair each against ONE batched pair (lstep_linear_wgrad_batch)
+print("six products of a step, one by one vs batched (us):")
+for m in (600, 1800, 12288, 49152):
+    shapes = [(272, 272), (176, 272), (176, 352), (176, 624), (176, 176), (176, 352)]
+    items = [(torch.randn(m if i != 4 else m // 3, n, device=dev), torch.randn(m if i != 4 else m // 3, k, device=dev), True, None) for i, (n, k) in enumerate(shapes)]
+    outs = [(torch.empty(n, k, device=dev), torch.empty(n, device=dev)) for (n, k) in shapes]
+    items = [(a, b, c, o) for (a, b, c, _), o in zip(items, outs)]
+    t_seq = timeit(lambda: [nat.linear_wgrad(a, b, out=o) for a, b, _, o in items])
+    t_bat = timeit(lambda: nat.linear_wgrad_batch(items))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        [nat.linear_wgrad(a, b, out=o) for a, b, _, o in items]
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        nat.linear_wgrad_batch(items)
+    print(f"  m = {m:6d}: launch by launch {t_seq:7.1f} / {t_bat:7.1f}   graph replay {timeit(g.replay):7.1f} / {timeit(g2.replay):7.1f}")
