@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 35
+#define LSTEP_ABI_VERSION 36
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -406,6 +406,18 @@ int lstep_update_entries_p2_dev(const int32_t* order, const int32_t* seg, const 
  * deterministic lstep_segment_rows_sum path). */
 int lstep_scatter_add_rows(float* out, int32_t width, int32_t ld_out, const int32_t* slot, int64_t n, const float* rows, int32_t ld_rows,
                            void* stream);
+
+/* The gradient of the spliced PE rows of a SMALL batch in one launch, no sort and no atomics (backward of the PE channel of
+ * models/LSTEP.py:222-249 and of the PE loss rows, train_LSTEP_link_prediction.py:257-275, with respect to the filtered rows of train:230):
+ *   out[u, :width] = sum over the slots (b, j) with hits[b * K + j] == u of g_hit[b, :width]      (ascending b, j)
+ *                  + sum over the rows b with slot_of[ids[b]] == u of g_self[b, :width]             (ascending b)
+ * for u < num_rows; hits int32 [num_hits] (lstep_gather_aggregate_bwd's out_hits, -1 = no spliced row), slot_of / ids as everywhere.
+ * Either part may be absent (g_hit or g_self NULL).  Every output row is written whole.  Cost O(num_rows * (num_hits + num_self) / 64)
+ * scan steps: meant for the reference's own batch sizes (a few hundred batch nodes); the sorted path (lstep_sort_live_bounded +
+ * lstep_segment_rows_sum_live) serves everything else. */
+int lstep_spliced_grad_small(const int32_t* hits, int64_t num_hits, int32_t num_neighbors, const float* g_hit, int32_t ld_hit,
+                             const int32_t* slot_of, const int64_t* ids, int64_t num_self, const float* g_self, int32_t ld_self,
+                             int32_t width, float* out, int32_t ld_out, int64_t num_rows, void* stream);
 
 /* U2, row 0 -- what the PADDED slots of update_pe's sampled neighbourhoods scatter into row 0 (models/LSTEP.py:317-322):
  *   sum_r (number of zero entries of nbr[r, :]) * table[ids[r], :width]

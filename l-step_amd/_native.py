@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 35
+ABI_VERSION = 36
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -157,6 +157,7 @@ SIGNATURES = {
     "lstep_batch_prepare": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_padding_rows_finish": (C.c_int, [_P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_add_overflow": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _I32, _P]),
+    "lstep_spliced_grad_small": (C.c_int, [_P, _I64, _I32, _P, _I32, _P, _P, _I64, _P, _I32, _I32, _P, _I32, _I64, _P]),
     "lstep_scatter_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _P]),
     "lstep_residual_tanh_rows": (C.c_int, [_P, _I32, _P, _I64, _P, _I32, _P]),
     "lstep_group_by_key_workspace": (_I64, [_I64, _I32]),

@@ -876,6 +876,9 @@ def _segment_reduce_rows(mod, out: torch.Tensor, seg_of_entry: torch.Tensor, src
                                              n_hit, nat.ptr(out), P, 1 if accumulate else 0, None, nat.ptr(ws), ws_bytes, nat.current_stream()))
 
 
+SPLICE_SMALL_ROWS, SPLICE_SMALL_HITS = 2048, 65536     # up to this many spliced rows / gather slots the gradient is reduced by one scanning launch
+
+
 def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, self_groups=None):
     """Gradient of the spliced PE rows: every (row b, slot j) whose neighbour is spliced row u contributes g_pe[b, :P],
     every row b whose own node is spliced row u contributes g_self[b].  Grouped by u (``lstep_sort_live``) and reduced
@@ -886,6 +889,21 @@ def _reduce_spliced_gradient(mod, num_rows: int, hits, g_pe, self_slot, g_self, 
     lib = nat.load_library()
     K = hits.shape[1]
     P = mod.pe_dim
+    slot_of, ids = self_slot if isinstance(self_slot, tuple) else (None, None)
+    if (slot_of is not None and num_rows <= SPLICE_SMALL_ROWS and hits.numel() <= SPLICE_SMALL_HITS and (g_pe is not None or g_self is not None)
+            and os.environ.get("LSTEP_NO_SMALL_SPLICE") != "1"):
+        # the reference's own batch sizes: one launch that scans the hit list once per spliced row -- no compaction, no sort, no joins, no
+        # atomics (lstep_spliced_grad_small); at B = 200 the nine launches it replaces were the critical chain of the captured step
+        total = torch.empty((num_rows, P), dtype=torch.float32, device=hits.device)
+        with torch.cuda.device(hits.device):
+            nat.check(lib.lstep_spliced_grad_small(nat.ptr(hits), hits.numel() if g_pe is not None else 0, K, nat.ptr(g_pe),
+                                                   int(g_pe.stride(0)) if g_pe is not None else P, nat.ptr(slot_of), nat.ptr(ids),
+                                                   ids.numel() if g_self is not None else 0, nat.ptr(g_self),
+                                                   int(g_self.stride(0)) if g_self is not None else P, P, nat.ptr(total), P, num_rows,
+                                                   nat.current_stream()))
+        return total
+    if slot_of is not None:
+        self_slot = slot_of[ids]
     total = torch.zeros((num_rows, P), dtype=torch.float32, device=hits.device)
     if g_pe is not None:
         _segment_reduce_rows(mod, total, hits.reshape(-1), lambda o: (o // K).contiguous(), g_pe, accumulate=False, div=K)
@@ -1055,7 +1073,7 @@ class _GatherAggregate(torch.autograd.Function):
         if os.environ.get("LSTEP_WGRAD_LATE") != "1":
             _flush_deferred(dev)     # the critical kernel is out: now launch the postponed auxiliary-stream work
         if use_slot:
-            grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, slot_of[ids], g_self, ctx.self_groups)
+            grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, (slot_of, ids), g_self, ctx.self_groups)
         if g_w is None and slot_dot is not None:
             g_w = slot_dot.sum(dim=0)
         g_table = None

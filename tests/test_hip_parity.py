@@ -773,6 +773,59 @@ def test_linear_wgrad_vs_float64(hip, m, n, k):
     assert float((dw2.double() - wide_y[:, 16:16 + n].double().t() @ wide_x[:, :k].double()).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("U,B,K,hub", [(184, 600, 20, True), (1200, 1800, 20, False), (37, 96, 6, True), (2048, 3000, 20, False)])
+def test_spliced_row_gradient_small_batch_scan_vs_sorted_path_and_float64(hip, monkeypatch, U, B, K, hub):
+    """lstep_spliced_grad_small (one scanning launch: no sort, no atomics) against the general path (bounded sort + segment sums + scatter)
+    on the same hits and against a float64 index_add: hub rows (every batch node of an Enron-shaped batch collects dozens of slots),
+    rows nobody hits (written as zeros), a part that is absent, and run-to-run identical bits."""
+    from lstep_amd import model as lm
+    from lstep_amd import _native as nat
+    g = torch.Generator().manual_seed(U + B)
+    P = 172
+    num_nodes = 4 * U
+    ids = torch.randint(1, num_nodes, (B,), generator=g)
+    spliced = torch.randperm(num_nodes - 1, generator=g)[:U] + 1
+    slot_of = torch.full((num_nodes + 1,), -1, dtype=torch.int32)
+    slot_of[spliced] = torch.arange(U, dtype=torch.int32)
+    if hub:       # most query rows ARE spliced rows and most slots hit a handful of them
+        ids[: B * 3 // 4] = spliced[torch.randint(0, U, (B * 3 // 4,), generator=g)]
+        hits = torch.where(torch.rand(B, K, generator=g) < 0.6, torch.randint(0, max(1, U // 8), (B, K), generator=g), torch.full((B, K), -1)).to(torch.int32)
+    else:
+        hits = torch.where(torch.rand(B, K, generator=g) < 0.05, torch.randint(0, U, (B, K), generator=g), torch.full((B, K), -1)).to(torch.int32)
+    hits[:, 0][hits[:, 0] == U - 1] = -1
+    hits[hits == U - 1] = -1                                     # the last spliced row: no slot hits it (it may still be somebody's own row)
+    g_pe = torch.randn(B, P + 100 + 4, generator=g)             # (row-padded, as the dense tail hands it over)
+    g_self = torch.randn(B, 2 * 176, generator=g)
+    dev = dict(ids=ids.to(DEV), slot_of=slot_of.to(DEV), hits=hits.to(DEV), g_pe=g_pe.to(DEV), g_self=g_self.to(DEV))
+
+    class Mod:
+        pe_dim = P
+    want = torch.zeros(U + 1, P, dtype=torch.float64)
+    flat = hits.reshape(-1).long()
+    want.index_add_(0, torch.where(flat >= 0, flat, torch.full_like(flat, U)), g_pe[:, :P].double().repeat_interleave(K, dim=0))
+    own = slot_of[ids].long()
+    want_self = torch.zeros(U + 1, P, dtype=torch.float64)
+    want_self.index_add_(0, torch.where(own >= 0, own, torch.full_like(own, U)), g_self[:, :P].double())
+
+    def run(small, with_hits=True, with_self=True):
+        mod = Mod()
+        if small:
+            monkeypatch.delenv("LSTEP_NO_SMALL_SPLICE", raising=False)
+        else:
+            monkeypatch.setenv("LSTEP_NO_SMALL_SPLICE", "1")
+        return lm._reduce_spliced_gradient(mod, U, dev["hits"], dev["g_pe"] if with_hits else None, (dev["slot_of"], dev["ids"]),
+                                           dev["g_self"] if with_self else None)
+    a, b = run(True), run(False)
+    tol = 2e-5 * max(1.0, (B * K / U) ** 0.5)
+    assert float((a.double().cpu() - (want + want_self)[:U]).abs().max()) <= tol
+    assert float((a - b).abs().max()) <= tol                     # (different association of the same sums)
+    assert torch.equal(a, run(True))
+    assert float((run(True, with_self=False).double().cpu() - want[:U]).abs().max()) <= tol
+    assert float((run(True, with_hits=False).double().cpu() - want_self[:U]).abs().max()) <= tol
+    if not bool((hits == U - 1).any()) and not bool((own == U - 1).any()):
+        assert float(a[U - 1].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("m", [600, 4096, 49152])
 def test_linear_wgrad_batch_is_the_products_one_by_one(hip, m):
     """lstep_linear_wgrad_batch (the four products of the dense tail and the two of the link predictor in ONE partial launch and ONE
