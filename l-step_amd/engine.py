@@ -870,6 +870,24 @@ class LstepEngine:
             self.slot_of.index_fill_(0, batch_nodes, -1)   # (the dead tail is node 0, whose entry is -1 anyway)
             ring.tick()
             return out
+        if getattr(bb.neighbor_sampler, "sample_neighbor_strategy", "recent") != "recent":
+            # RNG-defined strategies: update_pe draws its neighbourhoods on the HOST (numpy's generator, torch CPU ops, pageable copies in
+            # both directions).  That work stays on this thread: the backward pass is enqueued first and runs on the GPU underneath it.
+            # (On a second host thread this path faulted the GPU twice and returned a wrong table twice in ~10 runs of the whole test
+            # suite -- never alone, never with the device sampler; the cause was not found)
+            try:
+                optimizer.zero_grad()
+                _backward_unit(loss)
+                bb.join_aux_stream()
+                with torch.cuda.stream(side):
+                    update_and_append()
+            finally:
+                ring.apply_advance()
+                main.wait_stream(side)
+            optimizer.step()
+            self.slot_of.index_fill_(0, batch_nodes, -1)
+            ring.tick()
+            return out
         err = []
 
         def worker():

@@ -27,3 +27,20 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"))
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _gpu_memory_log(request):
+    """LSTEP_TEST_MEMLOG=<file>: after every GPU test, one line with the device memory still free and what torch's caching allocator holds
+    (diagnostics for failures that only show behind the whole suite)."""
+    yield
+    path = os.environ.get("LSTEP_TEST_MEMLOG")
+    if not path or request.node.get_closest_marker("gpu") is None:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        return
+    free, total = torch.cuda.mem_get_info()
+    with open(path, "a") as f:
+        f.write(f"{request.node.nodeid} free_GB={free / 2**30:.2f} total_GB={total / 2**30:.1f} reserved_GB={torch.cuda.memory_reserved() / 2**30:.2f} "
+                f"allocated_GB={torch.cuda.memory_allocated() / 2**30:.2f}\n")
