@@ -378,7 +378,27 @@ def main():
     # first synchronous gradient sort of every call site, and above all the caching allocator, which needs about ten iterations of the
     # three-stream schedule before it stops calling hipMalloc); with the driver's `--warmup 5` they sat inside the timed region
     # (round-1 record: 4.35 ms/step over 20 steps whose last twelve ran at 3.6).
-    for i in range(-prime, 0):
+    pre_sink, pre_log, pre_steps = None, None, 0
+    if use_dist and getattr(runner, "use_step_graph", False) and args.mode == "train" and prime >= 6:
+        # Multi-GPU, graph mode: the launch-by-launch iterations that carry the timed events (gather kernel, every collective: the `comm`
+        # object) are taken from the pre-roll, BEFORE the step is captured.  Behind the replays they ended the process once (round 4, one
+        # rank over RCCL, pull form): the process group's watchdog thread queried an event "last recorded in a capturing stream" of a
+        # collective issued launch by launch after a capture -- not a risk to take on the line a multi-GPU run is measured by.
+        pre_steps = min(6, prime - 4)
+        pre_sink, runner.comm_log = [], []
+        model[0].gather_event_sink = pre_sink
+        runner.use_step_graph = False
+        for i in range(-prime, -prime + pre_steps):
+            step(i)
+            if i == -prime:        # (the very first training iteration sets communicators and lazy state up: not logged)
+                barrier()
+                pre_sink.clear()
+                runner.comm_log = []
+        barrier()
+        runner.use_step_graph = True
+        model[0].gather_event_sink = None
+        pre_log, runner.comm_log = runner.comm_log, None
+    for i in range(-prime + pre_steps, 0):
         step(i)
     for i in range(args.warmup):
         step(i)
@@ -416,7 +436,12 @@ def main():
             prev_h, prev_g = h, g
         print("[trace] per step host-enqueue ms / GPU ms since previous step end: " + " ".join(rows), file=sys.stderr)
     timing_note = "HIP events on the launch stream around every gather launch of the timed steps"
-    if not sink:
+    if not sink and pre_sink:
+        sink = pre_sink
+        runner.comm_log = pre_log
+        timing_note = (f"the timed steps are graph replays, which cannot carry timed events: HIP events around the gather launch (and around every "
+                       f"collective) of {pre_steps - 1} iterations issued launch by launch in the pre-roll, before the step was captured")
+    elif not sink:
         # the timed steps were graph replays (engine.GraphedTrainStep), and a graph cannot carry timed events: the gather kernel's launch
         # duration is measured the same way on the next batches of the same stream, issued launch by launch right after the timed region
         eng_g = getattr(runner, "use_step_graph", None)
@@ -446,7 +471,7 @@ def main():
         comm = {"host_ms_per_step": host_s / args.steps * 1e3, "device_driven": bool(getattr(runner, "device_driven", False)),
                 "collectives_per_step": {k: {"calls": v[0] / steps_logged, "bytes_per_call": v[1] // max(v[0], 1), "ms_per_call": v[2] / max(v[0], 1)}
                                          for k, v in agg.items()},
-                "timing": "HIP events around every collective of the launch-by-launch iterations run after the timed region (rank 0)"}
+                "timing": "HIP events around every collective of the launch-by-launch iterations " + ("of the pre-roll, before the step was captured" if pre_sink else "run after the timed region") + " (rank 0)"}
         comm["timed_steps_are_graph_replays"] = bool(getattr(runner, "use_step_graph", False)) and args.mode == "train"
         comm["captured_collective_probe"] = probe_note
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
