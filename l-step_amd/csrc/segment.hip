@@ -507,7 +507,7 @@ extern "C" int lstep_segment_rows_sum_live(const float* table, int32_t width, in
 // reference's own batch sizes (B = 200 / 600: U <= 1 200 rows, n <= 36 000 hits), where the general path -- compaction, a
 // single-workgroup sort, two segment sums with their joins, a scatter with atomics: nine dependent launches -- is the critical chain of the
 // whole captured step (round 4).  Fixed order of summation, no atomics.
-constexpr int kSpliceQueue = 128;      // queued row numbers per wave (a scan step adds at most 64)
+constexpr int kSpliceQueue = 16 * 64 + 64;      // queued row numbers per wave: a round of kSpliceAhead scan steps adds at most 64 each
 constexpr int kSpliceInFlight = 16;
 constexpr int kSpliceAhead = 16;       // scan steps (64 entries each) whose loads are in flight together
 __device__ __forceinline__ void splice_take(const int* __restrict__ q, int first, int count, const float* __restrict__ table, int ld, bool wa, int lane,
@@ -522,8 +522,7 @@ __device__ __forceinline__ void splice_take(const int* __restrict__ q, int first
             }
 #pragma unroll
             for (int i = 0; i < kSpliceInFlight; ++i) {
-                if ((g + i) >= count) break;
-                acc.x += x[i].x; acc.y += x[i].y; acc.z += x[i].z; acc.w += x[i].w;
+                if ((g + i) < count) { acc.x += x[i].x; acc.y += x[i].y; acc.z += x[i].z; acc.w += x[i].w; }      // (no early exit: x[] stays in registers)
             }
         }
     }
@@ -565,23 +564,18 @@ __global__ __launch_bounds__(kSpliceWaves * kWave) void spliced_grad_small_kerne
                 for (int a = 0; a < kSpliceAhead; ++a) key[a] = key[a] >= 0 ? slot_of[key[a]] : -2;
             }
 #pragma unroll
-            for (int a = 0; a < kSpliceAhead; ++a) {
+            for (int a = 0; a < kSpliceAhead; ++a) {       // (only the cheap part is unrolled: the keys stay in registers)
                 const bool hit = key[a] == (int32_t)u;
                 const unsigned long long m = __ballot(hit);
-                if (m == 0ull) continue;
                 const int64_t e = e0 + (int64_t)a * kWave + lane;
                 if (hit) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (int)(pass == 0 ? e / K : e);
                 qn += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= kWave) {            // the queue holds a round's matches at most (kSpliceAhead x 64) plus < 64 left over
+                splice_take(q, 0, qn, table, ld, wa, lane, acc);
                 __builtin_amdgcn_wave_barrier();
-                if (qn >= kWave) {        // fetch the first 64 queued rows, keep the rest (< 64) at the front of the queue
-                    splice_take(q, 0, kWave, table, ld, wa, lane, acc);
-                    const int rest = qn - kWave;
-                    const int moved = lane < rest ? q[kWave + lane] : 0;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < rest) q[lane] = moved;
-                    __builtin_amdgcn_wave_barrier();
-                    qn = rest;
-                }
+                qn = 0;
             }
         }
         if (qn > 0) splice_take(q, 0, qn, table, ld, wa, lane, acc);
