@@ -719,6 +719,15 @@ extern "C" int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t*
     hipStream_t s = (hipStream_t)stream;
     static const bool no_wide = getenv("LSTEP_WGRAD_DWORD") != nullptr;
     static const bool no_batch = getenv("LSTEP_WGRAD_NO_BATCH") != nullptr;      // A/B switch: one (partial, reduce) launch pair per product
+    // Products of more than this many rows keep their own launch pairs: one launch of all six 49 152-row products puts 6 144 waves of
+    // 240 registers on the chip at once, two per SIMD, for ~0.5 ms -- alone that is 5 % faster than six launches, but under it the step's
+    // other kernels (update_rows, gather backward) run at half speed and the c4 step does not gain (3.18 vs 3.15 ms; under the kernel
+    // tracer 7.5 vs 3.7 ms per iteration).  Small batches are launch-latency-bound: there the single pair is 2x faster.
+    static const int64_t batch_rows = [] {
+        const char* e = getenv("LSTEP_WGRAD_BATCH_ROWS");
+        const long long v = e ? atoll(e) : 0;
+        return (int64_t)(v > 0 ? v : 16384);
+    }();
     WgradBatch pb;
     WgradReduceBatch rb;
     pb.count = rb.count = 0;
@@ -732,7 +741,7 @@ extern "C" int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t*
         const bool wide = !no_wide && d.n % 4 == 0 && d.k % 4 == 0 && d.n >= 4 && d.k >= 4 && d.ldy % 4 == 0 && d.ldx % 4 == 0 &&
                           ((uintptr_t)d.dy & 15) == 0 && ((uintptr_t)d.x & 15) == 0;
         const WgradPlan pl = wgrad_plan(d.m, d.n, d.k, wide);
-        if (no_batch || !pl.small || d.m == 0) {      // plans the batched kernel does not cover: their own launches, same stream, same result
+        if (no_batch || !pl.small || d.m == 0 || d.m > batch_rows) {      // plans the batched kernel does not cover: their own launches, same stream, same result
             if (int rc = lstep_linear_wgrad(d.dy, d.ldy, d.x, d.ldx, d.m, d.n, d.k, d.dw, d.ld_dw, d.db, ws, bytes, stream)) return rc;
         } else {
             WgradParams& p = pb.p[pb.count];
