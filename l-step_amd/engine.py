@@ -452,7 +452,9 @@ class _LinkLoss(torch.autograd.Function):
         d_logits = torch.empty(2 * n, dtype=torch.float32, device=dev)
         g_rows = torch.empty((3 * n, P), dtype=torch.float32, device=dev)
         neg_slot = torch.empty(n, dtype=torch.int32, device=dev)
-        d_rows = torch.zeros_like(rows)
+        from .model import SPLICE_SMALL_HITS, SPLICE_SMALL_ROWS
+        small = rows.shape[0] <= SPLICE_SMALL_ROWS and 3 * n <= SPLICE_SMALL_HITS and os.environ.get("LSTEP_NO_SMALL_SPLICE") != "1"
+        d_rows = torch.empty_like(rows) if small else torch.zeros_like(rows)
         losses = torch.empty(3, dtype=torch.float32, device=dev)
         ws = nat._workspace(dev, int(lib.lstep_link_loss_workspace(n)))
         rows_c = rows.detach().contiguous()
@@ -461,7 +463,12 @@ class _LinkLoss(torch.autograd.Function):
                                           float(pe_weight), float(neg_weight), nat.ptr(predicts), nat.ptr(d_logits), nat.ptr(g_rows),
                                           nat.ptr(neg_slot), nat.ptr(losses), nat.ptr(ws), ws.numel(), nat.current_stream()))
             ld = int(d_rows.stride(0))
-            if groups is not None and groups[0].numel() == 2 * n:
+            if small:
+                # small batches: the per-occurrence rows are reduced by spliced row in ONE scanning launch, in occurrence order -- no
+                # grouping, no join, and none of the float atomics the negatives' scatter needs (lstep_spliced_grad_small writes every row)
+                nat.check(lib.lstep_spliced_grad_small(None, 0, 1, None, P, nat.ptr(slot_of), nat.ptr(ids), 3 * n, nat.ptr(g_rows), P, P,
+                                                       nat.ptr(d_rows), ld, rows.shape[0], nat.current_stream()))
+            elif groups is not None and groups[0].numel() == 2 * n:
                 seg, order = groups
                 sws, sws_bytes = nat.segment_workspace(dev, 2 * n, P)
                 nat.check(lib.lstep_segment_rows_sum(nat.ptr(g_rows), P, P, None, None, 0, nat.ptr(seg), nat.ptr(order), None, 2 * n,
