@@ -557,7 +557,10 @@ def test_group_by_key_vs_torch(hip):
     gen.manual_seed(3)
     # (up to 4096 keys the whole grouping is one workgroup: sizes at the edges of its three instantiations, limits inside and outside the key range)
     for n, hi, limit in ((1, 5, 5), (1000, 17, 10), (655360, 1_000_001, 1_000_001), (70000, 300, 300), (5000, 50, 0), (400, 184, 185), (512, 9, 4),
-                         (513, 9000, 9001), (1200, 9227, 9228), (2048, 3, 0), (2049, 100000, 50000), (4096, 7, 8), (4097, 7, 8)):
+                         (513, 9000, 9001), (1200, 9227, 9228), (2048, 3, 0), (2049, 100000, 50000), (4096, 7, 8), (4097, 7, 8),
+                         # 8 k - 24 k keys: one workgroup, entry index packed into the sorted word when the keys have <= 16 bits
+                         (8193, 184, 185), (16384, 9227, 9228), (16385, 65535, 60000), (24000, 9227, 9228), (24576, 3, 2), (24000, 200000, 200001),
+                         (24577, 9227, 9228)):
         keys = torch.randint(0, hi + 1, (n,), generator=gen, device=DEV, dtype=torch.int32)
         bits = max(1, int(hi).bit_length())
         sk, order, seg, uniq, (nu, n_below, nu_below) = nat.group_by_key(keys, bits, limit)
