@@ -379,7 +379,7 @@ def main():
     # three-stream schedule before it stops calling hipMalloc); with the driver's `--warmup 5` they sat inside the timed region
     # (round-1 record: 4.35 ms/step over 20 steps whose last twelve ran at 3.6).
     pre_sink, pre_log, pre_steps = None, None, 0
-    if use_dist and getattr(runner, "use_step_graph", False) and args.mode == "train" and prime >= 6:
+    if use_dist and args.mode == "train" and prime >= 6:
         # Multi-GPU, graph mode: the launch-by-launch iterations that carry the timed events (gather kernel, every collective: the `comm`
         # object) are taken from the pre-roll, BEFORE the step is captured.  Behind the replays they ended the process once (round 4, one
         # rank over RCCL, pull form): the process group's watchdog thread queried an event "last recorded in a capturing stream" of a
@@ -387,6 +387,7 @@ def main():
         pre_steps = min(6, prime - 4)
         pre_sink, runner.comm_log = [], []
         model[0].gather_event_sink = pre_sink
+        graph_flag = getattr(runner, "use_step_graph", False)      # (False: the captured-collective probe failed or LSTEP_DIST_GRAPH=0)
         runner.use_step_graph = False
         for i in range(-prime, -prime + pre_steps):
             step(i)
@@ -395,7 +396,7 @@ def main():
                 pre_sink.clear()
                 runner.comm_log = []
         barrier()
-        runner.use_step_graph = True
+        runner.use_step_graph = graph_flag
         model[0].gather_event_sink = None
         pre_log, runner.comm_log = runner.comm_log, None
     for i in range(-prime + pre_steps, 0):
@@ -436,9 +437,10 @@ def main():
             prev_h, prev_g = h, g
         print("[trace] per step host-enqueue ms / GPU ms since previous step end: " + " ".join(rows), file=sys.stderr)
     timing_note = "HIP events on the launch stream around every gather launch of the timed steps"
+    if pre_log is not None:
+        runner.comm_log = pre_log          # (the collectives' timed events always come from the pre-roll)
     if not sink and pre_sink:
         sink = pre_sink
-        runner.comm_log = pre_log
         timing_note = (f"the timed steps are graph replays, which cannot carry timed events: HIP events around the gather launch (and around every "
                        f"collective) of {pre_steps - 1} iterations issued launch by launch in the pre-roll, before the step was captured")
     elif not sink:
