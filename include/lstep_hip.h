@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 36
+#define LSTEP_ABI_VERSION 37
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -66,6 +66,16 @@ int lstep_ring_tick(int32_t* start, int32_t slots, void* stream);
 
 int lstep_abi_version(void);
 const char* lstep_last_error(void);
+
+/* Streams of the caller's own.  The reference runs everything on the framework's default stream (SURVEY.md 8b "Threading"); the host
+ * layer here overlaps update_pe (models/LSTEP.py:268-340), the ring's copies and the parameter-gradient products with the critical chain
+ * on side streams.  Those must be DEDICATED queues: a framework that hands streams out round-robin from a small pool (PyTorch: 32 per
+ * device) sooner or later gives two roles -- or a role and its own graph-capture stream -- the same queue; work a second host thread
+ * enqueues on a stream that another thread is capturing is recorded into that graph instead of executed (round 4's memory access fault).
+ * lstep_stream_create: a non-blocking hipStream_t, `priority` clamped to the device's range (0 = default, negative = higher);
+ * lstep_stream_destroy: the stream must be idle and not capturing. */
+int lstep_stream_create(void** out_stream, int32_t priority);
+int lstep_stream_destroy(void* stream);
 
 /* S -- NeighborSampler.get_historical_neighbors, 'recent' strategy (utils/utils.py:148-213, search :129-146).
  * Row r < min(num_ids, num_times): the last min(c, K) of the c interactions of node_ids[r] strictly earlier

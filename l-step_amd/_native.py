@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 36
+ABI_VERSION = 37
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -117,6 +117,8 @@ SIGNATURES = {
     "lstep_abi_version": (C.c_int, []),
     "lstep_adam_step": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "lstep_last_error": (C.c_char_p, []),
+    "lstep_stream_create": (C.c_int, [C.POINTER(C.c_void_p), _I32]),
+    "lstep_stream_destroy": (C.c_int, [_P]),
     "lstep_sample_recent": (C.c_int, [C.POINTER(CsrStruct), _P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "lstep_time_encode": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P, _P]),
     "lstep_gather_aggregate_fwd": (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32,
@@ -251,20 +253,49 @@ def current_stream():
     return C.c_void_p(_raw_stream())
 
 
+_ROLE_STREAMS = {}
+
+
+def role_stream(dev, role: str, priority: int = 0):
+    """THE stream of ``role`` on ``dev``: a HIP stream of our own (``lstep_stream_create``), wrapped as ``torch.cuda.ExternalStream``, one per
+    (device, role) for the life of the process.  Roles: "update" (update_pe beside the backward pass), "ring-copy", "aux" (weight-gradient
+    products, weight composition), "side" (edge re-gather of the backward pass), "capture" (every graph capture of this package), "pull",
+    "dist-copy" (lstep_amd.parallel).
+
+    Why not ``torch.cuda.Stream()``: PyTorch hands those out round-robin from a pool of 32 per device, and ``torch.cuda.graph`` takes its
+    default capture stream from the same pool.  Behind ~130 tests of one process the engine's update stream WAS that capture stream
+    (profiles/r05_stream_alias_probe.txt), while update_pe was issued by a second host thread: whatever that thread enqueued while the
+    autograd thread captured the weight-composition backward was recorded into the graph instead of executed and replayed with stale
+    arguments on every later step -- round 4's "memory access fault / identical wrong table, only behind the whole suite".  Dedicated
+    streams cannot collide with the pool or with each other: two roles never share a queue, whatever else the process has created."""
+    import torch
+
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        return None
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, role)
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        lib = load_library()
+        handle = C.c_void_p()
+        with torch.cuda.device(index):
+            check(lib.lstep_stream_create(C.byref(handle), int(priority)))
+        st = _ROLE_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", index))
+    return st
+
+
 _WORKSPACES = {}
 
 
 def _workspace(dev, need: int):
-    """Device scratch, one buffer per (device, stream, HOST THREAD), grown on demand: the engine runs update_pe on a side stream (its own
-    host thread) while the backward pass works on the main stream.
+    """Device scratch, one buffer per (device, stream, HOST THREAD), grown on demand.
 
-    The thread is part of the key because a scratch buffer lives across the launches of ONE native call sequence (partial sums and their
-    reduction, a sort's passes, chunk flags and their join), and PyTorch hands out streams from a pool of 32 per device: in a process that
-    has created more than that, the engine's update stream can be the SAME queue as the auxiliary stream of the backward pass.  Two host
-    threads then interleave their launch sequences on one queue -- harmless for stream order, fatal for a scratch buffer shared by both
-    (a clobbered chunk-flag word is an out-of-range read in the join kernel).  Seen once as a wrong gradient and once as a GPU fault, only
-    behind ~130 other tests (round 4).  Python threads are keyed by name (the engine's per-iteration worker threads share one), the
-    autograd engine's device thread by its ident."""
+    A scratch buffer lives across the launches of ONE native call sequence (partial sums and their reduction, a sort's passes, chunk flags
+    and their join).  The stream is part of the key because sequences on different streams run concurrently; the host thread because the
+    main thread (forward pass, update_pe) and the autograd engine's device thread (backward pass) may both issue sequences onto one
+    stream -- harmless for stream order, fatal for a buffer shared by both (a clobbered chunk-flag word is an out-of-range read in the join
+    kernel).  Python threads are keyed by name, the autograd engine's device thread by its ident."""
     import threading
 
     import torch

@@ -21,7 +21,6 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
-import threading
 from dataclasses import dataclass
 
 import numpy as np
@@ -75,7 +74,7 @@ class HistoryRing:
         self.buf = torch.zeros((self.S, self.rows, self.P), dtype=torch.float32, device=device)
         self.start = 0   # physical slot of the oldest snapshot in the window
         self.len = 0     # snapshots in the window (<= T)
-        self._copy_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self._copy_stream = nat.role_stream(device, "ring-copy")     # (a stream of our own, never one of PyTorch's pool: _native.role_stream)
         self._prefetched = None  # (slot index, event) of a base copy issued ahead of time
         self.words = (self.S + 31) // 32
         on = torch.device(device).type == "cuda" and self.words <= 4 and os.environ.get("LSTEP_DENSE_HISTORY") != "1"
@@ -567,7 +566,7 @@ class GraphedTrainStep:
         dot = os.environ.get("LSTEP_GRAPH_DOT")       # diagnostics: the captured graph's nodes and edges as a DOT file (tools/graph_dot_summary.py)
         if dot:
             graph.enable_debug_mode()
-        with _no_gc(), torch.cuda.graph(graph):
+        with _no_gc(), torch.cuda.graph(graph, stream=nat.role_stream(eng.device, "capture")):
             with eng.aux_streams():
                 self.out = eng._train_iteration(self.optimizer, batch_idx, self.src, self.dst, self.ts, self.eid, self.neg, None, None)
             main = torch.cuda.current_stream(eng.device)
@@ -593,7 +592,7 @@ class LstepEngine:
         self.ring = HistoryRing(rows, backbone.pe_dim, backbone.num_fft_batches, dev, sparse=True) if make_ring else None
         # update_pe on a side stream underneath the backward pass (LSTEP_NO_OVERLAP=1 runs the reference order serially)
         self.overlap_update = torch.device(dev).type == "cuda" and os.environ.get("LSTEP_NO_OVERLAP") != "1"
-        self._update_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
+        self._update_stream = nat.role_stream(dev, "update")    # (a stream of our own, never one of PyTorch's pool: _native.role_stream)
         self.slot_of = torch.full((rows,), -1, dtype=torch.int32, device=dev)
         self.fused_loss = torch.device(dev).type == "cuda" and backbone.pe_dim % 4 == 0 and os.environ.get("LSTEP_TORCH_LOSS") != "1"
         # every data-dependent size (batch nodes, grouped neighbour slots, touched rows) stays on the device: no host synchronisation and
@@ -850,8 +849,7 @@ class LstepEngine:
             return out
 
         # update_pe (forward-only, reads and writes only the current PE table) and the backward pass (never reads that table)
-        # are independent: update_pe runs on a side stream, driven by its own host thread because it needs a few host syncs
-        # for data-dependent sizes, while this thread runs the backward pass on the main stream.
+        # are independent: update_pe runs on the update stream, the backward pass on the main stream, both issued by this thread.
         main = torch.cuda.current_stream(self.device)
         side = self._update_stream
         side.wait_stream(main)
@@ -877,49 +875,21 @@ class LstepEngine:
             self.slot_of.index_fill_(0, batch_nodes, -1)   # (the dead tail is node 0, whose entry is -1 anyway)
             ring.tick()
             return out
-        if getattr(bb.neighbor_sampler, "sample_neighbor_strategy", "recent") != "recent":
-            # RNG-defined strategies: update_pe draws its neighbourhoods on the HOST (numpy's generator, torch CPU ops, pageable copies in
-            # both directions).  That work stays on this thread: the backward pass is enqueued first and runs on the GPU underneath it.
-            # (On a second host thread this path faulted the GPU twice and returned a wrong table twice in ~10 runs of the whole test
-            # suite -- never alone, never with the device sampler; the cause was not found)
-            try:
-                optimizer.zero_grad()
-                _backward_unit(loss)
-                bb.join_aux_stream()
-                with torch.cuda.stream(side):
-                    update_and_append()
-            finally:
-                ring.apply_advance()
-                main.wait_stream(side)
-            optimizer.step()
-            self.slot_of.index_fill_(0, batch_nodes, -1)
-            ring.tick()
-            return out
-        err = []
-
-        def worker():
-            try:
-                with torch.cuda.device(self.device), torch.cuda.stream(side):
-                    update_and_append()
-            except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
-                err.append(e)
-
-        # (enqueueing update_pe from THIS thread onto the side stream before the backward pass was measured too: 6.0-6.8 ms/step
-        # against 5.2 with the second thread -- the backward's launches would start 0.7 ms late)
-        th = threading.Thread(target=worker, name="lstep-update-pe")
-        th.start()
+        # Host-sized update_pe (RNG-defined strategies: numpy's generator, torch CPU ops, pageable copies both ways; LSTEP_HOST_COUNTS=1 and
+        # non-default widths: a few host reads of data-dependent sizes): the backward pass is enqueued first and runs on the GPU underneath
+        # update_pe, which THIS thread then issues onto the update stream.  There is no second host thread anywhere in this package: rounds
+        # 2-4 drove this branch from one (it hid ~1 ms of host waits), and in round 4 that thread's launches landed on a stream another
+        # thread was capturing a graph on -- PyTorch's round-robin stream pool had given the engine's update stream and torch.cuda.graph's
+        # capture stream the same queue (the streams are dedicated now, _native.role_stream, and the thread is gone).
         try:
             optimizer.zero_grad()
             _backward_unit(loss)
             bb.join_aux_stream()
+            with torch.cuda.stream(side):
+                update_and_append()
         finally:
-            # whatever happened above, the worker must not be left mutating the table / mask / commit state behind our back, and the
-            # streams must meet again
-            th.join()
-            ring.apply_advance()  # (no-op unless the worker committed) the backward pass is enqueued: `oldest` may move on behind it
+            ring.apply_advance()  # (no-op unless update_pe committed) the backward pass is enqueued: `oldest` may move on behind it
             main.wait_stream(side)
-        if err:
-            raise err[0]
         optimizer.step()      # after update_pe has read its weights
         self.slot_of.index_fill_(0, batch_nodes, -1)   # (tensor[index] = scalar blocks the host until the GPU has drained)
         ring.tick()

@@ -329,7 +329,7 @@ class _TailWeightsGraph:
                 if self.g_fwd is not None:
                     retire_graph(self.g_fwd)
                 self.g_fwd = new_graph(self)
-                with _no_gc(), torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(self.g_fwd, stream=nat.role_stream(self.params[0].device, "capture"), capture_error_mode="thread_local"):
                     self.outs, self.transposed, self.saved = _tail_weights_forward(self.dims, *self._detached())
         if self.prepared is not None:        # replayed ahead of time on the auxiliary stream (LSTEP.prepare_step): just wait for it
             torch.cuda.current_stream().wait_event(self.prepared)
@@ -376,7 +376,7 @@ class _TailWeightsGraph:
                 _tail_weights_backward(*args)
                 torch.cuda.current_stream().synchronize()
                 self.g_bwd = new_graph(self)
-                with _no_gc(), torch.cuda.graph(self.g_bwd, capture_error_mode="thread_local"):
+                with _no_gc(), torch.cuda.graph(self.g_bwd, stream=nat.role_stream(self.params[0].device, "capture"), capture_error_mode="thread_local"):
                     self.pgrads = _tail_weights_backward(*args)
                 for g, k in zip(self.gin, keep):
                     g.copy_(k)
@@ -512,7 +512,7 @@ def _aux_stream(dev):
     dev = torch.device(dev)
     st = _AUX_STREAMS.get(dev)
     if st is None:
-        st = _AUX_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        st = _AUX_STREAMS[dev] = nat.role_stream(dev, "aux")
     return st
 
 
@@ -523,7 +523,7 @@ def _side_stream(dev):
     dev = torch.device(dev)
     st = _SIDE_STREAMS.get(dev)
     if st is None:
-        st = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        st = _SIDE_STREAMS[dev] = nat.role_stream(dev, "side")
     return st
 
 

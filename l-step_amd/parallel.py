@@ -40,6 +40,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _native as nat
 from .engine import HistoryRing, LstepEngine, _LinkLoss, _backward_unit, _lookup_rows
 from .model import SplicedRows
 
@@ -477,8 +478,7 @@ class DistributedLstep:
         self._pending_pull, self._pull_min_capacity = None, 0
         # the pull's own stream: its request (a sampler launch and a ~1 M-key sort) runs beside the forward pass, its row exchange behind
         # update_pe -- on neither the critical stream nor in front of update_pe on the update stream
-        self._pull_stream = (torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("LSTEP_PULL_PRIORITY", "1") == "1" else 0)
-                             if torch.device(dev).type == "cuda" else None)
+        self._pull_stream = nat.role_stream(dev, "pull", priority=-1 if os.environ.get("LSTEP_PULL_PRIORITY", "1") == "1" else 0)
         if self.form in ("replicate", "pull"):
             self._ring = ShardedSparseRing(self.table, self.W, self.rank, self.bb.num_fft_batches)
             engine.ring = self._ring        # (lets the engine's grouping helpers take their device-count branch; its own iterations are not used)
@@ -495,7 +495,7 @@ class DistributedLstep:
                 self.pull_group = dist.new_group(backend=dist.get_backend(group)) if not (_skip_single(self.W) or captured) else group
         else:
             self._ring = HistoryRing(owned_rows(rows, self.W, self.rank), self.bb.pe_dim, self.bb.num_fft_batches, dev)
-        self._copy_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == "cuda" else None
+        self._copy_stream = nat.role_stream(dev, "dist-copy")
         # DEVICE-DRIVEN iteration (round 4): every collective has a fixed capacity and its live count travels on the device
         # (``lstep_owner_partition``), so the host never waits for the GPU inside an iteration and -- over RCCL -- the whole training
         # iteration, collectives included, is captured once and replayed as ONE HIP graph (``GraphedDistStep``), like the single-GPU engine's.
@@ -1690,7 +1690,7 @@ class GraphedDistStep:
         # (hipEventQuery); in the default "global" mode that call from another thread is an error that kills the capture
         # ("operation not permitted when stream is capturing" out of ProcessGroupNCCL's watchdog -- seen once the bench's eager iterations
         # ran right in front of the capture).  The autograd thread's launches are captured in either mode.
-        with _no_gc(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with _no_gc(), torch.cuda.graph(graph, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
             with eng.aux_streams():
                 self.out = dl._train_iteration_dev(self.optimizer, batch_idx, src, dst, ts, eid, neg, None, ahead)
             main = torch.cuda.current_stream(dl.device)

@@ -44,3 +44,40 @@ def _gpu_memory_log(request):
     with open(path, "a") as f:
         f.write(f"{request.node.nodeid} free_GB={free / 2**30:.2f} total_GB={total / 2**30:.1f} reserved_GB={torch.cuda.memory_reserved() / 2**30:.2f} "
                 f"allocated_GB={torch.cuda.memory_allocated() / 2**30:.2f}\n")
+
+
+# ---- diagnostics (round 5): LSTEP_STREAM_LOG=<file> logs every stream PyTorch hands out from its round-robin pool (handle, running test,
+# requesting code).  This is how round 4's fault was explained: the engine's update stream had been given the same queue as
+# torch.cuda.graph's capture stream (profiles/r05_stream_alias_probe.txt).
+_STREAM_LOG = os.environ.get("LSTEP_STREAM_LOG")
+_CURRENT_TEST = ["<collection>"]
+
+
+def _install_stream_probe():
+    import traceback
+
+    import torch
+    orig_new = torch.cuda.Stream.__new__
+
+    def new(cls, *a, **k):
+        s = orig_new(cls, *a, **k)
+        try:
+            if s.cuda_stream != 0 and cls is torch.cuda.Stream:
+                frames = [f for f in traceback.extract_stack()[:-1] if "dist-packages" not in f.filename and "/usr/lib" not in f.filename]
+                who = "; ".join(f"{os.path.basename(f.filename)}:{f.lineno}:{f.name}" for f in frames[-3:])
+                with open(_STREAM_LOG, "a") as f:
+                    f.write(f"STREAM {s.cuda_stream:#x} test={_CURRENT_TEST[0]} by={who}\n")
+        except Exception:  # noqa: BLE001  (diagnostics must never break a test)
+            pass
+        return s
+    torch.cuda.Stream.__new__ = staticmethod(new)
+
+
+if _STREAM_LOG:
+    _install_stream_probe()
+
+
+@pytest.fixture(autouse=True)
+def _stream_probe_test_name(request):
+    _CURRENT_TEST[0] = request.node.nodeid
+    yield

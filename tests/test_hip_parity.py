@@ -2086,15 +2086,45 @@ def test_engine_with_rng_sampler_vs_oracle_protocol(hip, strategy):
 
 
 @pytest.mark.parametrize("which", ["auxiliary", "side"])
-def test_update_thread_sharing_a_queue_with_the_backward_pass(hip, monkeypatch, which):
-    """PyTorch hands out streams from a pool of 32 per device: in a process that has created more, the engine's update stream can BE the
-    queue the backward pass puts its weight-gradient products (or its edge re-gather) on, and the host-sized update_pe's own host thread
-    then interleaves its launch sequences with the autograd thread's on one queue.  Forced here by handing the engine that very stream:
-    the iteration must not depend on it (native scratch buffers are per host thread: lstep_amd._native._workspace)."""
+def test_update_stream_sharing_a_queue_with_the_backward_pass(hip, monkeypatch, which):
+    """The host-sized update_pe (here: the device sampler with LSTEP_HOST_COUNTS=1) and the backward pass's parameter-gradient work (or its
+    edge re-gather) on ONE queue: the main thread and the autograd thread then interleave their launch sequences on it.  The iteration must
+    not depend on that (native scratch buffers are per host thread: lstep_amd._native._workspace).  Forced by handing the engine that very
+    stream -- the package's own streams are dedicated per role and cannot coincide (``test_role_streams_never_come_from_the_framework_pool``)."""
     from lstep_amd import model as lm
-    monkeypatch.setenv("LSTEP_HOST_COUNTS", "1")          # the device sampler with host-sized update_pe: the path that runs on a second thread
+    monkeypatch.setenv("LSTEP_HOST_COUNTS", "1")
 
     def share(eng):
         eng._update_stream = (lm._aux_stream if which == "auxiliary" else lm._side_stream)(torch.device(DEV))
     for _ in range(3):
         _rng_engine_scenario(hip, "recent", tweak=share)
+
+
+def test_role_streams_never_come_from_the_framework_pool(hip):
+    """Round 4's memory access fault / wrong table: PyTorch hands ``torch.cuda.Stream()`` out round-robin from a pool of 32 per device and
+    ``torch.cuda.graph`` takes its default capture stream from the same pool -- behind ~130 tests the engine's update stream WAS that capture
+    stream (profiles/r05_stream_alias_probe.txt) while a second host thread issued update_pe onto it.  The package's streams are now created
+    by the library (``lstep_stream_create``), one per role: whatever else the process has created, no two roles share a queue, none is a
+    pool stream, and none is the framework's capture stream."""
+    from lstep_amd import _native as nat
+    from lstep_amd import model as lm
+    dev = torch.device(DEV)
+    pool = {torch.cuda.Stream(device=dev).cuda_stream for _ in range(80)}      # the whole pool, more than twice over
+    assert len(pool) <= 32
+    seen = {}
+
+    def check(eng):
+        roles = {"update": eng._update_stream, "ring-copy": eng.ring._copy_stream, "aux": lm._aux_stream(dev), "side": lm._side_stream(dev),
+                 "capture": nat.role_stream(dev, "capture")}
+        handles = {k: v.cuda_stream for k, v in roles.items()}
+        assert len(set(handles.values())) == len(handles), handles
+        assert not (set(handles.values()) & pool), (handles, pool)
+        assert 0 not in handles.values()
+        seen.update(handles)
+    _rng_engine_scenario(hip, "time_interval_aware", tweak=check)       # (the scenario that faulted, behind a pool that has wrapped around)
+    first = dict(seen)
+    _rng_engine_scenario(hip, "uniform", tweak=check)
+    assert seen == first                                                 # one stream per (device, role) for the life of the process
+    default_capture = torch.cuda.graph.default_capture_stream
+    if default_capture is not None:
+        assert default_capture.cuda_stream not in seen.values()
