@@ -217,18 +217,21 @@ def launch_ranks(gpus: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def rccl_graph_probe(world: int, rank: int, local_rank: int):
+def rccl_probe_verdict(world: int, rank: int, local_rank: int) -> dict:
     """Multi-rank runs replay ONE captured graph per step with the RCCL collectives inside (``parallel.GraphedDistStep``) -- something a
     one-GPU box can only rehearse with a single rank.  Before this rank touches its GPU, a child process per rank captures and replays
-    the same kinds of collectives across the N ranks (tools/rccl_graph_probe.py).  Returns (ok, note): on anything but a clean exit the
-    bench keeps the device-driven iteration but issues it launch by launch, instead of failing the run on a capture it could never try."""
+    the same kinds of collectives across the N ranks (tools/rccl_graph_probe.py), and then the owner-sharded form's exchange pattern (two
+    synchronous equal-split all-to-alls from the capturing stream, on the main and on a second communicator).  Returns
+    {"captured": bool, "pull": bool, "note": str}: on anything but a clean exit the bench keeps the device-driven iteration but issues it
+    launch by launch instead of failing the run on a capture it could never try; "pull" (the form ``DistributedLstep`` takes beyond four
+    ranks) needs the child's own verdict on the exchange pattern as well, else the run takes "replicate"."""
     import subprocess
     if world <= 1 and os.environ.get("LSTEP_FORCE_GRAPH_PROBE") != "1":
-        return True, "skipped (one rank)"
+        return {"captured": True, "pull": True, "note": "skipped (one rank)"}
     if os.environ.get("LSTEP_DIST_GRAPH", "1") == "0":
-        return False, "skipped (LSTEP_DIST_GRAPH=0)"
+        return {"captured": False, "pull": False, "note": "skipped (LSTEP_DIST_GRAPH=0)"}
     if os.environ.get("LSTEP_SKIP_GRAPH_PROBE") == "1" or os.environ.get("LSTEP_DIST_BACKEND", "nccl") != "nccl":
-        return True, "skipped"
+        return {"captured": True, "pull": True, "note": "skipped"}
     env = dict(os.environ)
     env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 23))
@@ -239,11 +242,27 @@ def rccl_graph_probe(world: int, rank: int, local_rank: int):
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("LSTEP_GRAPH_PROBE_TIMEOUT", "240")))
     except subprocess.TimeoutExpired:
-        return False, "timeout"
+        return {"captured": False, "pull": False, "note": "timeout"}
     if r.returncode == 0:
-        return True, "ok"
+        pull, note = False, "ok (no verdict on the pull pattern)"
+        for ln in reversed((r.stdout or "").strip().splitlines()):
+            if ln.startswith("{"):
+                try:
+                    v = json.loads(ln)
+                    pull = bool(v.get("pull"))
+                    note = "ok" if pull else f"ok; pull pattern: {v.get('pull_note')}"
+                except ValueError:
+                    pass
+                break
+        return {"captured": True, "pull": pull, "note": note}
     tail = (r.stderr or r.stdout or "").strip().splitlines()
-    return False, f"exit code {r.returncode}" + (f": {tail[-1][:160]}" if tail else "")
+    return {"captured": False, "pull": False, "note": f"exit code {r.returncode}" + (f": {tail[-1][:160]}" if tail else "")}
+
+
+def rccl_graph_probe(world: int, rank: int, local_rank: int):
+    """(captured ok, note) of ``rccl_probe_verdict``."""
+    v = rccl_probe_verdict(world, rank, local_rank)
+    return v["captured"], v["note"]
 
 
 def main():
@@ -284,7 +303,8 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {args.gpus}` (it starts its own ranks) "
                          f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
-    probe_ok, probe_note = rccl_graph_probe(world, rank, local_rank)      # (a child process: before THIS process initialises HIP)
+    verdict = rccl_probe_verdict(world, rank, local_rank)      # (a child process: before THIS process initialises HIP)
+    probe_ok, probe_note, pull_ok = verdict["captured"], verdict["note"], verdict["pull"]
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if os.environ.get("LSTEP_SINGLE_DEVICE") == "1":   # rehearsal of the N > 1 plumbing on a one-GPU box (with LSTEP_DIST_BACKEND=gloo)
         local_rank = 0
@@ -316,12 +336,17 @@ def main():
         eng.use_step_graph = args.graph == "on" and args.mode == "train"
     else:
         from lstep_amd.workload import prefill_distributed
-        runner = DistributedLstep(eng, opt)
-        if world > 1:       # every rank takes the same path: the graph only if every rank's probe came back clean
-            flag = torch.tensor([1 if probe_ok else 0], dtype=torch.int32, device=dev)
+        if world > 1:       # every rank takes the same path: the graph / the owner-sharded form only if every rank's probe came back clean
+            flag = torch.tensor([1 if probe_ok else 0, 1 if pull_ok else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and probe_ok:
+            got = flag.tolist()
+            if got[0] == 0 and probe_ok:
                 probe_ok, probe_note = False, "another rank's probe failed"
+            if got[1] == 0 and pull_ok:
+                pull_ok, probe_note = False, probe_note + "; another rank's pull-pattern probe failed"
+        # the probe's verdict decides what DistributedLstep does by default: the whole-step graph (W > 1) only with a clean capture probe, the
+        # owner-sharded "pull" form beyond four ranks only with a clean pull-pattern probe ("replicate" otherwise)
+        runner = DistributedLstep(eng, opt, probe={"captured": probe_ok, "pull": probe_ok and pull_ok})
         if not probe_ok:
             runner.use_step_graph = False
             if rank == 0:
@@ -476,6 +501,10 @@ def main():
                 "timing": "HIP events around every collective of the launch-by-launch iterations " + ("of the pre-roll, before the step was captured" if pre_sink else "run after the timed region") + " (rank 0)"}
         comm["timed_steps_are_graph_replays"] = bool(getattr(runner, "use_step_graph", False)) and args.mode == "train"
         comm["captured_collective_probe"] = probe_note
+        comm["probe_verdict"] = {"captured": bool(probe_ok), "pull_pattern": bool(pull_ok)}
+        comm["update_form"] = getattr(runner, "form", None)
+        comm["update_form_chosen_by"] = ("LSTEP_PHASE2=" + os.environ["LSTEP_PHASE2"]) if os.environ.get("LSTEP_PHASE2", "auto") != "auto" else \
+            "auto: pull beyond four ranks with a clean pull-pattern probe on every rank, replicate otherwise"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -557,15 +586,34 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.workload, args.time_gap, args.batch)
         print(json.dumps(line))
     if use_dist:
-        # leave without tearing the communicators down: one `pull` rehearsal (world size 1 over RCCL) sat in destroy_process_group until the
-        # caller's timeout after its line was out; nothing is left to do but exit, and every rank has passed the barrier below
+        # Orderly teardown, bounded.  Round 4 left through os._exit(0) because one `pull` rehearsal (world size 1 over RCCL) sat in
+        # destroy_process_group until the caller's timeout: the captured step's graph -- which holds kernels of BOTH communicators -- was still
+        # alive, and a communicator cannot be destroyed before the graphs that captured its collectives.  Now: drop the captured steps
+        # (explicit graph lifetime, model.drain_dead_graphs), drain the GPU, destroy the process group from a helper thread and give it
+        # 30 s; only if THAT does not return is the process ended with os._exit, and the line says so on stderr (nothing is hidden: the
+        # JSON line is out, every rank has passed the barrier).
         sys.stdout.flush()
         sys.stderr.flush()
         barrier()
-        if os.environ.get("LSTEP_BENCH_NORMAL_EXIT") == "1":      # (under rocprofv3: the tracer writes its files at interpreter exit)
-            return
-        os._exit(0)
+        try:
+            runner.close()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: closing the captured steps failed: {type(e).__name__}: {e}", file=sys.stderr)
+        import threading
+        done = threading.Event()
 
+        def teardown():
+            try:
+                dist.destroy_process_group()
+            finally:
+                done.set()
+        th = threading.Thread(target=teardown, name="lstep-bench-teardown", daemon=True)      # (no GPU launches: communicator teardown only)
+        th.start()
+        if not done.wait(timeout=float(os.environ.get("LSTEP_BENCH_TEARDOWN_TIMEOUT", "30"))):
+            print(f"bench.py: rank {rank}: destroy_process_group did not return within its timeout; leaving through os._exit(0)", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(0)
 
 if __name__ == "__main__":
     main()

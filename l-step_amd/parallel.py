@@ -456,8 +456,15 @@ class ShardedSparseRing(HistoryRing):
 class DistributedLstep:
     """Drives one ``LstepEngine``'s model over a global batch shared by all ranks of ``group``."""
 
-    def __init__(self, engine: LstepEngine, optimizer=None, group=None):
+    def __init__(self, engine: LstepEngine, optimizer=None, group=None, probe: dict = None):
+        """``probe`` = {"captured": bool, "pull": bool}: what a rehearsal of captured collectives ACROSS the ranks of ``group`` found
+        (tools/rccl_graph_probe.py, run by ``bench.py`` in a child process per rank before the rank initialises HIP, agreed by an
+        all-reduce).  It is what lets a multi-rank job take the two things this torch / RCCL pair can get wrong in a way that kills the
+        process: the whole-step HIP graph with the collectives inside (W > 1: only with probe["captured"], or LSTEP_DIST_GRAPH=1), and the
+        owner-sharded "pull" form as the default beyond four ranks (only with probe["pull"]).  Without a probe a multi-rank job runs the
+        device-driven iteration launch by launch in the "replicate" form."""
         self.eng = engine
+        self.probe = dict(probe) if probe else None
         self.bb, self.predictor = engine.backbone, engine.predictor
         self.group = group
         self.W, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -489,8 +496,7 @@ class DistributedLstep:
                 # launch by launch (gloo; LSTEP_PULL_COMM=own; LSTEP_DIST_GRAPH=0) the pulled rows travel on a communicator of their own: on the
                 # main one they would queue behind the backward pass's reduce-scatter / all-reduce (a communicator runs its collectives in
                 # issue order) instead of underneath them.  A captured iteration keeps every collective on the main communicator (below).
-                captured = (os.environ.get("LSTEP_DIST_HOST_COUNTS") != "1" and os.environ.get("LSTEP_DIST_GRAPH", "1") != "0"
-                            and torch.device(dev).type == "cuda" and dist.get_backend(group) != "gloo"
+                captured = (os.environ.get("LSTEP_DIST_HOST_COUNTS") != "1" and self._graph_allowed(group)
                             and os.environ.get("LSTEP_PULL_COMM", "main") != "own")
                 self.pull_group = dist.new_group(backend=dist.get_backend(group)) if not (_skip_single(self.W) or captured) else group
         else:
@@ -501,8 +507,7 @@ class DistributedLstep:
         # iteration, collectives included, is captured once and replayed as ONE HIP graph (``GraphedDistStep``), like the single-GPU engine's.
         # LSTEP_DIST_HOST_COUNTS=1: the host-sized iterations of rounds 2-3 (A/B; also what "allgather" always takes).
         self.device_driven = self.form in ("replicate", "pull") and os.environ.get("LSTEP_DIST_HOST_COUNTS") != "1"
-        self.use_step_graph = (self.device_driven and os.environ.get("LSTEP_DIST_GRAPH", "1") != "0" and torch.device(dev).type == "cuda"
-                               and dist.get_backend(group) != "gloo")
+        self.use_step_graph = self.device_driven and self._graph_allowed(group)
         self._graphed, self._steady_steps = {}, 0
         self._overflow = torch.zeros(1, dtype=torch.int32, device=dev)      # sticky: some fixed-capacity block was too small
         self._overflow_poll = None
@@ -514,6 +519,18 @@ class DistributedLstep:
         # update_pe's layers are forward-only (no gradient ever reaches them): they stay out of the bucket
         frozen = {id(p) for m in (self.bb.pe_mlp_1, self.bb.pe_mlp_2, self.bb.self_update_pe) for p in m.parameters()}
         self._trainable = [p for p in list(self.bb.parameters()) + list(self.predictor.parameters()) if id(p) not in frozen]
+
+    def _graph_allowed(self, group) -> bool:
+        """May the iteration be captured as one HIP graph with its RCCL collectives inside?  One rank: yes (rehearsed on hardware: world
+        size 1 with every collective forced).  More ranks: capturing collectives that really cross links has never run on this pool, and
+        the patterns this torch / RCCL pair gets wrong SIGSEGV the process (tools/rccl_capture_probe.py) -- so only when a cross-rank
+        rehearsal came back clean (``probe["captured"]``) or the caller insists (LSTEP_DIST_GRAPH=1).  LSTEP_DIST_GRAPH=0: never."""
+        flag = os.environ.get("LSTEP_DIST_GRAPH")
+        if flag == "0" or torch.device(self.device).type != "cuda" or dist.get_backend(group) == "gloo":
+            return False
+        if self.W == 1 or flag == "1":
+            return True
+        return bool(self.probe and self.probe.get("captured"))
 
     # ---- state import/export (tests, checkpoints)
     def load_history(self, history: torch.Tensor):
@@ -654,7 +671,8 @@ class DistributedLstep:
     def _choose_form(self) -> str:
         """LSTEP_PHASE2 = auto | replicate | allgather | pull (module docstring).
         ``auto``: "replicate" up to W = 4 -- zero update bytes and the single-GPU engine's host-free path; the redundant work (phase 2
-        touches 0.72 / 0.91 M rows at W = 2 / 4 on c4) still fits under the backward pass -- and "pull" beyond: at W = 8 on c5 the
+        touches 0.72 / 0.91 M rows at W = 2 / 4 on c4) still fits under the backward pass -- and "pull" beyond (when the job's probe of its
+        exchange pattern is clean, below): at W = 8 on c5 the
         replicated update would touch 2.9 M rows per step (~6.7 ms of update kernels against a ~3.4 ms step) and an all-gather of them
         would move 1.77 GB per rank, while the pull moves the ~0.55 GB a rank's next gather reads and keeps the update at 1 / W of the
         rows.  Configurations the device-count update does not cover (non-default widths, RNG-defined sampling, T > 126) take
@@ -667,9 +685,14 @@ class DistributedLstep:
                 raise RuntimeError(f"LSTEP_PHASE2={policy} needs the device-count update path (default widths, 'recent' sampling, T <= 126, a GPU)")
             return "allgather"
         if policy == "auto":
-            # (round-3 ADVICE: "pull" has never run on more than one real RCCL rank -- no multi-GPU box was ever leased to the builder -- so
-            # it is opt-in, LSTEP_PHASE2=pull, until a multi-rank hardware run of tests/test_parallel.py has passed; "replicate" issues three
-            # plain equal-block collectives per step on one communicator)
+            # "pull" is the form whose bytes and FLOPs are flat in W (expected efficiency ~0.6-0.7 at W = 8 against
+            # ~0.45 for "replicate"), but its exchange pattern -- two all-to-alls per step, captured from the capturing stream -- has only
+            # ever run on ONE real RCCL rank.  So it is taken beyond LSTEP_PULL_MIN_WORLD - 1 = four ranks exactly when a rehearsal of that
+            # pattern across the job's real ranks came back clean on every rank (``probe["pull"]``, tools/rccl_graph_probe.py through
+            # bench.py), and "replicate" -- three plain equal-block collectives per step on one communicator -- otherwise.
+            min_world = int(os.environ.get("LSTEP_PULL_MIN_WORLD", "5"))
+            if self.W >= min_world and self.probe and self.probe.get("pull"):
+                return "pull"
             return "replicate"
         return policy
 
@@ -1624,6 +1647,7 @@ class GraphedDistStep:
         self.graph, self.out, self.replays, self.hyper = None, None, 0, None
         self._ahead_key = None
         self._pull_cap, self._cnt_max = None, None      # ("pull") block size the captured requests use / their largest count, on the device
+        self.pull_graph, self._pull_now_cap, self._pull_now_keep, self.pull_now_replays = None, None, None, 0    # (``_pull_now_graphed``)
 
     def _hyper(self):
         o = self.optimizer
@@ -1631,21 +1655,20 @@ class GraphedDistStep:
 
     def close(self):
         from .model import drain_dead_graphs, retire_graph
-        if self.graph is not None:
-            retire_graph(self.graph)
-        self.graph, self.out = None, None
+        for g in (self.graph, self.pull_graph):
+            if g is not None:
+                retire_graph(g)
+        self.graph, self.out, self.pull_graph, self._pull_now_keep = None, None, None, None
         drain_dead_graphs()
 
     def step(self, batch_idx, src, dst, ts, eid, neg_dst, lookahead):
         dl = self.dl
         pull = dl.form == "pull"
+        fresh = True
         if pull:
             # the rows of THIS gather were requested and fetched by the previous replay from its look-ahead buffers: valid only if that
-            # look-ahead named exactly this batch; otherwise fetch them now, launch by launch
+            # look-ahead named exactly this batch (else: ``_pull_now_graphed`` below, once the batch sits in the fixed buffers)
             fresh = self._ahead_key is not None and self._ahead_key.matches(src, dst, ts, neg_dst)
-            if not fresh:
-                pend = dl._take_pull(src, dst, ts, neg_dst)        # (fetched by a launch-by-launch iteration from ITS look-ahead)
-                (pend or dl._pull_now_dev((src, dst, neg_dst), ts)).wait()
             if lookahead is None or len(lookahead) < 4:
                 lookahead = (src, dst, ts, neg_dst)          # (no look-ahead: the rows fetched for "the next batch" are simply not used)
                 self._ahead_key = None
@@ -1655,6 +1678,12 @@ class GraphedDistStep:
             self.nxt[2].copy_(lookahead[2])
         torch._foreach_copy_([self.cur[0], self.cur[1], self.cur[3], self.cur[4]], [src, dst, eid, neg_dst])
         self.cur[2].copy_(ts)
+        if pull and not fresh:
+            pend = dl._take_pull(src, dst, ts, neg_dst)        # (fetched by a launch-by-launch iteration from ITS look-ahead: an event wait)
+            if pend is not None:
+                pend.wait()
+            else:
+                self._pull_now_graphed()
         dl.eng.__dict__.pop("_prefetched_group", None)
         dl._pending_pull = None
         if self.graph is not None and self.hyper != self._hyper():
@@ -1673,6 +1702,34 @@ class GraphedDistStep:
             if pull and self._cnt_max is not None:
                 dl._note_pull_counts(self._cnt_max)
         return self.out
+
+    def _pull_now_graphed(self):
+        """The rows this batch's gather reads, requested and fetched ON THE SPOT (the previous step's look-ahead did not name this batch: the
+        first replayed step, an epoch boundary, a switch between training and evaluation) -- as a small captured graph of its own over the
+        fixed batch buffers, replayed in front of the step's graph.  Once a step has been captured NO collective of this object is issued
+        launch by launch any more: eager collectives behind a capture are what ended a process in round 4 (the process group's watchdog
+        thread queried an event of an eager collective that had last been recorded in a capturing stream -- torch caches and re-uses the
+        HIP events of its collective Work objects), and what ``bench.py`` had to route around."""
+        from .model import _no_gc, new_graph, retire_graph
+        dl = self.dl
+        n_rows = 3 * (self.B // dl.W)
+        cap = dl._pull_capacity_dev(n_rows * (dl.K + 1) + 1)      # (the size RowPullDev sizes its blocks from)
+        if self.pull_graph is not None and self._pull_now_cap != cap:
+            retire_graph(self.pull_graph)
+            self.pull_graph = None
+        if self.pull_graph is None:
+            src, dst, ts, _, neg = self.cur
+            torch.cuda.synchronize(dl.device)
+            g = new_graph(self)
+            with _no_gc(), torch.cuda.graph(g, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
+                p = dl._pull_now_dev((src, dst, neg), ts)
+                p.wait()
+                self._pull_now_keep = p          # (its tensors are the graph's: request blocks, served rows, the largest per-owner count)
+            self.pull_graph, self._pull_now_cap = g, cap
+        self.pull_graph.replay()
+        self.pull_now_replays += 1
+        if self._pull_now_keep is not None and self._pull_now_keep.cnt_max is not None:
+            dl._note_pull_counts(self._pull_now_keep.cnt_max)
 
     def _capture(self, batch_idx):
         from .model import _aux_stream, _no_gc, new_graph

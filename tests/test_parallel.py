@@ -124,6 +124,16 @@ def test_collective_helpers_gloo_world2():
     _run(_cpu_worker, 2)
 
 
+def _probe_and_form(world):
+    """(probe handed to DistributedLstep, the form LSTEP_PHASE2 must resolve to).  LSTEP_TEST_PROBE=clean stands for bench.py's cross-rank
+    rehearsal of captured collectives and of the pull exchange pattern having come back clean on every rank."""
+    probe = {"captured": True, "pull": True} if os.environ.get("LSTEP_TEST_PROBE") == "clean" else None
+    policy = os.environ.get("LSTEP_PHASE2", "auto")
+    if policy == "auto":
+        policy = "pull" if (probe is not None and world >= int(os.environ.get("LSTEP_PULL_MIN_WORLD", "5"))) else "replicate"
+    return probe, policy
+
+
 def _gpu_worker(rank, world, port, q, backend="gloo", ahead=False):
     try:
         torch.cuda.set_device(0)
@@ -139,7 +149,8 @@ def _gpu_worker(rank, world, port, q, backend="gloo", ahead=False):
         model = build_hip_model(node_raw, edge_raw, sampler, TRACE_K, TRACE_T, synth.make_state_dict(TRACE_K, TRACE_T), dev)
         model.train()
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-        dl = DistributedLstep(LstepEngine(model[0], model[1], TRACE_K, TRACE_G, make_ring=False), opt)
+        probe, want_form = _probe_and_form(world)
+        dl = DistributedLstep(LstepEngine(model[0], model[1], TRACE_K, TRACE_G, make_ring=False), opt, probe=probe)
         assert dl.ring.rows == (65 - rank + world - 1) // world
         stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], dev)
         init = torch.from_numpy(pe0.copy()).to(dev)
@@ -152,7 +163,7 @@ def _gpu_worker(rank, world, port, q, backend="gloo", ahead=False):
             return torch.cat([cat[:, 0, :].reshape(-1), cat[:, 1, :].reshape(-1)]).cpu().numpy()
 
         pull = dl.form == "pull"
-        assert dl.form == os.environ.get("LSTEP_PHASE2", "auto").replace("auto", "replicate")
+        assert dl.form == want_form, (dl.form, want_form)
         assert dl.device_driven == (dl.form != "allgather" and os.environ.get("LSTEP_DIST_HOST_COUNTS") != "1")
 
         poisoned = [0]
@@ -208,7 +219,8 @@ def _gpu_worker(rank, world, port, q, backend="gloo", ahead=False):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,phase2,ahead,host_counts", [(2, "allgather", False, False), (2, "replicate", False, False), (4, "auto", False, False),
                                                             (2, "pull", False, False), (2, "pull", True, False), (4, "pull", True, False),
-                                                            (2, "replicate", False, True), (2, "pull", True, True)])
+                                                            (2, "replicate", False, True), (2, "pull", True, True),
+                                                            (2, "auto+clean-probe", True, False), (4, "auto+clean-probe", True, False)])
 def test_distributed_engine_reproduces_golden_trace_ranks_on_one_gpu(monkeypatch, world, phase2, ahead, host_counts):
     """W ranks share the one GPU of the test box (gloo staging the device tensors through the host) and must reproduce the REFERENCE's
     golden training + evaluation trace: owner-sharded history ring and FFT filter, batch slices through the gather stage, and the three
@@ -216,7 +228,14 @@ def test_distributed_engine_reproduces_golden_trace_ranks_on_one_gpu(monkeypatch
     rows, all-to-all pull of the rows the next gather reads, requested on the spot and one step ahead), two ranks and four (17 / 16 /
     16 / 16 owned rows, 4 edges of the batch per rank)."""
     assert torch.cuda.is_available()
-    monkeypatch.setenv("LSTEP_PHASE2", phase2)      # (inherited by the spawned ranks)
+    if phase2 == "auto+clean-probe":
+        # the default (LSTEP_PHASE2 unset = auto) with a clean cross-rank probe: the owner-sharded form beyond LSTEP_PULL_MIN_WORLD - 1 ranks
+        # (five in production: what `python bench.py --gpus 8` runs; lowered here to the ranks one test box can hold)
+        monkeypatch.delenv("LSTEP_PHASE2", raising=False)
+        monkeypatch.setenv("LSTEP_TEST_PROBE", "clean")
+        monkeypatch.setenv("LSTEP_PULL_MIN_WORLD", "2")
+    else:
+        monkeypatch.setenv("LSTEP_PHASE2", phase2)      # (inherited by the spawned ranks)
     monkeypatch.setenv("LSTEP_PULL_POISON", "1")    # "pull": rows a rank does not own are NaN unless a collective delivered them
     if host_counts:                                 # the host-sized iterations of rounds 2-3 (A/B switch; what "allgather" always takes)
         monkeypatch.setenv("LSTEP_DIST_HOST_COUNTS", "1")
@@ -257,7 +276,9 @@ def _long_worker(rank, world, port, q, backend, expect_replays):
         model = build_hip_model(node_raw, edge_raw, sampler, TRACE_K, TRACE_T, synth.make_state_dict(TRACE_K, TRACE_T), dev)
         model.train()
         opt = FusedAdam(model.parameters(), lr=1e-4)
-        dl = DistributedLstep(LstepEngine(model[0], model[1], TRACE_K, TRACE_G, make_ring=False), opt)
+        probe, want_form = _probe_and_form(world)
+        dl = DistributedLstep(LstepEngine(model[0], model[1], TRACE_K, TRACE_G, make_ring=False), opt, probe=probe)
+        assert dl.form == want_form, (dl.form, want_form)
         assert dl.device_driven and dl.use_step_graph == (backend == "nccl")
         stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], dev)
         init = torch.from_numpy(pe0.copy()).to(dev)
@@ -301,6 +322,9 @@ def _long_worker(rank, world, port, q, backend, expect_replays):
         if expect_replays:
             assert gs is not None and gs.graph is not None and gs.replays == LONG_BATCHES - 7, (gs and gs.replays)
             assert int(dl.ring.dev_start.item()) == dl.ring.start
+            # the step behind the one without a look-ahead fetched its rows on the spot -- through the small captured graph of its own,
+            # not through collectives issued launch by launch between two replays
+            assert gs.pull_now_replays == (1 if pull else 0), gs.pull_now_replays
         else:
             assert gs is None
         if rank == 0:
@@ -315,7 +339,7 @@ def _long_worker(rank, world, port, q, backend, expect_replays):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("phase2", ["replicate", "pull"])
+@pytest.mark.parametrize("phase2", ["replicate", "pull", "auto+clean-probe"])
 def test_distributed_graph_replay_reproduces_long_golden_trace_rccl(monkeypatch, phase2):
     """the multi-GPU iteration is device-driven and replayed as ONE HIP graph with its RCCL collectives captured inside
     (world size 1 with LSTEP_FORCE_COLLECTIVES=1, the only RCCL set-up a one-GPU box allows): batches 0-3 fill the T = 4 window, 4-5
@@ -323,7 +347,12 @@ def test_distributed_graph_replay_reproduces_long_golden_trace_rccl(monkeypatch,
     REFERENCE produced (tests/golden/traces_long.npz)."""
     assert torch.cuda.is_available()
     monkeypatch.setenv("LSTEP_FORCE_COLLECTIVES", "1")
-    monkeypatch.setenv("LSTEP_PHASE2", phase2)
+    if phase2 == "auto+clean-probe":       # the auto-selected form of a job whose probe is clean ("pull"), through the captured step
+        monkeypatch.delenv("LSTEP_PHASE2", raising=False)
+        monkeypatch.setenv("LSTEP_TEST_PROBE", "clean")
+        monkeypatch.setenv("LSTEP_PULL_MIN_WORLD", "1")
+    else:
+        monkeypatch.setenv("LSTEP_PHASE2", phase2)
     monkeypatch.setenv("LSTEP_PULL_POISON", "1")
     _run(_long_worker, 1, "nccl", True)
 
@@ -648,7 +677,8 @@ def test_bench_captured_collective_probe_decisions(monkeypatch, tmp_path):
     monkeypatch.setenv("MASTER_PORT", "29700")
     monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
     seen["rc"] = 0
-    assert mod.rccl_graph_probe(4, 3, 3) == (True, "ok")
+    ok, note = mod.rccl_graph_probe(4, 3, 3)
+    assert ok is True and note.startswith("ok")
     assert seen["env"]["RANK"] == "3" and seen["env"]["WORLD_SIZE"] == "4" and seen["env"]["MASTER_PORT"] == "29723"
     assert "TORCHELASTIC_USE_AGENT_STORE" not in seen["env"] and seen["cmd"][-1].endswith(os.path.join("tools", "rccl_graph_probe.py"))
     seen["rc"], seen["err"] = 3, "rccl_graph_probe: rank 3: wrong values in replay 1\n"
@@ -659,3 +689,56 @@ def test_bench_captured_collective_probe_decisions(monkeypatch, tmp_path):
         raise subprocess.TimeoutExpired(cmd, timeout)
     monkeypatch.setattr(subprocess, "run", hang)
     assert mod.rccl_graph_probe(4, 0, 0) == (False, "timeout")
+    assert mod.rccl_probe_verdict(8, 0, 0) == {"captured": False, "pull": False, "note": "timeout"}
+
+    # round 5: the child's last stdout line is its verdict on the owner-sharded form's exchange pattern
+    class Out(Done):
+        def __init__(self, rc, out):
+            super().__init__(rc)
+            self.stdout = out
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, **kw: Out(0, 'rccl_graph_probe: 8 rank(s): ok\n{"captured": true, "pull": true, "pull_note": "ok"}\n'))
+    assert mod.rccl_probe_verdict(8, 0, 0) == {"captured": True, "pull": True, "note": "ok"}
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, **kw: Out(0, '{"captured": true, "pull": false, "pull_note": "wrong values in replay 1 on the second communicator"}\n'))
+    v = mod.rccl_probe_verdict(8, 0, 0)
+    assert v["captured"] is True and v["pull"] is False and "second communicator" in v["note"]
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None, **kw: Out(0, "no verdict line\n"))
+    assert mod.rccl_probe_verdict(8, 0, 0)["pull"] is False
+    assert mod.rccl_probe_verdict(1, 0, 0) == {"captured": True, "pull": True, "note": "skipped (one rank)"}
+
+
+def test_distributed_defaults_follow_the_cross_rank_probe(monkeypatch):
+    """What a multi-rank job runs BY DEFAULT (round-4 VERDICT item 2, ADVICE): the owner-sharded "pull" form beyond four ranks and the
+    whole-step graph with the collectives inside only behind a clean cross-rank probe; "replicate", launch by launch, without one.  The
+    decision logic alone, without a GPU or a process group."""
+    import types
+
+    import torch.distributed as dist
+    from lstep_amd.parallel import DistributedLstep
+    for k in ("LSTEP_PHASE2", "LSTEP_PULL_MIN_WORLD", "LSTEP_DIST_GRAPH"):
+        monkeypatch.delenv(k, raising=False)
+
+    def stub(world, probe, ok=True):
+        return types.SimpleNamespace(W=world, probe=probe, device="cuda:0", _device_update_ok=lambda: ok)
+    clean, no_pull = {"captured": True, "pull": True}, {"captured": True, "pull": False}
+    form = DistributedLstep._choose_form
+    assert form(stub(8, clean)) == "pull" and form(stub(5, clean)) == "pull"
+    assert form(stub(8, None)) == "replicate" and form(stub(8, no_pull)) == "replicate"
+    assert form(stub(4, clean)) == "replicate" and form(stub(2, clean)) == "replicate" and form(stub(1, clean)) == "replicate"
+    assert form(stub(8, clean, ok=False)) == "allgather"             # (configurations the device-count update does not cover)
+    monkeypatch.setenv("LSTEP_PHASE2", "pull")
+    assert form(stub(2, None)) == "pull"                              # (explicit choice: no probe needed)
+    monkeypatch.setenv("LSTEP_PHASE2", "auto")
+    monkeypatch.setenv("LSTEP_PULL_MIN_WORLD", "2")
+    assert form(stub(2, clean)) == "pull" and form(stub(2, None)) == "replicate"
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    allowed = DistributedLstep._graph_allowed
+    assert allowed(stub(1, None), None) is True                       # one rank: rehearsed on hardware
+    assert allowed(stub(8, None), None) is False and allowed(stub(8, {"captured": False, "pull": False}), None) is False
+    assert allowed(stub(8, clean), None) is True
+    monkeypatch.setenv("LSTEP_DIST_GRAPH", "1")
+    assert allowed(stub(8, None), None) is True                       # (the caller insists)
+    monkeypatch.setenv("LSTEP_DIST_GRAPH", "0")
+    assert allowed(stub(1, clean), None) is False
+    monkeypatch.delenv("LSTEP_DIST_GRAPH")
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+    assert allowed(stub(1, clean), None) is False

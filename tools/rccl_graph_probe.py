@@ -8,6 +8,13 @@ stream, ``capture_error_mode="thread_local"`` -- replays the graph three times o
 safe to capture the step; anything else (a wrong value, an exception, a crash, the parent's timeout) makes the bench fall back to the
 launch-by-launch device-driven iteration instead of failing the run.
 
+Round 5: a SECOND graph rehearses the owner-sharded ("pull") form's exchange pattern exactly as ``parallel.RowPullDev`` issues it inside a
+captured step -- two equal-split ``all_to_all_single`` calls issued synchronously from the capturing stream, last: int32 id blocks [W, Cp]
+one way, the float32 rows [W, Cp, P] they name the other way, every value checked on three replays with changing ids -- on the main
+communicator and on a second one (``dist.new_group``: what the launch-by-launch pull uses).  The last stdout line of rank 0's child AND of
+every other rank's is a JSON verdict {"captured": true, "pull": true|false}: ``bench.py`` lets ``DistributedLstep`` choose "pull" beyond four
+ranks only when every rank says pull = true, and "replicate" otherwise (exit code 0 either way: the basic capture is what decides the graph).
+
 env: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT (the parent passes its own port + an offset)."""
 import os
 import sys
@@ -21,6 +28,8 @@ def main() -> int:
     local = 0 if os.environ.get("LSTEP_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29591")
+    os.environ.setdefault("RANK", "0")                # (run by hand on a one-GPU box: one rank)
+    os.environ.setdefault("WORLD_SIZE", "1")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", device_id=dev)
@@ -75,8 +84,67 @@ def main() -> int:
     dist.barrier()
     if rank == 0:
         print(f"rccl_graph_probe: {world} rank(s): captured collectives replay correctly")
+    pull_ok, pull_note = True, "ok"
+    try:
+        pull_ok, pull_note = pull_pattern(rank, world, dev)
+    except Exception as e:  # noqa: BLE001  (the basic capture above is what decides the graph; the pull pattern only decides the form)
+        pull_ok, pull_note = False, f"{type(e).__name__}: {e}"
+    if not pull_ok:
+        print(f"rccl_graph_probe: rank {rank}: pull pattern: {pull_note}", file=sys.stderr)
+    import json
+    print(json.dumps({"captured": True, "pull": bool(pull_ok), "pull_note": pull_note}))
     sys.stdout.flush()
-    os._exit(0)        # (no communicator teardown: it can block behind the watchdog thread; the process has nothing left to do)
+    os._exit(0)        # (no communicator teardown: graphs that hold the communicator's kernels are still alive; the process has nothing left to do)
+
+
+def pull_pattern(rank: int, world: int, dev):
+    """The owner-sharded form's row pull as a captured step issues it (``parallel.RowPullDev`` with ``defer_exchange``): requester r asks owner
+    p for the rows ``req[p, :]`` (-1 = unused slot), the owner gathers them from its table, the rows come back in the same block layout."""
+    cp, width, rows = 512, 172, 4096
+    table = (torch.arange(rows, dtype=torch.float32, device=dev)[:, None] * 8.0 + float(rank)
+             + torch.arange(width, dtype=torch.float32, device=dev)[None, :] / 256.0)        # table[i, c] encodes (row, owner, column) exactly (24 bits)
+    seed = torch.zeros(1, dtype=torch.int64, device=dev)
+    req = torch.empty((world, cp), dtype=torch.int32, device=dev)
+    asked = torch.empty((world, cp), dtype=torch.int32, device=dev)
+    rows_out = torch.empty((world * cp, width), dtype=torch.float32, device=dev)
+    rows_in = torch.zeros((world * cp, width), dtype=torch.float32, device=dev)
+    slots = torch.arange(world * cp, dtype=torch.int64, device=dev).reshape(world, cp)
+
+    def body(group):
+        ids = (slots * 7 + seed + rank * 13) % rows
+        ids = torch.where(slots % 5 == 4, torch.full_like(ids, -1), ids)                              # holes, as in the fixed-capacity blocks
+        req.copy_(ids.to(torch.int32))
+        dist.all_to_all_single(asked.reshape(-1), req.reshape(-1), group=group)                       # synchronous, capturing stream
+        a = asked.reshape(-1).long()
+        rows_out.copy_(torch.where((a >= 0)[:, None], table[a.clamp(min=0)], torch.zeros((), device=dev)))
+        dist.all_to_all_single(rows_in, rows_out, group=group)
+
+    def check():
+        ids = ((slots * 7 + seed + rank * 13) % rows)
+        hole = slots % 5 == 4
+        owner = torch.arange(world, dtype=torch.float32, device=dev)[:, None].expand(world, cp)
+        want = ids.to(torch.float32)[:, :, None] * 8.0 + owner[:, :, None] + torch.arange(width, dtype=torch.float32, device=dev) / 256.0
+        want = torch.where(hole[:, :, None], torch.zeros((), device=dev), want)
+        return bool((rows_in.reshape(world, cp, width) == want).all())
+
+    second = dist.new_group(backend="nccl")
+    for name, group in (("main communicator", None), ("second communicator", second)):
+        body(group)                                   # once launch by launch (communicator set-up)
+        torch.cuda.synchronize()
+        if not check():
+            return False, f"wrong values launch by launch on the {name}"
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            body(group)
+        for it in range(3):
+            seed.fill_(101 * it + 17)
+            rows_in.fill_(-1.0)
+            graph.replay()
+            torch.cuda.synchronize()
+            if not check():
+                return False, f"wrong values in replay {it} on the {name}"
+    dist.barrier()
+    return True, "ok"
 
 
 if __name__ == "__main__":
