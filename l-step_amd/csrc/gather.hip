@@ -448,8 +448,9 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
                     part[u] = 0.f;
                     if ((j + u) < m && bcast_i32(nb, j + u) != 0) {     // wave-uniform
                         const float dj = bcast_f32(dt, j + u);
-                        part[u] = gt0 * time_feat(dj, w0, b0);          // (lanes past D hold gt = 0)
-                        part[u] = fmaf(gt1, time_feat(dj, w1, b1), part[u]);
+                        // (cos_hw: these dots only feed d(edge_agg.weight), and the kernel is bound by the cosines' issue slots)
+                        part[u] = gt0 * time_feat_grad(dj, w0, b0);     // (lanes past D hold gt = 0)
+                        part[u] = fmaf(gt1, time_feat_grad(dj, w1, b1), part[u]);
                     }
                 }
                 if (fa) {      // (same predicate as the loads: the rows need no merge value)

@@ -574,18 +574,33 @@ extern "C" int lstep_history_filter_runs_fwd(const float* hist, int64_t node_str
     return check_launch("history_filter_runs_fwd_kernel");
 }
 
-// Nodes per wave of the run backward: 128 when there are enough nodes to fill the chip (1 M-node workload: 32 768 batch nodes -> 1 792 waves),
-// fewer for small batches -- a wave walks its nodes one after the other, a few dependent row loads each, so 400 nodes in 4 chunks of
-// 128 took 250 us (28 waves on 1 024 SIMDs) where 8-node chunks take 20.
+// Nodes per wave of the run backward.  A wave walks its nodes one after the other -- one round trip per node: its run rows of the wave's
+// 16-snapshot group, ~4.5 loads -- so the launch takes (nodes per wave) x (a memory latency), whatever the number of waves, as long as they
+// are all resident: 143 registers = 3 waves per SIMD = 3072 on the chip.  Rounds 1-4 used 128 nodes per wave (1 792 waves for the
+// 1 M-node workload's 32 768 batch nodes: 1.75 per SIMD, 128 round trips: 272 us alone); halving the chunk doubles the waves past what
+// is resident and the second round costs what the shorter chunks gain (64: 277 us, 32: 302 us with the extra partials, round 5).  So: as
+// few nodes per wave as keeps every wave resident in ONE round -- ceil(nodes x groups / 3072), e.g. 75 for 32 768 nodes -- and
+// never fewer than 4 (small batches: 400 nodes in 4 chunks of 128 took 250 us where 8-node chunks take 20).
 static int runs_bwd_nodes_per_chunk(int64_t num_ids, int32_t t_len) {
     const int groups = (t_len + kRunsTimeGroup - 1) / kRunsTimeGroup;
-    int per = kBwdNodesPerChunk;
     if (const char* e = getenv("LSTEP_RUNS_BWD_CHUNK")) {      // tuning knob (tools/history_bench.py)
         const int v = atoi(e);
-        if (v >= 4 && v <= 1024) per = v;
+        if (v >= 4 && v <= 1024) return v;
     }
-    while (per > 4 && ((num_ids + per - 1) / per) * groups < 1024) per >>= 1;
-    return per;
+    static const int resident = [] {
+        int cus = 256;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        return cus * 4 * 3;       // SIMDs x waves per SIMD at this kernel's register count
+    }();
+    int64_t per = (num_ids * groups + resident - 1) / resident;
+    per = (per + 3) / 4 * 4;
+    if (per < 4) per = 4;
+    if (per > 1024) per = 1024;
+    return (int)per;
 }
 
 extern "C" int64_t lstep_history_filter_runs_bwd_chunks(int64_t num_ids, int32_t t_len) {

@@ -87,6 +87,19 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return
 // (utils/utils.py:166 stores neighbour times as float32; models/LSTEP.py:153,228-230 subtract in float64).
 __device__ __forceinline__ float delta_t(double t, double nbr_ts) { return (float)(t - (double)(float)nbr_ts); }
 
+// cos(x) on the hardware's transcendental unit (round 5): v_cos_f32 takes its argument in REVOLUTIONS and is only defined on [-256, 256], so
+// the argument is divided by 2 pi and reduced to [-0.5, 0.5] in float64 (exact enough up to 2e9: 22 fraction bits left at the top of the
+// range) -- 4 float64 instructions and one 8-cycle transcendental instead of the ~27 instructions of cos_full_range.  Measured over 4 M
+// arguments, log-uniform in [1e-6, 2e9] (tools/microbench/vcos_accuracy.hip, profiles/r05_cos_ab.txt): max |error| 2.7e-7, rms 4.3e-8
+// (cos_full_range: 9.1e-8 / 1.9e-8).  Used where a kernel is bound by the cosines' issue slots and the result feeds a parameter
+// GRADIENT (gather_aggregate_bwd_kernel: 212 -> 177 us alone at 49 152 rows); the forward kernels, whose outputs are held to the
+// reference's values, keep cos_full_range.
+__device__ __forceinline__ float cos_hw(float x) {
+    if (!(fabsf(x) <= 2.0e9f)) return cosf(x);      // (also NaN / inf)
+    const double rev = (double)x * 0.15915494309189533577;
+    return __builtin_amdgcn_cosf((float)(rev - __builtin_rint(rev)));
+}
+
 // cos(x) for any float32 x.  The time encoder's arguments span 1e-6 .. 1e9 inside ONE wave (w_d = 10^(-9 d / (D - 1)), models/modules.py:30),
 // so the library cosf runs its small-argument path AND its Payne-Hanek path (integer multi-word multiplies, ~150 instructions, divergent) for
 // every wave.  Up to 2e9 a float64 reduction by pi/2 (two-word constant: the reduced argument is exact to 1e-16) is enough; the rest is the
@@ -95,6 +108,8 @@ __device__ __forceinline__ float delta_t(double t, double nbr_ts) { return (floa
 __device__ __forceinline__ float cos_full_range(float x) {
 #ifdef LSTEP_LIBRARY_COS   // tuning A/B only
     return cosf(x);
+#elif defined(LSTEP_HW_COS)  // tuning A/B only (round 5): every cosine of the library through cos_hw below
+    return cos_hw(x);
 #else
     if (!(fabsf(x) <= 2.0e9f)) return cosf(x);      // (also NaN / inf)
     const double xd = (double)x;
@@ -111,11 +126,19 @@ __device__ __forceinline__ float cos_full_range(float x) {
 #endif
 }
 
+// (the same element for consumers that feed a gradient sum, not a reference-checked output: see cos_hw)
+#ifdef LSTEP_NO_HW_COS   // A/B switch back (build flag)
+#define LSTEP_TIME_FEAT_GRAD_COS cos_full_range
+#else
+#define LSTEP_TIME_FEAT_GRAD_COS cos_hw
+#endif
+
 // TimeEncoder element: cos(dt * w + b) in float32 (models/modules.py:37).  Full-range: arguments reach 1e9.
 #ifdef LSTEP_ABLATE_COS  // tuning experiment only: price of the cosine (never defined in product builds)
 __device__ __forceinline__ float time_feat(float dt, float w, float b) { return fmaf(dt, w, b); }
 #else
 __device__ __forceinline__ float time_feat(float dt, float w, float b) { return cos_full_range(fmaf(dt, w, b)); }
 #endif
+__device__ __forceinline__ float time_feat_grad(float dt, float w, float b) { return LSTEP_TIME_FEAT_GRAD_COS(fmaf(dt, w, b)); }
 
 }  // namespace lstep

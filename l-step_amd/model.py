@@ -961,6 +961,10 @@ class _GatherAggregate(torch.autograd.Function):
         if sink is not None and torch.cuda.is_current_stream_capturing():
             sink = None                                  # (timed events cannot be recorded into a graph)
         if sink is not None:
+            if getattr(mod, "gather_event_idle", False):
+                # bench.py's second timing: the launch with every other stream idle (the in-step launch runs beside the window slide,
+                # history_advance_oldest, on the auxiliary stream: roofline.launch_ms vs roofline.launch_ms_idle)
+                torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         ws_flag = nat.WEIGHTED_SUM if (en and mod.weighted_sum) else 0
