@@ -1022,10 +1022,17 @@ class _GatherAggregate(torch.autograd.Function):
         grad_rows = None
         hits = None
         use_slot = False
+        atomic_rows = False
         if want_pe:
             if need_rows:
                 use_slot = True
-                hits = torch.empty((B, K), dtype=torch.int32, device=dev)   # sort-based reduction below, no atomics
+                # LSTEP_HITS_ATOMIC=1 (A/B, measured and left off: DESIGN.md appendix A): the spliced rows' gradient accumulated by the
+                # backward kernel itself with float atomics instead of hit list -> compaction -> sort -> segment sums
+                atomic_rows = os.environ.get("LSTEP_HITS_ATOMIC") == "1" and ctx.explicit is None
+                if atomic_rows:
+                    grad_rows = torch.zeros(ctx.rows_shape, dtype=torch.float32, device=dev)
+                else:
+                    hits = torch.empty((B, K), dtype=torch.int32, device=dev)   # sort-based reduction below, no atomics
             else:
                 grad_rows = torch.zeros(ctx.pe_shape, dtype=torch.float32, device=dev)
         tw, tb = mod.time_encoder.w.weight, mod.time_encoder.w.bias
@@ -1076,7 +1083,7 @@ class _GatherAggregate(torch.autograd.Function):
         g_w_done = g_w is not None
         if os.environ.get("LSTEP_WGRAD_LATE") != "1":
             _flush_deferred(dev)     # the critical kernel is out: now launch the postponed auxiliary-stream work
-        if use_slot:
+        if use_slot and not atomic_rows:
             grad_rows = _reduce_spliced_gradient(mod, ctx.rows_shape[0], hits, g_pe, (slot_of, ids), g_self, ctx.self_groups)
         if g_w is None and slot_dot is not None:
             g_w = slot_dot.sum(dim=0)
