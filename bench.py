@@ -492,6 +492,7 @@ def main():
         torch.cuda.set_sync_debug_mode("warn")
     sink = []
     model[0].gather_event_sink = sink
+    steps_issued = args.warmup + args.steps       # (batches consumed so far; the event-timed launch-by-launch iterations below go on from here)
     trace = os.environ.get("LSTEP_BENCH_TRACE") == "1"      # per-step host / GPU times on stderr (does not drain the GPU between steps)
     marks = []
     barrier()
@@ -532,6 +533,7 @@ def main():
         extra = max(3, min(10, args.steps))
         for i in range(extra):
             step(args.warmup + args.steps + i)
+        steps_issued = args.warmup + args.steps + extra
         barrier()
         runner.use_step_graph = eng_g
         timing_note = (f"the timed steps are graph replays, which cannot carry timed events: HIP events around the gather launch of the {extra} "
@@ -545,10 +547,9 @@ def main():
         eng_g = getattr(runner, "use_step_graph", None)
         runner.use_step_graph = False
         model[0].gather_event_sink, model[0].gather_event_idle = idle_sink, True
-        base_i = args.warmup + args.steps + 10
         for i in range(5):
-            if (start + (base_i + i + 2) * B * world) <= wl.num_edges:
-                step(base_i + i)
+            if (start + (steps_issued + i + 2) * B * world) <= wl.num_edges:
+                step(steps_issued + i)
         barrier()
         model[0].gather_event_sink, model[0].gather_event_idle = None, False
         runner.use_step_graph = eng_g

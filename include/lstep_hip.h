@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 37
+#define LSTEP_ABI_VERSION 38
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -76,6 +76,20 @@ const char* lstep_last_error(void);
  * lstep_stream_destroy: the stream must be idle and not capturing. */
 int lstep_stream_create(void** out_stream, int32_t priority);
 int lstep_stream_destroy(void* stream);
+
+/* Checked build (round 5; no reference counterpart: the reference's index errors are Python IndexErrors, utils/utils.py:160-169,
+ * models/LSTEP.py:152,181,233).  A library compiled with -DLSTEP_BOUNDS_CHECK=1 (tools/build_checked.py -> liblstep_hip_checked.so, loaded
+ * with LSTEP_LIB=...) compares every id-indexed load of its kernels -- neighbour / edge / node ids in the gather stage, row ids of
+ * update_pe, of the history filter, of the loss and of the row scatters -- with the row count of the table it indexes; an index out of
+ * range reads the padding row 0 instead of faulting the GPU and is recorded in a sticky device record.
+ * lstep_debug_bounds_check_enabled: 1 in a checked build, 0 otherwise (the other two calls are then no-ops that report nothing).
+ * lstep_debug_set_limits: rows of the node-shaped tables (node features, PE tables: N + 1) and of the edge table (E + 1), for the loads
+ *   whose entry point carries no row count of its own (0 = unknown: not checked).
+ * lstep_debug_device_error: waits for the device, returns {tag of the first offending load (0 = none), its index, the limit, number of
+ *   offenders since the last call} and clears the record.  Tags: enum CheckTag in csrc/lstep_common.h. */
+int lstep_debug_bounds_check_enabled(void);
+int lstep_debug_set_limits(int64_t node_rows, int64_t edge_rows);
+int lstep_debug_device_error(int64_t out[4]);
 
 /* S -- NeighborSampler.get_historical_neighbors, 'recent' strategy (utils/utils.py:148-213, search :129-146).
  * Row r < min(num_ids, num_times): the last min(c, K) of the c interactions of node_ids[r] strictly earlier

@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 37
+ABI_VERSION = 38
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -119,6 +119,9 @@ SIGNATURES = {
     "lstep_last_error": (C.c_char_p, []),
     "lstep_stream_create": (C.c_int, [C.POINTER(C.c_void_p), _I32]),
     "lstep_stream_destroy": (C.c_int, [_P]),
+    "lstep_debug_bounds_check_enabled": (C.c_int, []),
+    "lstep_debug_set_limits": (C.c_int, [_I64, _I64]),
+    "lstep_debug_device_error": (C.c_int, [C.POINTER(C.c_int64)]),
     "lstep_sample_recent": (C.c_int, [C.POINTER(CsrStruct), _P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P]),
     "lstep_time_encode": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P, _P]),
     "lstep_gather_aggregate_fwd": (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32,
@@ -218,6 +221,63 @@ def load_library():
         raise LstepNativeError("liblstep_hip.so ABI version mismatch; rebuild")
     _LIB = lib
     return lib
+
+
+CHECK_TAGS = {1: "gather forward: row's own node id", 2: "gather forward: neighbour id (edge / PE channel slots)", 3: "gather forward: edge id",
+              4: "gather forward: neighbour id (node channel slots)", 5: "gather backward: row's own node id", 6: "gather backward: neighbour id",
+              7: "gather backward: edge id", 8: "sampler: node id", 9: "history filter: node id", 10: "update_rows: row id",
+              11: "link loss: endpoint id", 12: "row scatter / residual update: row id", 13: "segment sum: source row", 14: "segment sum: segment id",
+              15: "rows_by_id: row id", 16: "scatter_owner_rows: row id", 17: "spliced_grad_small: own-node id"}
+
+
+def bounds_check_enabled() -> bool:
+    """Is the loaded library a checked build (``-DLSTEP_BOUNDS_CHECK=1``: ``build_checked_library``, loaded with ``LSTEP_LIB=...``)?"""
+    return bool(load_library().lstep_debug_bounds_check_enabled())
+
+
+_DEBUG_LIMITS = [0, 0]
+
+
+def set_debug_limits(node_rows: int, edge_rows: int, reset: bool = False):
+    """Row counts of the node-shaped tables and of the edge table for the guards of a checked build whose entry points carry no row count
+    of their own (no-op in a product build).  The limits are process-wide, so they only ever GROW (the largest tables any model of the
+    process holds: an id valid for one of them never trips a guard); ``reset=True`` starts over (tests/conftest.py: per test)."""
+    lib = load_library()
+    if lib.lstep_debug_bounds_check_enabled():
+        if reset:
+            _DEBUG_LIMITS[:] = [0, 0]
+        _DEBUG_LIMITS[0], _DEBUG_LIMITS[1] = max(_DEBUG_LIMITS[0], int(node_rows)), max(_DEBUG_LIMITS[1], int(edge_rows))
+        check(lib.lstep_debug_set_limits(_DEBUG_LIMITS[0], _DEBUG_LIMITS[1]))
+
+
+def device_error():
+    """None, or (tag, description, index, limit, count) of the first out-of-range id a checked build's kernels met since the last call."""
+    lib = load_library()
+    if not lib.lstep_debug_bounds_check_enabled():
+        return None
+    out = (C.c_int64 * 4)()
+    check(lib.lstep_debug_device_error(out))
+    if out[0] == 0:
+        return None
+    return int(out[0]), CHECK_TAGS.get(int(out[0]), "?"), int(out[1]), int(out[2]), int(out[3])
+
+
+def check_device_errors():
+    """Raise if a checked build's kernels met an out-of-range id (they read the padding row instead of faulting the GPU)."""
+    err = device_error()
+    if err is not None:
+        tag, what, idx, limit, count = err
+        raise LstepNativeError(f"checked build: out-of-range id in {what} (tag {tag}): index {idx}, table rows {limit}; {count} offending load(s)")
+
+
+CHECKED_LIB_PATH = os.path.join(CSRC, "liblstep_hip_checked.so")
+
+
+def build_checked_library(force: bool = False) -> str:
+    """The same sources with ``-DLSTEP_BOUNDS_CHECK=1`` into ``csrc/liblstep_hip_checked.so`` (use: ``LSTEP_LIB=<that path> python -m pytest ...``)."""
+    if not force and os.path.exists(CHECKED_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(CHECKED_LIB_PATH) for d in _deps() if os.path.exists(d)):
+        return CHECKED_LIB_PATH
+    return build_library(defines=("LSTEP_BOUNDS_CHECK=1",), lib_path=CHECKED_LIB_PATH)
 
 
 def check(rc: int):

@@ -48,8 +48,12 @@ __global__ __launch_bounds__(kBlock) void fft_coef_fwd_kernel(const float* __res
     __syncthreads();
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
         double acc = 0.0;
+        // (unrolled: the filter weights come from global memory inside this loop -- one dependent-latency load per step otherwise; these
+        // three parameter-side kernels sit on the critical chain of EVERY configuration: 14.6 + 11 + 12 us at T = 100 before, round 5)
+#pragma unroll 10
         for (int f = 0, k = 0; f < T; ++f) {           // k = (f * s) mod T
-            const cd q = cmul(cd{(double)w[((size_t)f * P + p) * 2], (double)w[((size_t)f * P + p) * 2 + 1]}, c[f]);
+            const float2 wv = *reinterpret_cast<const float2*>(w + ((size_t)f * P + p) * 2);
+            const cd q = cmul(cd{(double)wv.x, (double)wv.y}, c[f]);
             const cd e = tw[k];                                    // e^{-i theta} = conj
             acc += e.re * q.re + e.im * q.im;                      // Re(conj(e) q)
             k += s;
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(kBlock) void fft_coef_bwd_kernel(const float* __res
     double sr = 0.0, si = 0.0;
     for (int p = threadIdx.x; p < P; p += blockDim.x) {
         cd gq{0.0, 0.0};
+#pragma unroll 10
         for (int s = 0, k = 0; s < T; ++s) {           // k = (f * s) mod T
             const cd e = tw[k];
             const double gv = (double)g[(size_t)s * P + p];
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(kBlock) void fft_coef_bwd_agg_kernel(const double* 
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         double acc = 0.0;
+#pragma unroll 10
         for (int f = 0, k = 0; f < T; ++f) {           // k = (f * t) mod T
             const cd e = tw[k];
             const double sc = m[f] / (double)T;

@@ -106,6 +106,8 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
                 ed = p.csr.eid[e];
                 dt = delta_t(t, p.csr.ts[e]);
             }
+            nb = LSTEP_CHECKED(nb, p.csr.num_rows, kCheckGatherFwdNbr);       // (checked builds only: lstep_common.h)
+            ed = LSTEP_CHECKED(ed, LSTEP_EDGE_ROWS(), kCheckGatherFwdEdge);
             if (kEdgeNode) aw = p.edge_agg_w[npad + c0 + lane];
         }
         // Settle the slot metadata BEFORE the row loop: otherwise hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         int valid = 0;
         for (int64_t c0 = 0; c0 < v; c0 += kWave) {
             const int m = (int)((v - c0) < kWave ? (v - c0) : kWave);
-            const int idx = lane < m ? (kExplicit ? (int)p.ex_nbr_g[row * (int64_t)p.G + c0 + lane] : p.csr.nbr[vfirst + c0 + lane]) : 0;
+            int idx = lane < m ? (kExplicit ? (int)p.ex_nbr_g[row * (int64_t)p.G + c0 + lane] : p.csr.nbr[vfirst + c0 + lane]) : 0;
+            idx = LSTEP_CHECKED(idx, p.csr.num_rows, kCheckGatherFwdNbrGap);
             float wslot = 1.f;
             if (p.weighted_sum && lane < m) {
                 const int64_t s = c0 + lane;
@@ -272,7 +275,8 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             int pvalid = 0;
             for (int64_t c0 = (int64_t)wv * kWave; c0 < vr; c0 += (int64_t)kWave * kWavesPerBlock) {
                 const int m = (int)((vr - c0) < kWave ? (vr - c0) : kWave);
-                const int idx = lane < m ? (kExplicit ? (int)p.ex_nbr_g[first + c0 + lane] : p.csr.nbr[first + c0 + lane]) : 0;
+                int idx = lane < m ? (kExplicit ? (int)p.ex_nbr_g[first + c0 + lane] : p.csr.nbr[first + c0 + lane]) : 0;
+                idx = LSTEP_CHECKED(idx, p.csr.num_rows, kCheckGatherFwdNbrGap);
                 pvalid += __popcll(__ballot(idx > 0));
                 settle(idx);
                 for (int j = 0; j < m; j += kCoopRowsInFlight) {
@@ -423,6 +427,8 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_bwd_kernel(GatherBwdP
                 ed = p.csr.eid[e];
                 dt = delta_t(t, p.csr.ts[e]);
             }
+            nb = LSTEP_CHECKED(nb, p.csr.num_rows, kCheckGatherBwdNbr);       // (checked builds only: lstep_common.h)
+            ed = LSTEP_CHECKED(ed, LSTEP_EDGE_ROWS(), kCheckGatherBwdEdge);
         }
         if (do_edge) {
             // Settled metadata, kBwdRows edge rows in flight, the slots' time-feature dots computed while they travel, and ONE butterfly

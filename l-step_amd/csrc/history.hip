@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void history_filter_fwd_kernel(HistView h, 
     const int64_t u = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (u >= num_ids) return;
     if (lane >= (P >> 2)) return;
-    const int64_t node = ids[u];
+    const int64_t node = LSTEP_CHECKED(ids[u], LSTEP_NODE_ROWS(), kCheckFilterNode);      // (checked builds only: lstep_common.h)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < t_len; s += kHistInFlight) {
         float4 x[kHistInFlight], c[kHistInFlight];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void history_filter_bwd_kernel(HistView h, 
 #pragma unroll
     for (int i = 0; i < kBwdTimeGroup; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t u = u0; u < u1; ++u) {
-        const int64_t node = ids[u];
+        const int64_t node = LSTEP_CHECKED(ids[u], LSTEP_NODE_ROWS(), kCheckFilterNode);
         const float4 g = ld4(grad + u * (int64_t)P + lane * 4);
         float4 x[kBwdTimeGroup];
 #pragma unroll
@@ -207,13 +207,13 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : kBlock) void history_filter_runs_fw
     if (u >= num_ids) return;
     const bool active = lane < (P >> 2);
     const int col = active ? lane * 4 : 0;
-    int64_t node = uniform_i64(ids[u]);
+    int64_t node = uniform_i64(LSTEP_CHECKED(ids[u], LSTEP_NODE_ROWS(), kCheckFilterNode));
     ChangeBits bits = load_change_bits(mask, words, node, h.slots, h.rot);
     for (; u < num_ids; u += waves) {
         const int64_t node_now = node;
         const ChangeBits b = bits;
         if (u + waves < num_ids) {
-            node = uniform_i64(ids[u + waves]);
+            node = uniform_i64(LSTEP_CHECKED(ids[u + waves], LSTEP_NODE_ROWS(), kCheckFilterNode));
             bits = load_change_bits(mask, words, node, h.slots, h.rot);
         }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -303,13 +303,13 @@ __global__ __launch_bounds__(kBlock) void history_filter_runs_bwd_kernel(HistVie
 #pragma unroll
     for (int i = 0; i < kRunsTimeGroup; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t valid = t_len - s0 >= kRunsTimeGroup ? 0xFFFFu : (1u << (t_len - s0)) - 1u;   // s0 < t_len: groups = ceil(t_len / 16)
-    int64_t node = uniform_i64(ids[u0]);
+    int64_t node = uniform_i64(LSTEP_CHECKED(ids[u0], LSTEP_NODE_ROWS(), kCheckFilterNode));
     ChangeBits bits = load_change_bits(mask, words, node, h.slots, h.rot);
     for (int64_t u = u0; u < u1; ++u) {
         const int64_t node_now = node;
         const ChangeBits b = bits;
         if (u + 1 < u1) {     // next node's id and mask travel while this node's rows do
-            node = uniform_i64(ids[u + 1]);
+            node = uniform_i64(LSTEP_CHECKED(ids[u + 1], LSTEP_NODE_ROWS(), kCheckFilterNode));
             bits = load_change_bits(mask, words, node, h.slots, h.rot);
         }
         const float4 g = ld4(grad + u * (int64_t)P + col);

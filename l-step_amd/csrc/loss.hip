@@ -54,7 +54,8 @@ __global__ __launch_bounds__(kBlock) void link_loss_kernel(const LinkLossParams 
             bce += bce_term(p, y);
             q.d_logits[j] = bce_grad_logit(p, y, (1.f - q.pe_weight) / (float)(2 * q.n));
         }
-        const int64_t a = q.ids[i], b = q.ids[q.n + i], c = q.ids[2 * q.n + i];
+        const int64_t a = LSTEP_CHECKED(q.ids[i], LSTEP_NODE_ROWS(), kCheckLossNode), b = LSTEP_CHECKED(q.ids[q.n + i], LSTEP_NODE_ROWS(), kCheckLossNode),
+                      c = LSTEP_CHECKED(q.ids[2 * q.n + i], LSTEP_NODE_ROWS(), kCheckLossNode);      // (checked builds only: lstep_common.h)
         const int sa = q.slot_of[a], sb = q.slot_of[b], sc = q.slot_of[c];
         const float* ra = sa >= 0 ? q.rows + (int64_t)sa * P : q.table + a * P;
         const float* rb = sb >= 0 ? q.rows + (int64_t)sb * P : q.table + b * P;

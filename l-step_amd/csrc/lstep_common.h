@@ -17,6 +17,50 @@ constexpr int kMaxRowVec = 64;     // one float4 per lane => rows up to 256 floa
 int set_error(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
+// ---- checked build (-DLSTEP_BOUNDS_CHECK=1, `python tools/build_checked.py`): every id-indexed load of the kernels compares its index with
+// the table's row count first.  An index out of range does NOT fault the GPU (it is replaced by row 0, the padding row): the first
+// offender is recorded in a sticky device record -- which load (tag), the index, the limit -- that lstep_debug_device_error returns and
+// clears, so that ONE ordinary run of the test suite names the kernel (tests/conftest.py checks it behind every GPU test when the
+// loaded library is a checked build).  Product builds compile the checks away.
+enum CheckTag : int {
+    kCheckGatherFwdNode = 1, kCheckGatherFwdNbr = 2, kCheckGatherFwdEdge = 3, kCheckGatherFwdNbrGap = 4,
+    kCheckGatherBwdNode = 5, kCheckGatherBwdNbr = 6, kCheckGatherBwdEdge = 7,
+    kCheckSampleNode = 8, kCheckFilterNode = 9, kCheckUpdateRowsId = 10, kCheckLossNode = 11, kCheckScatterRowsId = 12,
+    kCheckSegmentRow = 13, kCheckSegmentSeg = 14, kCheckRowsById = 15, kCheckOwnerRowsId = 16, kCheckSplicedGradKey = 17,
+};
+#ifdef LSTEP_BOUNDS_CHECK
+// words: [0] tag of the first offender (0 = none), [1] its index, [2] its limit, [3] number of offenders, [4] node-table rows, [5] edge-table
+// rows (lstep_debug_set_limits; 0 = unknown: loads without a row count of their own are then not checked).  One pointer per translation
+// unit (no relocatable device code in this build), all set to the same buffer by lstep_debug_* in api.hip.
+static __device__ unsigned long long* g_check_words = nullptr;
+void register_check_setter(void (*fn)(unsigned long long*));
+namespace {
+struct CheckTu {
+    CheckTu() {
+        register_check_setter([](unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_check_words), &p, sizeof(p)); });
+    }
+} g_check_tu;
+}  // namespace
+__device__ __forceinline__ bool check_index(long long idx, long long limit, int tag) {
+    if (limit <= 0 || (idx >= 0 && idx < limit)) return true;
+    unsigned long long* w = g_check_words;
+    if (w != nullptr) {
+        if (atomicCAS(w, 0ull, (unsigned long long)tag) == 0ull) { w[1] = (unsigned long long)idx; w[2] = (unsigned long long)limit; }
+        atomicAdd(w + 3, 1ull);
+    }
+    return false;
+}
+__device__ __forceinline__ long long check_node_rows() { return g_check_words ? (long long)g_check_words[4] : 0; }
+__device__ __forceinline__ long long check_edge_rows() { return g_check_words ? (long long)g_check_words[5] : 0; }
+#define LSTEP_CHECKED(idx, limit, tag) (lstep::check_index((long long)(idx), (long long)(limit), (tag)) ? (idx) : 0)
+#define LSTEP_NODE_ROWS() lstep::check_node_rows()
+#define LSTEP_EDGE_ROWS() lstep::check_edge_rows()
+#else
+#define LSTEP_CHECKED(idx, limit, tag) (idx)
+#define LSTEP_NODE_ROWS() 0
+#define LSTEP_EDGE_ROWS() 0
+#endif
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 // wave index inside the workgroup, as a scalar (the compiler cannot prove threadIdx.x >> 6 is wave-uniform)
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

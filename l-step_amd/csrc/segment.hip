@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void scatter_rows_kernel(float* __restrict_
     const int lane = lane_id();
     const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (i >= num_ids) return;
-    const int64_t r = ids[i];
+    const int64_t r = LSTEP_CHECKED(ids[i], LSTEP_NODE_ROWS(), kCheckScatterRowsId);      // (checked builds only: lstep_common.h)
     for (int c = lane; c < (W >> 2); c += kWave) st4(table + r * W + c * 4, ld4(rows + i * W + c * 4));
 }
 
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void residual_tanh_rows_kernel(float* __res
     const int lane = lane_id();
     const int64_t i = (int64_t)blockIdx.x * kWavesPerBlock + wave_in_block();
     if (i >= num_ids) return;
-    const int64_t r = ids[i];
+    const int64_t r = LSTEP_CHECKED(ids[i], LSTEP_NODE_ROWS(), kCheckScatterRowsId);
     for (int c = lane; c < (W >> 2); c += kWave) {
         const float4 a = ld4(table + r * W + c * 4);
         const float4 b = ld4(z + i * (int64_t)ld_z + c * 4);
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kSpliceWaves * kWave) void spliced_grad_small_kerne
             }
             if (pass == 1) {
 #pragma unroll
-                for (int a = 0; a < kSpliceAhead; ++a) key[a] = key[a] >= 0 ? slot_of[key[a]] : -2;
+                for (int a = 0; a < kSpliceAhead; ++a) key[a] = key[a] >= 0 ? slot_of[LSTEP_CHECKED(key[a], LSTEP_NODE_ROWS(), kCheckSplicedGradKey)] : -2;
             }
 #pragma unroll
             for (int a = 0; a < kSpliceAhead; ++a) {       // (only the cheap part is unrolled: the keys stay in registers)

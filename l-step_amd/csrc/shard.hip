@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void scatter_owner_rows_kernel(const float*
     if (e >= (int64_t)world * C) return;
     const int64_t p = e / C, i = e - p * C;
     if (i >= counts[p]) return;
-    const int64_t id = ids[e];
+    const int64_t id = LSTEP_CHECKED(ids[e], LSTEP_NODE_ROWS(), kCheckOwnerRowsId);      // (checked builds only: lstep_common.h)
     for (int c = lane; c < (width >> 2); c += kWave) st4(table + id * width + c * 4, ld4(rows + e * (int64_t)ld_rows + c * 4));
     if (slot_of && lane == 0) slot_of[id] = (int32_t)e;
 }
@@ -101,6 +101,9 @@ __global__ __launch_bounds__(kBlock) void rows_by_id_kernel(const int32_t* __res
     if (e >= n) return;
     const int64_t id = ids[e];
     if (id < 0) return;
+#ifdef LSTEP_BOUNDS_CHECK
+    if (!check_index(id, LSTEP_NODE_ROWS(), kCheckRowsById)) return;      // (checked builds: an id past the table is skipped and recorded)
+#endif
     float* t = table + id * width;
     float* b = buf + e * (int64_t)width;
     for (int c = lane; c < (width >> 2); c += kWave) {

@@ -653,7 +653,7 @@ __device__ __forceinline__ void update_rows_task(const UpdateParams& p, int64_t 
         live[s] = r < p.n;
         if (!live[s]) r = p.n - 1;
         agg_l[s] = p.agg + r * p.ld_agg + 4 * g;
-        id[s] = p.ids[r];
+        id[s] = LSTEP_CHECKED(p.ids[r], LSTEP_NODE_ROWS(), kCheckUpdateRowsId);      // (checked builds only: lstep_common.h)
     }
     auto wlane = [&](const float* w, int ldw) { return w + i * ldw + 4 * g; };
     // A wave has its SIMD to itself (all 512 registers): whatever it waits for, nothing else on the SIMD covers.  So the row loads are batched
@@ -817,7 +817,7 @@ __device__ __forceinline__ void update_rows_pre_task_halves(const UpdateParams& 
     const bool live = r < p.n;
     if (!live) r = p.n - 1;
     const float* agg_l = p.agg + r * p.ld_agg + 4 * g;
-    const int64_t id = p.ids[r];
+    const int64_t id = LSTEP_CHECKED(p.ids[r], LSTEP_NODE_ROWS(), kCheckUpdateRowsId);
     float* own_row = p.table + id * p.pe_dim;
     float* mir_row = nullptr;
     if (p.mirror) {
@@ -883,10 +883,10 @@ __global__ __launch_bounds__(kBlock) void update_rows_split_kernel(UpdateParams 
     const bool live = r0 + i < p.n;
     const int64_t r = live ? r0 + i : p.n - 1;
     const float* agg_l = p.agg + r * p.ld_agg + 4 * g;
-    float* own_row = p.table + p.ids[r] * p.pe_dim;
+    float* own_row = p.table + LSTEP_CHECKED(p.ids[r], LSTEP_NODE_ROWS(), kCheckUpdateRowsId) * p.pe_dim;
     float* mir_row = nullptr;
     if (p.mirror) {
-        const int64_t id = p.ids[r];
+        const int64_t id = LSTEP_CHECKED(p.ids[r], LSTEP_NODE_ROWS(), kCheckUpdateRowsId);
         if (p.mirror_world > 1) {
             if (id % p.mirror_world == p.mirror_rank) mir_row = p.mirror + (id / p.mirror_world) * p.pe_dim;
         } else {

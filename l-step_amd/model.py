@@ -1254,6 +1254,8 @@ class LSTEP(nn.Module):
         # plain attributes, not buffers: the reference keeps them out of state_dict too (models/LSTEP.py:45-46)
         self.node_raw_features = table(node_raw_features)
         self.edge_raw_features = table(edge_raw_features)
+        # (a checked build -- LSTEP_LIB=.../liblstep_hip_checked.so -- learns the table heights its guards compare ids with; no-op otherwise)
+        nat.set_debug_limits(self.node_raw_features.shape[0], self.edge_raw_features.shape[0])
         self.neighbor_sampler = neighbor_sampler
         self.full_neighbor_sampler = full_neighbor_sampler
         self.time_encoder = TimeEncoder(time_feat_dim, parameter_requires_grad=False)

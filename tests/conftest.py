@@ -81,3 +81,19 @@ if _STREAM_LOG:
 def _stream_probe_test_name(request):
     _CURRENT_TEST[0] = request.node.nodeid
     yield
+
+
+@pytest.fixture(autouse=True)
+def _checked_build_record(request):
+    """With a checked build loaded (LSTEP_LIB=.../liblstep_hip_checked.so, tools/build_checked.py) every GPU test ends by asking the library for
+    its sticky out-of-range record: an id that would have faulted the GPU (or read a neighbour's memory) fails THIS test, by kernel."""
+    checked = request.node.get_closest_marker("gpu") is not None and os.environ.get("LSTEP_LIB", "").find("checked") >= 0
+    if checked:
+        import torch
+        checked = torch.cuda.is_available()
+    if checked:
+        from lstep_amd import _native as nat
+        nat.set_debug_limits(0, 0, reset=True)      # (the table heights are process-wide: every test starts from "unknown"; models raise them)
+    yield
+    if checked:
+        nat.check_device_errors()

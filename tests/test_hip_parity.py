@@ -2128,3 +2128,54 @@ def test_role_streams_never_come_from_the_framework_pool(hip):
     default_capture = torch.cuda.graph.default_capture_stream
     if default_capture is not None:
         assert default_capture.cuda_stream not in seen.values()
+
+
+def test_checked_build_names_an_out_of_range_id():
+    """The checked twin of the library (``-DLSTEP_BOUNDS_CHECK=1``, built by ``__graft_entry__.build()`` next to the product library): an
+    out-of-range neighbour id in an explicit slot list -- which the product kernels would follow into whatever memory lies there, the kind of
+    access that ends in "Memory access fault by GPU" -- reads the padding row instead and is reported by kernel, id and limit.  Run in a child
+    process: the library is chosen at import time (LSTEP_LIB)."""
+    import subprocess
+    import sys
+    from lstep_amd import _native as nat
+    assert os.path.exists(nat.CHECKED_LIB_PATH), "run `python -c 'import __graft_entry__ as g; g.build()'` (it builds the checked library too)"
+    code = r'''
+import numpy as np, torch
+from lstep_amd import _native as nat, synth
+from lstep_amd.sampler import NeighborSampler
+from lstep_amd.workload import build_hip_model
+assert nat.bounds_check_enabled()
+N, E, K, T = 40, 400, 4, 4
+g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=1)
+node_raw, edge_raw = synth.make_features(N, E, seed=2)
+sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=N, sample_neighbor_strategy="uniform", seed=3, device="cuda:0")
+model = build_hip_model(node_raw, edge_raw, sampler, K, T, synth.make_state_dict(K, T), "cuda:0")
+bb = model[0]
+assert nat.device_error() is None
+ids, ts = g["src"][300:308], g["ts"][300:308]
+with torch.no_grad():
+    out = bb.aggregated_node_embeddings(ids, ts, K, 8)          # clean: nothing recorded
+torch.cuda.synchronize()
+assert nat.device_error() is None
+real = sampler.get_historical_neighbors
+def poisoned(node_ids, times, k):
+    n, e, t = real(node_ids, times, k)
+    n = n.copy(); n[0, -1] = N + 1000                             # a neighbour id far past the node table
+    return n, e, t
+sampler.get_historical_neighbors = poisoned
+with torch.no_grad():
+    out = bb.aggregated_node_embeddings(ids, ts, K, 8)
+torch.cuda.synchronize()
+err = nat.device_error()
+assert err is not None, "the out-of-range id was not recorded"
+tag, what, idx, limit, count = err
+assert idx == N + 1000 and limit == N + 1 and tag in (2, 4) and count >= 1, err
+assert nat.device_error() is None                                 # the record is cleared by reading it
+assert torch.isfinite(out).all()
+print("checked build:", what, idx, limit, count)
+'''
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = dict(os.environ, LSTEP_LIB=nat.CHECKED_LIB_PATH, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "checked build:" in r.stdout
