@@ -782,6 +782,20 @@ class LstepEngine:
         if (on_device and batch_idx > 0 and src.dtype == dst.dtype == neg_dst.dtype == torch.int64 and ts.dtype == torch.float64
                 and src.device == dst.device == neg_dst.device == ts.device and os.environ.get("LSTEP_NO_BATCH_PREPARE") != "1"):
             prep = self.prepare_batch(src, dst, neg_dst, ts)
+        # LSTEP_SPLIT_FORWARD=1 (A/B, measured and left off: DESIGN.md appendix A): the gather stage's edge + node channels -- 70 % of its
+        # bytes, and independent of the FFT splice -- launched on a side stream BEFORE the batch-node grouping and the history filter, the
+        # PE channel behind the splice; two launches instead of one fused one.
+        ahead = None
+        if (prep is not None and os.environ.get("LSTEP_SPLIT_FORWARD") == "1" and bb._fused_tail_ok()
+                and getattr(bb.neighbor_sampler, "sample_neighbor_strategy", "recent") == "recent"):
+            main = torch.cuda.current_stream(self.device)
+            fwd_side = nat.role_stream(self.device, "fwd-side")
+            fwd_side.wait_stream(main)
+            with torch.cuda.stream(fwd_side):
+                x_edge, x_node, _, _, _ = bb._gather(None, prep[0], prep[1], self.K, self.G, nat.BRANCH_EDGE_NODE, wide=True, row_blocks=3)
+                ev = torch.cuda.Event()
+                ev.record()
+            ahead = (x_edge, x_node, ev)
         if on_device:
             batch_nodes, n_live, presorted = self.batch_nodes_device(src, dst, keys=prep[2] if prep is not None else None)
         else:
@@ -796,7 +810,16 @@ class LstepEngine:
             cur, spliced = self._splice(batch_nodes, batch_idx, live=n_live)
             n = src.numel()
             ids3, t3 = (prep[0], prep[1]) if prep is not None else (torch.cat([src, dst, neg_dst]), torch.cat([ts, ts, ts]))
-            emb_p = bb.combining_pe_raw_feat(cur, ids3, t3, self.K, self.G, spliced=spliced, padded=True, row_blocks=3)
+            if ahead is not None:
+                x_edge, x_node, ev = ahead
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ev)
+                for t_ in (x_edge, x_node):
+                    t_.record_stream(main)
+                _, _, x_pe, own, _ = bb._gather(cur, ids3, t3, self.K, self.G, nat.BRANCH_PE, spliced, wide=True, row_blocks=3)
+                emb_p = bb._combined_tail(x_edge, x_node, x_pe, own, True)
+            else:
+                emb_p = bb.combining_pe_raw_feat(cur, ids3, t3, self.K, self.G, spliced=spliced, padded=True, row_blocks=3)
             emb = emb_p[:, :bb.feat_dim]
             pos_src = emb[:n]
             # both predictor calls of train:254-255 in one launch: rows [pos_src | pos_dst] and [pos_src | neg_dst] (neg_src = pos_src, train:245)
