@@ -663,6 +663,15 @@ def main():
                                                          "synchronisation right in front of it (no neighbour kernel on any stream)" if idle_sink else ""), "algorithmic_bytes_per_launch": float(np.mean(bytes_per_launch)),
                          "rows_per_launch": int(sink[0][2].numel()) if sink else 0},
         }
+        hub = model[0].__dict__.get("_last_hub")
+        if hub is not None and args.sampler == "recent":
+            # (csrc/hub.hip) rows whose node channel came from prefix differences over the union of their node's windows: the launch then
+            # reads far fewer node rows than SURVEY 8(d)'s per-row count prices (`achieved` / `frac` keep that algorithmic count)
+            line["roofline"]["hub_rows"] = {"rows_served": int(hub[0].sum().item()), "work_items": int(hub[1].item()),
+                                            "rows_per_launch": int(hub[0].numel()),
+                                            "note": "node channel of batch rows whose node occurs >= 4 times in the batch: one pass over the union of "
+                                                    "their windows (lstep_hub_node_sums) instead of time_gap row reads each; launch_ms covers the "
+                                                    "work-list kernels, the gather kernel and the hub kernel"}
         if comm is not None:
             line["comm"] = comm
         if world == 1 and not args.no_cpu_baseline and args.mode == "train" and not args.zipf and args.sampler == "recent":

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 38
+#define LSTEP_ABI_VERSION 39
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -146,6 +146,31 @@ int lstep_gather_aggregate_bwd(const lstep_csr_t* csr, const float* edge_raw, in
                                const float* grad_edge, const float* grad_pe_agg, const float* grad_self,
                                int32_t ld_edge, int32_t ld_pe, int32_t ld_self, const int32_t* slot_of,
                                float* out_slot_dot, float* grad_pe_rows, int32_t* out_hits, void* stream);
+
+/* N for hub nodes (round 5) -- models/LSTEP.py:177-211 for a node that occurs many times in ONE batch (power-law graphs: one node collects a
+ * fifth of a batch's endpoints).  The windows of consecutive occurrences overlap in all but a few slots, so the rows of a hub are served by
+ * prefix differences over the union of their windows instead of time_gap row reads each (csrc/hub.hip):
+ *   lstep_hub_worklist    from the grouping of the batch rows cat[src, dst] by node (lstep_group_by_key: seg / order int32 [n2]): rows of
+ *                         nodes with >= min_occ (>= 2) occurrences are marked in served (uint8 [num_rows], zeroed here) and cut into work
+ *                         items of <= 32 occurrences (work int32 [capacity, 2] = first sorted position, occurrences; *nwork their number);
+ *                         seg_start int32 [n2 + 1] is scratch; capacity >= lstep_hub_capacity(n2, min_occ) cannot overflow.
+ *   lstep_gather_aggregate_fwd_skip   lstep_gather_aggregate_fwd whose node channel skips the rows marked in skip_node (their out_node rows
+ *                         are not written); needs the long-row form of the kernel (csr->max_degree and time_gap > 256, no weighted_sum).
+ *   lstep_hub_node_sums   one workgroup per work item writes the out_node rows of its occurrences (feature width <= 176): same value as the
+ *                         gather kernel's up to the summation order (a difference of two fixed-order prefixes). */
+int64_t lstep_hub_capacity(int64_t n2, int32_t min_occ);
+int lstep_hub_worklist(const int32_t* seg, const int32_t* order, int64_t n2, int32_t min_occ, int32_t* seg_start, uint8_t* served,
+                       int64_t num_rows, int32_t* work, int32_t* nwork, int64_t capacity, void* stream);
+int lstep_gather_aggregate_fwd_skip(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
+                                    int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                                    int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids, const double* times,
+                                    int64_t batch, int32_t num_neighbors, int32_t time_gap, uint32_t branches,
+                                    float* out_edge, float* out_node, float* out_pe, float* out_self, int32_t ld_edge,
+                                    int32_t ld_node, int32_t ld_pe, int32_t ld_self, int32_t* out_count,
+                                    const uint8_t* skip_node, void* stream);
+int lstep_hub_node_sums(const lstep_csr_t* csr, const float* node_raw, int32_t feat_dim, const int64_t* node_ids, const double* times,
+                        int32_t time_gap, const int32_t* order, const int32_t* work, const int32_t* nwork, int64_t capacity, float* out_node,
+                        int32_t ld_node, void* stream);
 
 /* The gather stage on EXPLICIT neighbourhoods, for the RNG-defined sampling strategies ('uniform', 'time_interval_aware':
  * utils/utils.py:175-198), whose draws are defined by numpy's RandomState call order and therefore made on the host

@@ -16,11 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 LIB_PATH = os.environ.get("LSTEP_LIB", os.path.join(CSRC, "liblstep_hip.so"))  # LSTEP_LIB: A/B builds for tuning
 SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip", "group.hip", "dense.hip", "tail.hip", "loss.hip", "head.hip", "fftcoef.hip", "update.hip", "adam.hip",
-           "compose.hip", "shard.hip", "rng_sampler.hip"]
+           "compose.hip", "shard.hip", "rng_sampler.hip", "hub.hip"]
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 38
+ABI_VERSION = 39
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -126,6 +126,11 @@ SIGNATURES = {
     "lstep_time_encode": (C.c_int, [_P, _P, _I64, _P, _P, _I32, _P, _P]),
     "lstep_gather_aggregate_fwd": (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32,
                                              _I32, _U32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "lstep_gather_aggregate_fwd_skip": (C.c_int, [C.POINTER(CsrStruct), _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32,
+                                                  _I32, _U32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "lstep_hub_capacity": (_I64, [_I64, _I32]),
+    "lstep_hub_worklist": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _I64, _P, _P, _I64, _P]),
+    "lstep_hub_node_sums": (C.c_int, [C.POINTER(CsrStruct), _P, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P, _I32, _P]),
     "lstep_gather_aggregate_bwd": (C.c_int, [C.POINTER(CsrStruct), _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32, _P, _P, _P,
                                              _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "lstep_gather_explicit_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P, _P, _P, _P, _P, _I64,

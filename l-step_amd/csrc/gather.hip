@@ -38,6 +38,7 @@ struct GatherParams {
     const int64_t* ex_nbr_g;  // [batch, G]  (node branch)
     const float* ex_nt_g;     // [batch, G]  (node branch with weighted_sum)
     int weighted_sum;         // models/LSTEP.py:190-206: node rows weighted by exp(-(t - neighbour time)), normalised over the row's distinct times
+    const uint8_t* skip_node; // optional [batch]: rows whose node channel another kernel computes (hub nodes: csrc/hub.hip); long-row instantiation only
 };
 
 // zero the padding columns of one output row: [width, width rounded up to 16), clipped to the row stride.  A stride wider than that
@@ -178,7 +179,9 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
         }
 
         // node channel: the last v = min(cnt, G) interactions; score 1/valid on ids > 0, then mean over G slots
-        const int64_t v_all = !active ? 0 : (kExplicit ? (int64_t)p.G : (cnt < p.G ? cnt : p.G));
+        // (rows served by lstep_hub_node_sums: no node channel here, and the node output row is theirs)
+        const bool skip = kCoop && p.skip_node != nullptr && active && p.skip_node[row] != 0;
+        const int64_t v_all = (!active || skip) ? 0 : (kExplicit ? (int64_t)p.G : (cnt < p.G ? cnt : p.G));
         const int64_t vfirst = kExplicit ? row * (int64_t)p.G : lo + cnt - v_all;       // first slot: CSR position / position in the explicit list
         // LONG rows (more than kCoopMin slots: hub nodes of a power-law graph, every row of the reference's small dense datasets, every row of
         // an explicit time_gap-slot list) are summed by the whole workgroup: one wave walks a 2000-slot row in 250 dependent rounds of 8 row
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             }
             __syncthreads();
         }
-        if (fa && active) {
+        if (fa && active && !skip) {
             const float invG = 1.0f / (float)p.G;
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid > 0) {
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherPara
             if (in_range) self = ld4(p.node_raw + node * F + lane * 4);
             st4(p.out_node + row * (int64_t)p.ld_node + lane * 4, make_float4(r0.x + self.x, r0.y + self.y, r0.z + self.z, r0.w + self.w));
         }
-        if (active) zero_tail(p.out_node + row * (int64_t)p.ld_node, F, p.ld_node, lane);
+        if (active && !skip) zero_tail(p.out_node + row * (int64_t)p.ld_node, F, p.ld_node, lane);
     }
     if (kPe && active) {
         float* op = p.out_pe + row * (int64_t)p.ld_pe;
@@ -545,13 +548,13 @@ static int check_ld(const char* who, int a, int wa, int b, int wb, int c, int wc
 
 using namespace lstep;
 
-extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
-                                          int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
-                                          int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids,
-                                          const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap,
-                                          uint32_t branches, float* out_edge, float* out_node, float* out_pe, float* out_self,
-                                          int32_t ld_edge, int32_t ld_node, int32_t ld_pe, int32_t ld_self, int32_t* out_count,
-                                          void* stream) {
+static int gather_aggregate_fwd_impl(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
+                                     int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                                     int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids,
+                                     const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap,
+                                     uint32_t branches, float* out_edge, float* out_node, float* out_pe, float* out_self,
+                                     int32_t ld_edge, int32_t ld_node, int32_t ld_pe, int32_t ld_self, int32_t* out_count,
+                                     const uint8_t* skip_node, void* stream) {
     if (num_neighbors <= 0 || time_gap <= 0)
         return set_error(LSTEP_EINVAL, "Number of sampled neighbors for each node should be greater than 0!");
     if (int rc = check_dims("lstep_gather_aggregate_fwd", feat_dim, pe_dim, time_dim)) return rc;
@@ -572,11 +575,12 @@ extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* n
     if (int rc = check_ld("lstep_gather_aggregate_fwd", ld_edge, time_dim + feat_dim, ld_node, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
     GatherParams p{*csr, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
                    batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, out_count, ld_edge, ld_node, ld_pe, ld_self,
-                   nullptr, nullptr, nullptr, nullptr, nullptr, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0};
+                   nullptr, nullptr, nullptr, nullptr, nullptr, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0, skip_node};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
     // long node-channel rows possible?  (max_degree 0 = unknown: assume yes)
     const bool coop = en && !(branches & LSTEP_WEIGHTED_SUM) && (csr->max_degree == 0 || csr->max_degree > kCoopMin) && time_gap > kCoopMin;
+    if (skip_node && !coop) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd_skip: skip_node needs the long-row form (max_degree and time_gap > 256, no weighted_sum)");
     if (en && pb) {
         if (coop) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true>), grid, block, 0, s, p);
@@ -585,6 +589,32 @@ extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* n
         else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false>), grid, block, 0, s, p);
     } else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true>), grid, block, 0, s, p);
     return check_launch("gather_aggregate_fwd_kernel");
+}
+
+extern "C" int lstep_gather_aggregate_fwd(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
+                                          int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                                          int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids,
+                                          const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap,
+                                          uint32_t branches, float* out_edge, float* out_node, float* out_pe, float* out_self,
+                                          int32_t ld_edge, int32_t ld_node, int32_t ld_pe, int32_t ld_self, int32_t* out_count,
+                                          void* stream) {
+    return gather_aggregate_fwd_impl(csr, node_raw, edge_raw, pe, feat_dim, pe_dim, time_w, time_b, time_dim, edge_agg_w, node_ids, times, batch,
+                                     num_neighbors, time_gap, branches, out_edge, out_node, out_pe, out_self, ld_edge, ld_node, ld_pe, ld_self,
+                                     out_count, nullptr, stream);
+}
+
+// The same launch with rows whose node channel is computed elsewhere (hub nodes: lstep_hub_worklist / lstep_hub_node_sums, csrc/hub.hip):
+// skip_node uint8 [batch], non-zero = the row's node channel is skipped and its out_node row is NOT written.
+extern "C" int lstep_gather_aggregate_fwd_skip(const lstep_csr_t* csr, const float* node_raw, const float* edge_raw, const float* pe,
+                                               int32_t feat_dim, int32_t pe_dim, const float* time_w, const float* time_b,
+                                               int32_t time_dim, const float* edge_agg_w, const int64_t* node_ids,
+                                               const double* times, int64_t batch, int32_t num_neighbors, int32_t time_gap,
+                                               uint32_t branches, float* out_edge, float* out_node, float* out_pe, float* out_self,
+                                               int32_t ld_edge, int32_t ld_node, int32_t ld_pe, int32_t ld_self, int32_t* out_count,
+                                               const uint8_t* skip_node, void* stream) {
+    return gather_aggregate_fwd_impl(csr, node_raw, edge_raw, pe, feat_dim, pe_dim, time_w, time_b, time_dim, edge_agg_w, node_ids, times, batch,
+                                     num_neighbors, time_gap, branches, out_edge, out_node, out_pe, out_self, ld_edge, ld_node, ld_pe, ld_self,
+                                     out_count, skip_node, stream);
 }
 
 // The gather stage on EXPLICIT neighbourhoods: one branch per call, the slots exactly as a sampler returned them (the RNG-defined
@@ -615,7 +645,7 @@ extern "C" int lstep_gather_explicit_fwd(const float* node_raw, const float* edg
     lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0, 0};   // (only num_rows is read: the bound of the self-row lookups)
     GatherParams p{none, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
                    batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, nullptr, ld_edge, ld_node, ld_pe, ld_self,
-                   nbr, eid, nt, nbr_gap, nt_gap, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0};
+                   nbr, eid, nt, nbr_gap, nt_gap, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0, nullptr};
     const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
     if (en && time_gap > kCoopMin && !(branches & LSTEP_WEIGHTED_SUM))
         hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, true, true>), grid, block, 0, (hipStream_t)stream, p);

@@ -935,8 +935,10 @@ class LstepEngine:
         cur, _ = self._splice(batch_nodes, batch_idx, live=n_live)
         self.slot_of.index_fill_(0, batch_nodes, -1)
         n = src.numel()
+        # (the first 2 B rows are cat[src, dst], grouped by node by the batch-node grouping above: hub nodes' node channel, csrc/hub.hip)
+        groups = (presorted[1], presorted[0]) if (presorted[0].dtype == torch.int32 and presorted[1] is not None) else None
         emb_p = bb.combining_pe_raw_feat(cur, torch.cat([src, dst, neg_src, neg_dst]), torch.cat([ts, ts, ts, ts]), self.K, self.G, padded=True,
-                                         row_blocks=4)
+                                         row_blocks=4, row_groups=groups)
         if self.predictor.fused_ok(emb_p):      # both predictor calls of evaluate_model_utils.py:100-101 in one launch, no concatenation
             predicts = self.predictor.pair_logits(emb_p, n, (0, n, 2 * n, 3 * n)).sigmoid().clamp(0, 1)
         else:

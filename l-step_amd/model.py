@@ -933,7 +933,7 @@ class _GatherAggregate(torch.autograd.Function):
     16-aligned K: hipBLASLt runs 176-wide fp32 GEMMs up to 2.5x faster than 172-wide ones (tools/gemm_shapes.py)."""
 
     @staticmethod
-    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False, self_groups=None, explicit=None):
+    def forward(ctx, pe, rows, agg_w, mod, ids, times, K, G, branches, slot_of, wide=False, self_groups=None, explicit=None, hub_groups=None):
         ctx.set_materialize_grads(False)     # (no zero tensors for the outputs nobody differentiates: each would be a fill launch in backward)
         lib = nat.load_library()
         dev = ids.device
@@ -968,8 +968,39 @@ class _GatherAggregate(torch.autograd.Function):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         ws_flag = nat.WEIGHTED_SUM if (en and mod.weighted_sum) else 0
+        # Hub nodes (round 5, csrc/hub.hip): on a graph with long adjacency rows, the batch rows of a node that occurs >= 16 times in this batch
+        # -- known from the engine's grouping of cat[src, dst] by node (``self_groups``) -- get their node channel from prefix differences
+        # over the union of their windows instead of time_gap row reads each; the gather kernel skips it for them.  LSTEP_NO_HUB_SUMS=1: off.
+        # Measured (profiles/r05_hub_rows_ab.txt, c4-sized Zipf graphs): step 4.31 -> 2.91 ms (s = 1.2), 4.34 -> 2.87 (s = 1.5) with nodes of >= 4
+        # occurrences served (>= 16: 3.10 / 2.93); the reference's small batches lose (Enron shape 0.485 -> 0.50-0.53 ms: a handful of
+        # latency-bound work items and three more launches), so batches of fewer than 4096 grouped rows keep the gather kernel's own channel.
+        hub = None
+        groups = hub_groups if hub_groups is not None else self_groups
+        if (explicit is None and en and groups is not None and not ws_flag and int(G) > 256 and getattr(s, "max_degree", 0) > 256
+                and Fd <= 176 and 4096 <= groups[0].numel() <= B and groups[0].dtype == torch.int32 and os.environ.get("LSTEP_NO_HUB_SUMS") != "1"):
+            seg32, order32 = groups
+            n2 = seg32.numel()
+            min_occ = max(2, int(os.environ.get("LSTEP_HUB_MIN_OCC", "4")))
+            cap = int(lib.lstep_hub_capacity(n2, min_occ))
+            served = torch.empty(B, dtype=torch.uint8, device=dev)
+            seg_start = torch.empty(n2 + 1, dtype=torch.int32, device=dev)
+            work = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            nwork = torch.empty(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                nat.check(lib.lstep_hub_worklist(nat.ptr(seg32), nat.ptr(order32), n2, min_occ, nat.ptr(seg_start), nat.ptr(served), B, nat.ptr(work),
+                                                 nat.ptr(nwork), cap, nat.current_stream()))
+            hub = (served, order32, work, nwork, cap)
+            mod.__dict__["_last_hub"] = (served, nwork)      # (bench.py: how many rows / work items the last launch served)
         with torch.cuda.device(dev):
-            if explicit is None:
+            if explicit is None and hub is not None:
+                nat.check(lib.lstep_gather_aggregate_fwd_skip(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
+                                                              Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
+                                                              int(K), int(G), int(branches) | ws_flag, nat.ptr(out_edge), nat.ptr(out_node),
+                                                              nat.ptr(out_pe), nat.ptr(out_self), mod.ld_edge, ld_node, mod.ld_pe, ld_self,
+                                                              nat.ptr(count), nat.ptr(hub[0]), nat.current_stream()))
+                nat.check(lib.lstep_hub_node_sums(s.csr, nat.ptr(mod.node_raw_features), Fd, nat.ptr(ids), nat.ptr(times), int(G), nat.ptr(hub[1]),
+                                                  nat.ptr(hub[2]), nat.ptr(hub[3]), hub[4], nat.ptr(out_node), ld_node, nat.current_stream()))
+            elif explicit is None:
                 nat.check(lib.lstep_gather_aggregate_fwd(s.csr, nat.ptr(mod.node_raw_features), nat.ptr(mod.edge_raw_features), nat.ptr(pe_c),
                                                          Fd, P, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B,
                                                          int(K), int(G), int(branches) | ws_flag, nat.ptr(out_edge), nat.ptr(out_node),
@@ -1096,7 +1127,7 @@ class _GatherAggregate(torch.autograd.Function):
         elif grad_rows is not None and g_pe is not None:
             # spliced mode: row 0 only has gradient if node 0 is itself a spliced row (never in the reference data)
             pass
-        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None, None, None, None)
+        return (g_table, grad_rows if use_slot else None, g_w, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class _FftCoefficients(torch.autograd.Function):
@@ -1341,7 +1372,8 @@ class LSTEP(nn.Module):
                     torch.from_numpy(np.ascontiguousarray(cat[2], dtype=np.float32)).to(self.device))
         return tuple(to_dev(d) for d in draws)
 
-    def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None, wide: bool = False, row_blocks: int = 1):
+    def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None, wide: bool = False, row_blocks: int = 1,
+                row_groups=None):
         if K != self.num_neighbors and (branches & nat.BRANCH_EDGE_NODE):
             raise RuntimeError(f"edge_agg was built for num_neighbors={self.num_neighbors}, got {K} "
                                "(the reference fails the same way at models/LSTEP.py:164)")
@@ -1364,8 +1396,9 @@ class LSTEP(nn.Module):
         slot_of = spliced.slot_of if spliced is not None else None
         if slot_of is not None and (slot_of.dtype != torch.int32 or slot_of.numel() < self.neighbor_sampler.num_rows):
             raise ValueError("slot_of must be an int32 map with one entry per node id")
+        # (row_groups = (seg, order) int32: the leading rows grouped by node when no spliced-row grouping says so -- evaluation iterations: hub nodes)
         return _GatherAggregate.apply(pe, rows, self.edge_agg.weight.reshape(-1), self, ids, times, K, G, branches, slot_of, wide,
-                                      getattr(spliced, "self_groups", None), explicit)
+                                      getattr(spliced, "self_groups", None), explicit, row_groups)
 
     def _edge_node_tail(self, x_edge, x_node):
         """edge_mlp_1 -> edge_agg (reassociated) -> relu -> edge_mlp_2 ; node_mlp(cat[node, edge])  (models/LSTEP.py:161-170,219)."""
@@ -1392,11 +1425,12 @@ class LSTEP(nn.Module):
 
     # ---- O (models/LSTEP.py:251-266): one fused gather launch serves A, N and C
     def combining_pe_raw_feat(self, pe, node_ids, node_interact_times, num_neighbors: int = 30, time_gap: int = 2000, testing=False,
-                              spliced: SplicedRows = None, padded: bool = False, row_blocks: int = 1):
-        """``row_blocks`` (RNG-defined sampling only): see ``_draw_neighbourhoods``."""
+                              spliced: SplicedRows = None, padded: bool = False, row_blocks: int = 1, row_groups=None):
+        """``row_blocks`` (RNG-defined sampling only): see ``_draw_neighbourhoods``; ``row_groups``: see ``_gather``."""
         fused = self._fused_tail_ok()
         x_edge, x_node, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, time_gap,
-                                                    nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced, wide=fused, row_blocks=row_blocks)
+                                                    nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced, wide=fused, row_blocks=row_blocks,
+                                                    row_groups=row_groups)
         out = self._combined_tail(x_edge, x_node, x_pe, own, fused)
         # padded: the [B, 176] rows the kernels work on (columns >= 172 are 0), for lstep_head_fwd; default: the reference's [B, 172]
         return out if padded else out[:, :self.feat_dim]

@@ -2179,3 +2179,77 @@ print("checked build:", what, idx, limit, count)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "checked build:" in r.stdout
+
+
+def test_hub_node_sums_vs_gather_kernel(hip):
+    """Round 5: the node channel of batch rows whose node occurs >= 16 times in the batch from prefix differences over
+    the union of their windows (csrc/hub.hip: lstep_hub_worklist / lstep_gather_aggregate_fwd_skip / lstep_hub_node_sums) against the gather
+    kernel's own node channel on a power-law graph -- every served row, the rows left to the gather kernel, and the other outputs untouched.
+    The two differ only by summation order (a window as a difference of two fixed-order prefixes)."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    N, E, K, G, Bq = 400, 60000, 8, 2000, 384
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=171, zipf=1.3)
+    node_raw, edge_raw = synth.make_features(N, E, seed=172)
+    sampler = hip_sampler(hip, g)
+    assert sampler.max_degree > 2000
+    dev = torch.device(DEV)
+    sl = slice(50000, 50000 + Bq)
+    src, dst = torch.from_numpy(g["src"][sl]).to(dev), torch.from_numpy(g["dst"][sl]).to(dev)
+    neg = torch.from_numpy(synth.make_negatives(N, Bq, seed=173)).to(dev)
+    t = torch.from_numpy(g["ts"][sl]).to(dev)
+    ids, times = torch.cat([src, dst, neg]).contiguous(), torch.cat([t, t, t]).contiguous()
+    B = ids.numel()
+    F, D = 172, 100
+    LE, LN = 272, 176
+    node_t, edge_t = torch.from_numpy(node_raw).to(dev), torch.from_numpy(edge_raw).to(dev)
+    tw = torch.from_numpy(1 / 10 ** np.linspace(0, 9, D, dtype=np.float32)).to(dev)
+    tb = torch.zeros(D, device=dev)
+    aw = torch.rand(K, device=dev)
+    rows = N + 1
+    _, order, seg, _, _ = nat.group_by_key(torch.cat([src, dst]).to(torch.int32), max(1, int(rows).bit_length()), rows, wait=None)
+    n2 = order.numel()
+
+    def run(skip):
+        oe = torch.full((B, LE), float("nan"), device=dev)
+        on = torch.full((B, LN), float("nan"), device=dev)
+        cnt = torch.empty(B, dtype=torch.int32, device=dev)
+        args = (sampler.csr, nat.ptr(node_t), nat.ptr(edge_t), None, F, F, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw), nat.ptr(ids), nat.ptr(times), B, K, G,
+                nat.BRANCH_EDGE_NODE, nat.ptr(oe), nat.ptr(on), None, None, LE, LN, LE, LN, nat.ptr(cnt))
+        if not skip:
+            nat.check(lib.lstep_gather_aggregate_fwd(*args, nat.current_stream()))
+            return oe, on, None, None
+        cap = int(lib.lstep_hub_capacity(n2, 16))
+        served = torch.empty(B, dtype=torch.uint8, device=dev)
+        seg_start = torch.empty(n2 + 1, dtype=torch.int32, device=dev)
+        work = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        nwork = torch.empty(1, dtype=torch.int32, device=dev)
+        nat.check(lib.lstep_hub_worklist(nat.ptr(seg), nat.ptr(order), n2, 16, nat.ptr(seg_start), nat.ptr(served), B, nat.ptr(work), nat.ptr(nwork), cap,
+                                         nat.current_stream()))
+        nat.check(lib.lstep_gather_aggregate_fwd_skip(*args, nat.ptr(served), nat.current_stream()))
+        nat.check(lib.lstep_hub_node_sums(sampler.csr, nat.ptr(node_t), F, nat.ptr(ids), nat.ptr(times), G, nat.ptr(order), nat.ptr(work), nat.ptr(nwork), cap,
+                                          nat.ptr(on), LN, nat.current_stream()))
+        return oe, on, served, nwork
+
+    oe0, on0, _, _ = run(False)
+    oe1, on1, served, nwork = run(True)
+    torch.cuda.synchronize()
+    n_served, n_items = int(served.sum()), int(nwork)
+    assert n_served >= 64 and n_items >= 2 and n_served < B, (n_served, n_items)       # hubs and ordinary rows both present
+    assert int(served[n2:].sum()) == 0                                                  # (the negatives are never grouped)
+    assert torch.equal(oe0, oe1)                                                        # the edge channel is untouched
+    assert torch.isfinite(on1).all()                                                    # every node row was written by exactly one of the two kernels
+    keep = served == 0
+    assert torch.equal(on0[keep], on1[keep])
+    # served rows: same value up to the summation order of ~2000 N(0, 1) rows divided by valid x time_gap (the self row dominates: O(1))
+    np.testing.assert_allclose(on1[~keep].cpu().numpy(), on0[~keep].cpu().numpy(), rtol=0, atol=2e-6)
+    # ... and against float64 on a few of them: neither order is further from it than the other by more than rounding
+    csr_lo = sampler.indptr.cpu().numpy()
+    nbr_h, ts_h = sampler.nbr.cpu().numpy(), sampler.ts.cpu().numpy()
+    for r in torch.nonzero(~keep).reshape(-1)[:6].tolist():
+        n, tq = int(ids[r]), float(times[r])
+        lo, hi = csr_lo[n], csr_lo[n + 1]
+        c = int(np.searchsorted(ts_h[lo:hi], tq))
+        w = nbr_h[lo + max(0, c - G):lo + c]
+        want = node_raw[w].astype(np.float64).sum(0) / (max(len(w), 1) * G) + node_raw[n]
+        np.testing.assert_allclose(on1[r, :F].cpu().numpy(), want, rtol=0, atol=2e-6)

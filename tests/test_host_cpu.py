@@ -38,7 +38,7 @@ def test_abi_exports_every_declared_symbol(lib):
         assert hasattr(raw, n), f"{n} declared in include/lstep_hip.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes prototype"
     assert sorted(nat.SIGNATURES) == names
-    assert lib.lstep_abi_version() == nat.ABI_VERSION == 38
+    assert lib.lstep_abi_version() == nat.ABI_VERSION == 39
 
 
 def test_abi_argument_validation_without_gpu(lib):
