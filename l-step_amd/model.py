@@ -605,7 +605,13 @@ class _FusedTail(torch.autograd.Function):
         def weight_gradients():
             # the four products in ONE (partial, reduce) launch pair (lstep_linear_wgrad_batch); a link predictor that ran its backward just
             # before (``_Head.backward``, engine mode) has left its two products here to ride along
-            riders = _PENDING_HEAD_WGRADS.pop(dev, None)
+            # (the predictor's two products ride along only when they were parked for THIS auxiliary stream: a tail whose products run on
+            # the main stream -- no auxiliary stream, LSTEP_NO_GRAPH=1, a weight graph still in use -- leaves them to the predictor's own
+            # deferred launch, which waits for the right events)
+            pend = _PENDING_HEAD_WGRADS.get(dev)
+            riders = None
+            if pend is not None and ctx.aux is not None and pend[2] is not None and pend[2].cuda_stream == ctx.aux.cuda_stream:
+                riders = _PENDING_HEAD_WGRADS.pop(dev)
             items = [(d_h1, x_edge[:, :w1t.shape[0]], True, (gb[0], gb[1])), (d_p1, x_pe[:, :Cp], True, (gb[2], gb[3])),
                      (d_z, cat2, True, (gb[4], gb[5])), (g_out, cat1, True, (gb[6], gb[7]))]
             res = nat.linear_wgrad_batch(items + (riders[0] if riders else []))
@@ -724,7 +730,7 @@ class _Head(torch.autograd.Function):
         if os.environ.get("LSTEP_WGRAD_NO_RIDE") != "1":
             # the dense tail's backward runs next on this stream and launches its four products on the auxiliary stream behind an event
             # recorded after ITS kernel, i.e. after this one too: the two products here join that launch (one graph node instead of three)
-            _PENDING_HEAD_WGRADS[torch.device(dev)] = (head_items, done)
+            _PENDING_HEAD_WGRADS[torch.device(dev)] = (head_items, done, aux)
         _defer(dev, on_aux)
         return d_emb, None, None, None, None, None, None, None
 
