@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSTEP_ABI_VERSION 39
+#define LSTEP_ABI_VERSION 40
 
 #define LSTEP_OK 0
 #define LSTEP_EINVAL (-1) /* bad argument (NULL pointer, unsupported width, num_neighbors <= 0 ...) */
@@ -575,6 +575,16 @@ int lstep_count_before_host(const int64_t* indptr, const double* ts, int64_t num
 int lstep_sample_random_host(const int64_t* indptr, const int64_t* nbr, const int64_t* eid, const double* ts, int64_t num_rows,
                              const int64_t* node_ids, const double* times, int64_t m, int32_t num_neighbors, const float* p_values,
                              const int64_t* p_offsets, uint32_t* mt_key, int32_t* mt_pos, int64_t* out_nbr, int64_t* out_eid, float* out_t);
+/* The same draws WITH the re-sort of utils/utils.py:192-196 (ABI 40): a node's history is time-sorted and float32 rounding is monotone, so
+ * ordering a row's sampled slots by float32 time is ordering the drawn positions -- except among distinct positions with equal float32 times,
+ * where the reference's order is numpy's unstable argsort's.  Phase A draws on the calling thread (the generator is sequential); phase B sorts
+ * positions and gathers the triples on num_threads host threads (<= 0: hardware concurrency).  Rows WITHOUT such a tie are written in time
+ * order, ambiguous[r] = 0; rows with one are written in draw order, ambiguous[r] = 1 (the caller sorts those with numpy); rows without history
+ * are untouched, ambiguous[r] = 0.  ambiguous: uint8 [m]. */
+int lstep_sample_random_sorted_host(const int64_t* indptr, const int64_t* nbr, const int64_t* eid, const double* ts, int64_t num_rows,
+                                    const int64_t* node_ids, const double* times, int64_t m, int32_t num_neighbors, const float* p_values,
+                                    const int64_t* p_offsets, uint32_t* mt_key, int32_t* mt_pos, int64_t* out_nbr, int64_t* out_eid,
+                                    float* out_t, uint8_t* ambiguous, int32_t num_threads);
 int lstep_update_entries_p1(const int32_t* order, int64_t num_entries, const int64_t* src, const int64_t* dst, const double* times,
                             const float* now32, int64_t batch, int32_t* ent_row, float* ent_dt, void* stream);
 int lstep_update_keys_p2(const int64_t* nbr, int64_t n, int32_t sentinel, int32_t world, int32_t rank, int32_t* keys, void* stream);

@@ -20,7 +20,7 @@ SOURCES = ["api.hip", "sampler.hip", "gather.hip", "history.hip", "segment.hip",
 HEADERS = [os.path.join(CSRC, "lstep_common.h"), os.path.join(CSRC, "lstep_mma.h"), os.path.join(INCLUDE, "lstep_hip.h")]
 
 LSTEP_OK, LSTEP_EINVAL, LSTEP_EHIP = 0, -1, -2
-ABI_VERSION = 39
+ABI_VERSION = 40
 BRANCH_EDGE_NODE, BRANCH_PE, WEIGHTED_SUM = 1, 2, 4
 
 
@@ -164,6 +164,7 @@ SIGNATURES = {
     "lstep_rows_by_id": (C.c_int, [_P, _I64, _P, _I32, _P, _I32, _P]),
     "lstep_count_before_host": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _P]),
     "lstep_sample_random_host": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "lstep_sample_random_sorted_host": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32]),
     "lstep_batch_prepare": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _P]),
     "lstep_padding_rows_finish": (C.c_int, [_P, _I64, _I32, _P, _I32, _P]),
     "lstep_scatter_add_overflow": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _I32, _P]),

@@ -1360,14 +1360,32 @@ class LSTEP(nn.Module):
             raise ValueError("row_blocks must divide the number of rows")
         step = n // row_blocks
         en, pb = bool(branches & nat.BRANCH_EDGE_NODE), bool(branches & nat.BRANCH_PE)
+        sampler = self.neighbor_sampler
+        if hasattr(sampler, "sample_random_into") and len(ids) == len(ts) and os.environ.get("LSTEP_RNG_PAGEABLE") != "1":
+            # the draws land in pinned staging arrays, one [n, width] triple per channel, block by block in the reference's call order; one
+            # asynchronous copy each (round 5: against np.zeros + concatenate + a pageable copy of ~0.6 GB per iteration at time_gap = 2000)
+            chans = [(0, K, en), (1, G, en), (2, K, pb)]
+            stage = [self._rng_stage(c, n, w) if on else None for c, w, on in chans]
+            dev = [None if st is None else tuple(torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in st[0]) for st in stage]
+            for b in range(row_blocks):
+                sl = slice(b * step, (b + 1) * step)
+                for (c, w, on), st, dv in zip(chans, stage, dev):
+                    if on:
+                        sampler.sample_random_into(ids[sl], ts[sl], w, tuple(a[sl] for a in st[1]))
+                        for d, t in zip(dv, st[0]):       # (this block's copy runs under the next block's draws)
+                            d[sl].copy_(t[sl], non_blocking=True)
+            for st in stage:
+                if st is not None:
+                    st[2].record(torch.cuda.current_stream(self.device))
+            return tuple(dev)
         draws = ([], [], [])
         for b in range(row_blocks):
             sl = slice(b * step, (b + 1) * step)
             if en:
-                draws[0].append(self.neighbor_sampler.get_historical_neighbors(ids[sl], ts[sl], K))
-                draws[1].append(self.neighbor_sampler.get_historical_neighbors(ids[sl], ts[sl], G))
+                draws[0].append(sampler.get_historical_neighbors(ids[sl], ts[sl], K))
+                draws[1].append(sampler.get_historical_neighbors(ids[sl], ts[sl], G))
             if pb:
-                draws[2].append(self.neighbor_sampler.get_historical_neighbors(ids[sl], ts[sl], K))
+                draws[2].append(sampler.get_historical_neighbors(ids[sl], ts[sl], K))
 
         def to_dev(parts):
             if not parts:
@@ -1377,6 +1395,26 @@ class LSTEP(nn.Module):
                     torch.from_numpy(np.ascontiguousarray(cat[1], dtype=np.int64)).to(self.device),
                     torch.from_numpy(np.ascontiguousarray(cat[2], dtype=np.float32)).to(self.device))
         return tuple(to_dev(d) for d in draws)
+
+    def _rng_stage(self, channel: int, rows: int, width: int):
+        """Pinned host staging of one channel's draws: (three torch tensors, their numpy views, the event behind their last copy).  Two sets
+        per (channel, shape), used alternately, so that filling the next call's draws does not wait for the previous call's copy."""
+        pool = self.__dict__.setdefault("_rng_stages", {})
+        key = (channel, rows, width)
+        ring = pool.get(key)
+        if ring is None:
+            if len(pool) >= 12:                         # (shapes come and go with batch sizes: keep the staging bounded)
+                pool.clear()
+            ring = pool[key] = {"next": 0, "sets": []}
+        if len(ring["sets"]) < 2:
+            ts_ = (torch.empty((rows, width), dtype=torch.int64, pin_memory=True), torch.empty((rows, width), dtype=torch.int64, pin_memory=True),
+                   torch.empty((rows, width), dtype=torch.float32, pin_memory=True))
+            ring["sets"].append((ts_, tuple(t.numpy() for t in ts_), torch.cuda.Event()))
+            return ring["sets"][-1]
+        st = ring["sets"][ring["next"]]
+        ring["next"] ^= 1
+        st[2].synchronize()                             # (the copy that last read this set has finished)
+        return st
 
     def _gather(self, pe, node_ids, node_interact_times, K, G, branches, spliced: SplicedRows = None, wide: bool = False, row_blocks: int = 1,
                 row_groups=None):

@@ -154,27 +154,74 @@ class NeighborSampler:
         p[np.isnan(p)] = -1e10
         return p
 
-    def _sample_random_host(self, node_ids, node_interact_times, num_neighbors):
+    def _row_probabilities(self, node: int, cnt: int) -> np.ndarray:
+        """``torch.softmax(float32(weights of the node's FULL history)[:cnt])`` (utils/utils.py:180-182), computed exactly as the reference
+        computes it (one 1-D torch.softmax per row) but kept: the weights depend on the node only, the softmax on (node, cnt), and the
+        model asks for the same rows three times per call (edge, node and PE channel).  Both caches are bounded (the CSR never changes)."""
+        if self.__dict__.get("_p_tsf") != self.time_scaling_factor:        # (a public attribute: a change invalidates what was kept)
+            self._p_soft, self._p_node, self._p_soft_bytes, self._p_node_bytes = {}, {}, 0, 0
+            self._p_tsf = self.time_scaling_factor
+        soft = self._p_soft
+        p = soft.get((node, cnt))
+        if p is not None:
+            return p
+        indptr, _, _, tss = self._host
+        weights = self._p_node
+        w = weights.get(node)
+        if w is None:
+            w = self._sampled_probabilities(tss[indptr[node]:indptr[node + 1]])
+            if self._p_node_bytes + w.nbytes > (512 << 20):
+                weights.clear()
+                self._p_node_bytes = 0
+            weights[node] = w
+            self._p_node_bytes = self._p_node_bytes + w.nbytes
+        p = torch.softmax(torch.from_numpy(w[:cnt]).float(), dim=0).numpy()
+        if self._p_soft_bytes + p.nbytes > (256 << 20):
+            soft.clear()
+            self._p_soft_bytes = 0
+        soft[(node, cnt)] = p
+        self._p_soft_bytes = self._p_soft_bytes + p.nbytes
+        return p
+
+    def _sample_random_host(self, node_ids, node_interact_times, num_neighbors, out=None):
         """'uniform' / 'time_interval_aware' (utils/utils.py:175-198): per row, in row order, one RandomState.choice over the interactions
         strictly before the query time, then a re-sort of the sampled slots by (float32) time.  The draws are made by the native replay of
         numpy's legacy generator (``lstep_sample_random_host``: the row loop, MT19937 and both paths of ``RandomState.choice`` in C++, on
         numpy's OWN generator state, which is read before and stored back after the call -- Python-side and native draws share one
-        stream).  What stays in the interpreter is the re-sort of every sampled row by its float32 times (utils/utils.py:192-196): the reference
-        calls numpy's UNSTABLE ``argsort`` on each row, whose order among equal times is an implementation detail of numpy (introsort or a
-        SIMD sort, by version, length and CPU; a batched ``argsort(axis=1)`` runs a different code path, measured 4 x slower), so the same
-        1-D call is made per row -- ~3 us a row, against ~17 us for the whole reference loop body.
-        LSTEP_PY_RNG_SAMPLER=1: the interpreter loop of rounds 1-3 (A/B)."""
+        stream).  The re-sort of every sampled row by its float32 times (utils/utils.py:192-196) is an UNSTABLE numpy ``argsort`` in the
+        reference, whose order among equal times is an implementation detail of numpy (introsort or a SIMD sort, by version, length and
+        CPU).  The node's history is time-sorted, so that order is the order of the drawn POSITIONS wherever no two distinct positions share
+        a float32 time: ``lstep_sample_random_sorted_host`` (round 5) draws on one thread and then sorts the positions and gathers the
+        triples on ``LSTEP_HOST_THREADS`` workers (default: the cores there are, at most 16), flags the rows that do hold such a tie and
+        leaves those in draw order; only they go through numpy's 1-D ``argsort`` here (the same call the reference makes).
+        LSTEP_RNG_NUMPY_SORT=1: round 4's path (native draws, every row re-sorted by numpy; the A/B of the native sort).
+        LSTEP_PY_RNG_SAMPLER=1: the interpreter loop of rounds 1-3 (A/B).
+        ``out``: three C-contiguous arrays [rows, K] (int64, int64, float32) to fill instead of fresh ones (the model hands in slices of
+        pinned staging buffers: no concatenate, no pageable copy); rows without history are zeroed here."""
         import os
         if os.environ.get("LSTEP_PY_RNG_SAMPLER") == "1":
-            return self._sample_random_python(node_ids, node_interact_times, num_neighbors)
+            res = self._sample_random_python(node_ids, node_interact_times, num_neighbors)
+            if out is not None:
+                for dst, src in zip(out, res):
+                    dst[...] = src
+                return out
+            return res
         import ctypes
         indptr, nbrs, eids, tss = self._host
         rows = len(node_ids)
         K = int(num_neighbors)
         m = min(rows, len(node_interact_times))          # (the reference zips the two arrays: utils/utils.py:169)
-        out_n = np.zeros((rows, K), dtype=np.longlong)
-        out_e = np.zeros((rows, K), dtype=np.longlong)
-        out_t = np.zeros((rows, K), dtype=np.float32)
+        if out is None:
+            out_n = np.zeros((rows, K), dtype=np.longlong)
+            out_e = np.zeros((rows, K), dtype=np.longlong)
+            out_t = np.zeros((rows, K), dtype=np.float32)
+        else:
+            out_n, out_e, out_t = out
+            for a, dt in ((out_n, np.int64), (out_e, np.int64), (out_t, np.float32)):
+                if a.shape != (rows, K) or a.dtype != dt or not a.flags.c_contiguous:
+                    raise ValueError("out: three C-contiguous [rows, num_neighbors] arrays (int64, int64, float32)")
+            if m < rows:
+                out_n[m:], out_e[m:], out_t[m:] = 0, 0, 0
         if m == 0:
             return out_n, out_e, out_t
         ids = np.ascontiguousarray(np.asarray(node_ids)[:m], dtype=np.int64)
@@ -184,13 +231,14 @@ class NeighborSampler:
         p_vals = p_off = None
         cnt = np.empty(m, dtype=np.int64)
         nat.check(lib.lstep_count_before_host(vp(indptr), vp(tss), self.num_rows, vp(ids), vp(ts), m, vp(cnt)))
+        if out is not None:
+            empty = np.nonzero(cnt == 0)[0]               # (a reused buffer: the rows the native code leaves untouched)
+            if empty.size:
+                out_n[empty], out_e[empty], out_t[empty] = 0, 0, 0
         if self.sample_neighbor_strategy == "time_interval_aware":
             # the probabilities are torch.softmax's float32 output (utils/utils.py:182), row by row as the reference computes them: their
             # last bits depend on torch's vectorised exp, which only torch reproduces; everything behind them is replayed natively
-            parts = []
-            for r in np.nonzero(cnt)[0]:
-                lo, hi = indptr[ids[r]], indptr[ids[r] + 1]
-                parts.append(torch.softmax(torch.from_numpy(self._sampled_probabilities(tss[lo:hi])[:cnt[r]]).float(), dim=0).numpy())
+            parts = [self._row_probabilities(int(ids[r]), int(cnt[r])) for r in np.nonzero(cnt)[0]]
             p_vals = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros(0), dtype=np.float32)
             p_off = np.zeros(m + 1, dtype=np.int64)
             np.cumsum(cnt, out=p_off[1:])
@@ -200,14 +248,32 @@ class NeighborSampler:
         kind, key, pos, has_gauss, cached = owner.get_state()
         key = np.ascontiguousarray(key, dtype=np.uint32).copy()
         cpos = ctypes.c_int32(int(pos))
-        nat.check(lib.lstep_sample_random_host(vp(indptr), vp(nbrs), vp(eids), vp(tss), self.num_rows, vp(ids), vp(ts), m, K,
-                                               None if p_vals is None else vp(p_vals), None if p_off is None else vp(p_off), vp(key),
-                                               ctypes.byref(cpos), vp(out_n), vp(out_e), vp(out_t)))
+        args = (vp(indptr), vp(nbrs), vp(eids), vp(tss), self.num_rows, vp(ids), vp(ts), m, K, None if p_vals is None else vp(p_vals),
+                None if p_off is None else vp(p_off), vp(key), ctypes.byref(cpos), vp(out_n), vp(out_e), vp(out_t))
+        if os.environ.get("LSTEP_RNG_NUMPY_SORT") == "1":
+            nat.check(lib.lstep_sample_random_host(*args))
+            resort = np.nonzero(cnt)[0]                   # (rows without history stay all zeros)
+        else:
+            tied = np.zeros(m, dtype=np.uint8)
+            threads = int(os.environ.get("LSTEP_HOST_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            nat.check(lib.lstep_sample_random_sorted_host(*args, vp(tied), threads))
+            resort = np.nonzero(tied)[0]
         owner.set_state((kind, key, int(cpos.value), has_gauss, cached))
-        for r in np.nonzero(cnt)[0]:                      # (rows without history stay all zeros)
+        self.last_numpy_sorted_rows = int(resort.size)
+        for r in resort:
             order = out_t[r].argsort()
             out_n[r], out_e[r], out_t[r] = out_n[r][order], out_e[r][order], out_t[r][order]
         return out_n, out_e, out_t
+
+    def sample_random_into(self, node_ids, node_interact_times, num_neighbors, out):
+        """``get_historical_neighbors`` of an RNG-defined strategy, written into the caller's arrays (same checks, same draws)."""
+        assert num_neighbors > 0, "Number of sampled neighbors for each node should be greater than 0!"
+        if self.sample_neighbor_strategy == "recent":
+            raise ValueError("sample_random_into serves the RNG-defined strategies ('uniform', 'time_interval_aware')")
+        ids = np.asarray(node_ids)
+        if ids.size and (ids.min() < 0 or ids.max() >= self.num_rows):
+            raise IndexError("list index out of range")
+        return self._sample_random_host(ids, np.asarray(node_interact_times), num_neighbors, out=out)
 
     def _sample_random_python(self, node_ids, node_interact_times, num_neighbors):
         """The same as an interpreter loop around ``RandomState.choice`` itself (rounds 1-3; kept as the A/B reference of the native replay)."""

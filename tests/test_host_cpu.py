@@ -38,7 +38,7 @@ def test_abi_exports_every_declared_symbol(lib):
         assert hasattr(raw, n), f"{n} declared in include/lstep_hip.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes prototype"
     assert sorted(nat.SIGNATURES) == names
-    assert lib.lstep_abi_version() == nat.ABI_VERSION == 39
+    assert lib.lstep_abi_version() == nat.ABI_VERSION == 40
 
 
 def test_abi_argument_validation_without_gpu(lib):
@@ -160,6 +160,50 @@ def test_native_rng_replay_equals_the_numpy_loop(monkeypatch, strategy, tsf, see
             for x, y in zip(*res):
                 np.testing.assert_array_equal(x, y)
             assert after[0] == after[1], "the generator state diverged"
+
+
+@pytest.mark.parametrize("strategy,tsf", [("uniform", 0.0), ("time_interval_aware", 1e-3)])
+def test_native_row_sort_equals_numpy_argsort_per_row(monkeypatch, strategy, tsf):
+    """``lstep_sample_random_sorted_host`` (round 5: draws on one thread, positions sorted and triples gathered on worker threads; only rows
+    holding a float32-time tie among DISTINCT interactions are left to numpy) against round 4's path (native draws, numpy's 1-D argsort on
+    every row: LSTEP_RNG_NUMPY_SORT=1): identical arrays and generator state -- short histories (counting sort), histories far longer than K
+    (std::sort), quantised timestamps (ties: the flagged rows), one worker and several, and the fill-in-place form the model uses
+    (``sample_random_into`` on a dirty buffer: rows without history come back zeroed)."""
+    from lstep_amd.sampler import NeighborSampler
+    graphs = (dict(num_nodes=50, num_edges=3000, seed=3), dict(num_nodes=3, num_edges=30000, seed=5),
+              dict(num_nodes=30, num_edges=20000, seed=4, time_span=500.0, tie_quantum=5.0))
+    for gi, gkw in enumerate(graphs):
+        g = synth.make_temporal_graph(**gkw)
+        mk = lambda: NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], sample_neighbor_strategy=strategy, time_scaling_factor=tsf, seed=9,  # noqa: E731
+                                     device="cpu")
+        smp = {"numpy": mk(), "one": mk(), "many": mk(), "into": mk()}
+        rng = np.random.RandomState(2)
+        flagged = 0
+        for K in (1, 7, 64, 700):
+            n = 150 if K < 700 else 40
+            ids = rng.randint(0, g["num_nodes"] + 1, n)
+            ts = rng.uniform(g["ts"].min() - 1, g["ts"].max() + 1, n)
+            res = {}
+            for name, s in smp.items():
+                monkeypatch.setenv("LSTEP_RNG_NUMPY_SORT", "1" if name == "numpy" else "0")
+                monkeypatch.setenv("LSTEP_HOST_THREADS", "1" if name == "one" else "5")
+                if name == "into":
+                    out = (np.full((n, K), -7, np.int64), np.full((n, K), -7, np.int64), np.full((n, K), np.nan, np.float32))
+                    assert all(a is b for a, b in zip(s.sample_random_into(ids, ts, K, out), out))
+                    res[name] = out
+                else:
+                    res[name] = s.get_historical_neighbors(ids, ts, K)
+            flagged += smp["many"].last_numpy_sorted_rows
+            for name in ("one", "many", "into"):
+                for x, y in zip(res["numpy"], res[name]):
+                    np.testing.assert_array_equal(x, y, err_msg=f"{name} K={K} graph {gi}")
+                np.testing.assert_array_equal(res["numpy"][2].view(np.uint32), res[name][2].view(np.uint32))
+        states = {name: s.random_state.randint(0, 1 << 30) for name, s in smp.items()}
+        assert len(set(states.values())) == 1, states
+        if "tie_quantum" in gkw:
+            assert flagged > 0, "the quantised timestamps must have produced rows with ties (left to numpy)"
+        elif gi == 0:
+            assert flagged < 100, "only the rows that drew both ends of a self-loop (one interaction listed twice) hold a tie"
 
 
 def test_missing_library_fails_loudly(tmp_path):
