@@ -39,7 +39,18 @@ struct GatherParams {
     const float* ex_nt_g;     // [batch, G]  (node branch with weighted_sum)
     int weighted_sum;         // models/LSTEP.py:190-206: node rows weighted by exp(-(t - neighbour time)), normalised over the row's distinct times
     const uint8_t* skip_node; // optional [batch]: rows whose node channel another kernel computes (hub nodes: csrc/hub.hip); long-row instantiation only
+    int rows_per_block;       // long-row instantiation: batch rows a workgroup owns (4 = one per wave; 1 or 2 for small batches, see coop_rows_per_block)
 };
+
+// Long-row instantiation, small batches: with one row per WAVE, 600 rows are 150 workgroups on 256 CUs and every workgroup walks four
+// 2000-slot node channels one after the other (73 -> 61 us at the Enron shape, round 4: latency-bound per CU).  With fewer rows per
+// workgroup the same four waves share ONE row's walk and the grid covers the chip; a wave without a row of its own only helps.  The split
+// of a long row over the waves (every fourth 64-slot chunk) and the order its partial sums are added in do not change: same bits.
+static int coop_rows_per_block(int64_t batch) {
+    static const int forced = [] { const char* e = getenv("LSTEP_GATHER_ROWS_PER_BLOCK"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return batch <= 1024 ? 1 : (batch <= 2048 ? 2 : kWavesPerBlock);
+}
 
 // zero the padding columns of one output row: [width, width rounded up to 16), clipped to the row stride.  A stride wider than that
 // (the row is a block of a concatenated operand, lstep_tail_fwd) leaves the rest of the row to its owner.
@@ -62,7 +73,8 @@ template <bool kEdgeNode, bool kPe, bool kExplicit = false, bool kCoop = false>
 __global__ __launch_bounds__(kBlock) void gather_aggregate_fwd_kernel(GatherParams p) {
     const int lane = lane_id();
     const int wv = wave_in_block();
-    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+    const int64_t row = !kCoop ? (int64_t)blockIdx.x * kWavesPerBlock + wv
+                               : (wv < p.rows_per_block ? (int64_t)blockIdx.x * p.rows_per_block + wv : p.batch);      // (p.batch: a helper wave)
     if constexpr (!kCoop) {
         if (row >= p.batch) return;
     }
@@ -575,11 +587,12 @@ static int gather_aggregate_fwd_impl(const lstep_csr_t* csr, const float* node_r
     if (int rc = check_ld("lstep_gather_aggregate_fwd", ld_edge, time_dim + feat_dim, ld_node, feat_dim, ld_pe, pe_dim + time_dim, ld_self, pe_dim)) return rc;
     GatherParams p{*csr, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
                    batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, out_count, ld_edge, ld_node, ld_pe, ld_self,
-                   nullptr, nullptr, nullptr, nullptr, nullptr, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0, skip_node};
-    const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+                   nullptr, nullptr, nullptr, nullptr, nullptr, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0, skip_node, kWavesPerBlock};
     hipStream_t s = (hipStream_t)stream;
     // long node-channel rows possible?  (max_degree 0 = unknown: assume yes)
     const bool coop = en && !(branches & LSTEP_WEIGHTED_SUM) && (csr->max_degree == 0 || csr->max_degree > kCoopMin) && time_gap > kCoopMin;
+    if (coop) p.rows_per_block = coop_rows_per_block(batch);
+    const dim3 grid((unsigned)((batch + p.rows_per_block - 1) / p.rows_per_block)), block(kBlock);
     if (skip_node && !coop) return set_error(LSTEP_EINVAL, "lstep_gather_aggregate_fwd_skip: skip_node needs the long-row form (max_degree and time_gap > 256, no weighted_sum)");
     if (en && pb) {
         if (coop) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, true, false, true>), grid, block, 0, s, p);
@@ -645,9 +658,11 @@ extern "C" int lstep_gather_explicit_fwd(const float* node_raw, const float* edg
     lstep_csr_t none{nullptr, nullptr, nullptr, nullptr, num_rows, 0, 0};   // (only num_rows is read: the bound of the self-row lookups)
     GatherParams p{none, node_raw, edge_raw, pe, feat_dim, pe_dim, time_dim, time_w, time_b, edge_agg_w, node_ids, times,
                    batch, num_neighbors, time_gap, out_edge, out_node, out_pe, out_self, nullptr, ld_edge, ld_node, ld_pe, ld_self,
-                   nbr, eid, nt, nbr_gap, nt_gap, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0, nullptr};
-    const dim3 grid((unsigned)((batch + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
-    if (en && time_gap > kCoopMin && !(branches & LSTEP_WEIGHTED_SUM))
+                   nbr, eid, nt, nbr_gap, nt_gap, (branches & LSTEP_WEIGHTED_SUM) ? 1 : 0, nullptr, kWavesPerBlock};
+    const bool coop = en && time_gap > kCoopMin && !(branches & LSTEP_WEIGHTED_SUM);
+    if (coop) p.rows_per_block = coop_rows_per_block(batch);
+    const dim3 grid((unsigned)((batch + p.rows_per_block - 1) / p.rows_per_block)), block(kBlock);
+    if (coop)
         hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, true, true>), grid, block, 0, (hipStream_t)stream, p);
     else if (en) hipLaunchKernelGGL((gather_aggregate_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gather_aggregate_fwd_kernel<false, true, true>), grid, block, 0, (hipStream_t)stream, p);
