@@ -660,11 +660,12 @@ extern "C" int64_t lstep_linear_wgrad_workspace(int64_t m, int32_t n, int32_t k)
     return (need_a > need_b ? need_a : need_b) * (int64_t)sizeof(float);
 }
 
-extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t m, int32_t n, int32_t k, float* dw,
-                                  int32_t ld_dw, float* db, void* workspace, int64_t workspace_bytes, void* stream) {
+// the split-M partial products of one weight gradient into `workspace` (no reduction); the plan it ran with comes back in *plan
+static int wgrad_launch_partial(const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t m, int32_t n, int32_t k, int32_t ld_dw,
+                                void* workspace, int64_t workspace_bytes, void* stream, WgradPlan* plan) {
     if (m < 0 || n <= 0 || k <= 0 || ldy < n || ldx < k || ld_dw < k) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: bad sizes");
     if ((int64_t)n * k > ((int64_t)1 << 30)) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: weight matrix too large");
-    if (!dw || !workspace || (m > 0 && (!dy || !x))) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: NULL pointer");
+    if (!workspace || (m > 0 && (!dy || !x))) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: NULL pointer");
     if (workspace_bytes < lstep_linear_wgrad_workspace(m, n, k)) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: workspace too small");
     if (((uintptr_t)workspace & 15) != 0) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
@@ -695,9 +696,18 @@ extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, 
     else if (pl.nt == 11) hipLaunchKernelGGL((wgrad_partial_kernel<11, 3, 4>), grid, block, 0, s, p);
     else if (pl.ktw == 5) hipLaunchKernelGGL((wgrad_partial_kernel<9, 5, 4>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((wgrad_partial_kernel<9, 3, 4>), grid, block, 0, s, p);
+    *plan = pl;
+    return LSTEP_OK;
+}
+
+extern "C" int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx, int64_t m, int32_t n, int32_t k, float* dw,
+                                  int32_t ld_dw, float* db, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!dw) return set_error(LSTEP_EINVAL, "lstep_linear_wgrad: NULL pointer");
+    WgradPlan pl;
+    if (int rc = wgrad_launch_partial(dy, ldy, x, ldx, m, n, k, ld_dw, workspace, workspace_bytes, stream, &pl)) return rc;
     const unsigned rgrid = (unsigned)((pl.part_stride / 4 + 15) / 16);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), block, 0, s, (const float*)workspace, pl.part_stride, (int32_t)pl.splits, n, k,
-                       pl.bias_off, dw, ld_dw, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(kBlock), 0, (hipStream_t)stream, (const float*)workspace, pl.part_stride,
+                       (int32_t)pl.splits, n, k, pl.bias_off, dw, ld_dw, db);
     return check_launch("lstep_linear_wgrad");
 }
 
@@ -719,6 +729,7 @@ extern "C" int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t*
     hipStream_t s = (hipStream_t)stream;
     static const bool no_wide = getenv("LSTEP_WGRAD_DWORD") != nullptr;
     static const bool no_batch = getenv("LSTEP_WGRAD_NO_BATCH") != nullptr;      // A/B switch: one (partial, reduce) launch pair per product
+    static const bool reduce_each = no_batch || getenv("LSTEP_WGRAD_REDUCE_EACH") != nullptr;
     // Products of more than this many rows keep their own launch pairs: one launch of all six 49 152-row products puts 6 144 waves of
     // 240 registers on the chip at once, two per SIMD, for ~0.5 ms -- alone that is 5 % faster than six launches, but under it the step's
     // other kernels (update_rows, gather backward) run at half speed and the c4 step does not gain (3.18 vs 3.15 ms; under the kernel
@@ -741,8 +752,22 @@ extern "C" int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t*
         const bool wide = !no_wide && d.n % 4 == 0 && d.k % 4 == 0 && d.n >= 4 && d.k >= 4 && d.ldy % 4 == 0 && d.ldx % 4 == 0 &&
                           ((uintptr_t)d.dy & 15) == 0 && ((uintptr_t)d.x & 15) == 0;
         const WgradPlan pl = wgrad_plan(d.m, d.n, d.k, wide);
-        if (no_batch || !pl.small || d.m == 0 || d.m > batch_rows) {      // plans the batched kernel does not cover: their own launches, same stream, same result
-            if (int rc = lstep_linear_wgrad(d.dy, d.ldy, d.x, d.ldx, d.m, d.n, d.k, d.dw, d.ld_dw, d.db, ws, bytes, stream)) return rc;
+        if (no_batch || !pl.small || d.m == 0 || d.m > batch_rows) {      // plans the batched kernel does not cover: their own partial launches, same stream, same result
+            // round 5: their REDUCTIONS wait for the end of the call and go out as one launch (each product has its own slice of the
+            // workspace): on the auxiliary stream the five 49 152-row products of a c4 step ran partial -> reduce -> partial -> ..., and that
+            // chain is the longest dependent chain of the whole step (tools/graph_critical_path.py) -- 5 x 34 us of reductions that nothing
+            // in front of the optimiser needs early.  LSTEP_WGRAD_REDUCE_EACH=1: a reduction behind every product, as before.
+            if (reduce_each || rb.count >= kWgradReduceBatchMax) {
+                if (int rc = lstep_linear_wgrad(d.dy, d.ldy, d.x, d.ldx, d.m, d.n, d.k, d.dw, d.ld_dw, d.db, ws, bytes, stream)) return rc;
+            } else {
+                WgradPlan ran;
+                if (int rc = wgrad_launch_partial(d.dy, d.ldy, d.x, d.ldx, d.m, d.n, d.k, d.ld_dw, ws, bytes, stream, &ran)) return rc;
+                WgradReduceItem& r = rb.it[rb.count];
+                r.part = (const float*)ws; r.dw = d.dw; r.db = d.db; r.part_stride = ran.part_stride;
+                r.num_part = ran.splits; r.n = d.n; r.k = d.k; r.bias_off = ran.bias_off; r.ld_dw = d.ld_dw;
+                rb.first_block[rb.count + 1] = rb.first_block[rb.count] + (int32_t)((ran.part_stride / 4 + 15) / 16);
+                ++rb.count;
+            }
         } else {
             WgradParams& p = pb.p[pb.count];
             p.dy = d.dy; p.x = d.x; p.part = (float*)ws;
@@ -762,8 +787,8 @@ extern "C" int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t*
     if (pb.count > 0) {
         const unsigned waves = (unsigned)pb.first_wave[pb.count];
         hipLaunchKernelGGL(wgrad_partial_v2_batch_kernel, dim3((waves + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, pb);
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)rb.first_block[rb.count]), dim3(kBlock), 0, s, rb);
     }
+    if (rb.count > 0) hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)rb.first_block[rb.count]), dim3(kBlock), 0, s, rb);
     return check_launch("lstep_linear_wgrad_batch");
 }
 
