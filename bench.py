@@ -667,7 +667,11 @@ def main():
         if hub is not None and args.sampler == "recent":
             # (csrc/hub.hip) rows whose node channel came from prefix differences over the union of their node's windows: the launch then
             # reads far fewer node rows than SURVEY 8(d)'s per-row count prices (`achieved` / `frac` keep that algorithmic count)
-            line["roofline"]["hub_rows"] = {"rows_served": int(hub[0].sum().item()), "work_items": int(hub[1].item()),
+            served_rows = int(hub[0].sum().item())
+            if served_rows and line["roofline"]["bound_note"]:
+                line["roofline"]["bound_note"] += (f"; AND {served_rows} of the launch's rows take their node channel from the hub kernels' pass over the union "
+                                                   "of their windows, so most of the priced bytes are not moved at all (hub_rows)")
+            line["roofline"]["hub_rows"] = {"rows_served": served_rows, "work_items": int(hub[1].item()),
                                             "rows_per_launch": int(hub[0].numel()),
                                             "note": "node channel of batch rows whose node occurs >= 4 times in the batch: one pass over the union of "
                                                     "their windows (lstep_hub_node_sums) instead of time_gap row reads each; launch_ms covers the "

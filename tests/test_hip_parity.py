@@ -2163,6 +2163,12 @@ def poisoned(node_ids, times, k):
     n = n.copy(); n[0, -1] = N + 1000                             # a neighbour id far past the node table
     return n, e, t
 sampler.get_historical_neighbors = poisoned
+real_into = sampler.sample_random_into
+def poisoned_into(node_ids, times, k, out):                       # (the model's own route: draws written into its pinned staging arrays)
+    res = real_into(node_ids, times, k, out)
+    out[0][0, -1] = N + 1000
+    return res
+sampler.sample_random_into = poisoned_into
 with torch.no_grad():
     out = bb.aggregated_node_embeddings(ids, ts, K, 8)
 torch.cuda.synchronize()
