@@ -1,3 +1,6 @@
+#!/bin/bash
+# The round's final evidence on one box: profile capture (tools/capture_profiles.sh), the line as the driver runs it, the plain lines, the Zipf profile.
+# usage (through gpurun): bash tools/final_round_set.sh
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 bash $ROOT/tools/capture_profiles.sh r05_g > $ROOT/gpurun_out/r05_g_capture.log 2>&1
