@@ -29,7 +29,13 @@ struct WgradParams {
     int32_t k_blocks;      // v2 kernels: wave task t of a row slice owns n-block t / k_blocks and k-block t % k_blocks (0: the (y, z) grid mapping)
     int32_t tasks;         // with k_blocks: wave-tasks per row slice; waves are numbered over (slice, task) so that no SIMD slot idles
     int32_t slices;
+    int32_t no_fast;       // 0 with LSTEP_WGRAD_FAST=1: whole steps take the clamp-free path of wgrad_partial_v2_body (off by default, see there)
 };
+
+static int32_t wgrad_no_fast() {
+    static const int32_t v = getenv("LSTEP_WGRAD_FAST") != nullptr ? 0 : 1;
+    return v;
+}
 
 // One workgroup = 4 waves; wave w owns k-tiles [(blockIdx.y * 4 + w) * KTW, +KTW) x n-tiles [blockIdx.z * NT, +NT).
 // DEPTH row-steps (4 rows each) of operands are in flight per wave: one step is NT * KTW MFMAs = 32 * NT * KTW cycles, a load
@@ -190,6 +196,36 @@ __device__ __forceinline__ void wgrad_partial_v2_body(const WgradParams& p, int 
         for (int t = 0; t < KR; ++t) o.b1[t] = rb[colB1[t]];
     };
 
+    // Steps whose four rows all exist (everything but the end of the wave's slice) need no clamp and no dead-row select, and their
+    // addresses are a wave-uniform row base (scalar unit) plus a per-lane element offset that never changes: round 5 -- the per-load
+    // 64-bit row products, clamps and selects were ~250 vector-ALU instructions (60 of them quarter-rate multiplies) per 240 MFMAs, and
+    // a single resident wave does not hide them behind its own matrix instructions.  ALONE the products gain 6-8 % (76 -> 71, 104 -> 96,
+    // 85 -> 79, 134 -> 123 us: profiles/r05_wgrad_fast_path_ab.txt); INSIDE the training step, where the products share the chip with
+    // update_rows and the backward pass's HBM chain on other queues, the denser matrix-instruction stream makes the step SLOWER
+    // (3.13-3.16 vs 3.07-3.10 ms at c4) -- so the path is opt-in (LSTEP_WGRAD_FAST=1) and the default stays the clamped loop.
+    unsigned offA4[NG > 0 ? NG : 1], offA1[NR > 0 ? NR : 1], offB4[KG > 0 ? KG : 1], offB1[KR > 0 ? KR : 1];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) offA4[g] = (unsigned)(kk * p.ldy + colA4[g]);
+#pragma unroll
+    for (int t = 0; t < NR; ++t) offA1[t] = (unsigned)(kk * p.ldy + colA1[t]);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) offB4[g] = (unsigned)(kk * p.ldx + colB4[g]);
+#pragma unroll
+    for (int t = 0; t < KR; ++t) offB1[t] = (unsigned)(kk * p.ldx + colB1[t]);
+    const int64_t full_steps = p.no_fast ? 0 : (r_end - r_begin) >> 2;
+    auto issue_full = [&](Operands& o, int64_t step) {
+        const float* sa = p.dy + (r_begin + 4 * step) * (int64_t)p.ldy;      // wave-uniform
+        const float* sb = p.x + (r_begin + 4 * step) * (int64_t)p.ldx;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) o.a4[g] = *reinterpret_cast<const f32x4*>(sa + offA4[g]);
+#pragma unroll
+        for (int t = 0; t < NR; ++t) o.a1[t] = sa[offA1[t]];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) o.b4[g] = *reinterpret_cast<const f32x4*>(sb + offB4[g]);
+#pragma unroll
+        for (int t = 0; t < KR; ++t) o.b1[t] = sb[offB1[t]];
+    };
+
     f32x4 acc[NT][KTW];
     f32x4 bsum4[NG > 0 ? NG : 1];
     float bsum1[NR > 0 ? NR : 1];
@@ -228,6 +264,28 @@ __device__ __forceinline__ void wgrad_partial_v2_body(const WgradParams& p, int 
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) issue(blk[d], r_begin + 4 * (s + d));
     };
+    auto issue_block_full = [&](Operands (&blk)[DEPTH], int64_t s) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue_full(blk[d], s + d);
+    };
+    auto multiply_block_full = [&](const Operands (&blk)[DEPTH]) {      // (every row of the block exists)
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const f32x4 va = blk[d].a4[g];
+                bsum4[g] += va;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) row_of_tiles(4 * g + v, va[v], blk[d]);
+            }
+#pragma unroll
+            for (int t = 0; t < NR; ++t) {
+                const float va = blk[d].a1[t];
+                bsum1[t] += va;
+                row_of_tiles(4 * NG + t, va, blk[d]);
+            }
+        }
+    };
     auto multiply_block = [&](const Operands (&blk)[DEPTH], int64_t s) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -249,7 +307,19 @@ __device__ __forceinline__ void wgrad_partial_v2_body(const WgradParams& p, int 
         }
     };
     issue_block(buf[0], 0);
-    for (int64_t s = 0; s < steps; s += 2 * DEPTH) {   // (rows past the slice are clamped loads and zero operands)
+    int64_t s = 0;
+    // trips whose three blocks -- the two multiplied here and the one requested for the next trip -- hold whole steps only
+    for (; s + 3 * DEPTH <= full_steps; s += 2 * DEPTH) {
+        issue_block_full(buf[1], s + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply_block_full(buf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_block_full(buf[0], s + 2 * DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply_block_full(buf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; s < steps; s += 2 * DEPTH) {   // the end of the slice (rows past it are clamped loads and zero operands)
         issue_block(buf[1], s + DEPTH);
         __builtin_amdgcn_sched_barrier(0);
         multiply_block(buf[0], s);
@@ -678,7 +748,7 @@ static int wgrad_launch_partial(const float* dy, int32_t ldy, const float* x, in
     p.dy = dy; p.x = x; p.part = (float*)workspace;
     p.m = m; p.rows_per_wg = pl.rows_per_wg; p.part_stride = pl.part_stride;
     p.ldy = ldy; p.ldx = ldx; p.n = n; p.k = k; p.bias_off = pl.bias_off; p.k_blocks = pl.k_blocks;
-    p.tasks = (pl.small || pl.lds) ? pl.tasks : 0; p.slices = pl.splits;
+    p.tasks = (pl.small || pl.lds) ? pl.tasks : 0; p.slices = pl.splits; p.no_fast = wgrad_no_fast();
     const dim3 grid((unsigned)pl.splits, (unsigned)pl.gy, (unsigned)pl.gz), block(kBlock);
     if (pl.lds) {
         const dim3 lgrid((unsigned)((int64_t)pl.splits * pl.tasks));
@@ -773,7 +843,7 @@ extern "C" int lstep_linear_wgrad_batch(int32_t count, const lstep_wgrad_desc_t*
             p.dy = d.dy; p.x = d.x; p.part = (float*)ws;
             p.m = d.m; p.rows_per_wg = pl.rows_per_wg; p.part_stride = pl.part_stride;
             p.ldy = d.ldy; p.ldx = d.ldx; p.n = d.n; p.k = d.k; p.bias_off = pl.bias_off; p.k_blocks = pl.k_blocks;
-            p.tasks = pl.tasks; p.slices = pl.splits;
+            p.tasks = pl.tasks; p.slices = pl.splits; p.no_fast = wgrad_no_fast();
             pb.first_wave[pb.count + 1] = pb.first_wave[pb.count] + pl.splits * pl.tasks;
             ++pb.count;
             WgradReduceItem& r = rb.it[rb.count];
