@@ -320,8 +320,9 @@ int lstep_linear_wgrad(const float* dy, int32_t ldy, const float* x, int32_t ldx
 /* The same for several layers at once: ONE partial launch and ONE reduction launch for up to 8 products (the four of the dense tail, the
  * two of the link predictor: models/LSTEP.py:56-72, models/modules.py:52-68), instead of a dependent launch pair per product.  Results are
  * those of lstep_linear_wgrad product by product (same tiling, same summation order); products whose operands do not allow the 16-byte
- * loads of the batched kernel are launched on their own inside the call.  workspace: lstep_linear_wgrad_batch_workspace(count, descs)
- * bytes, 16-byte aligned. */
+ * loads of the batched kernel, or that are too large for it (more than 16 384 rows), keep a partial launch of their own inside the call;
+ * their reductions leave together as ONE launch at the end of the call (round 5: every product has its own slice of the workspace, and
+ * nothing needs a single product's result earlier).  workspace: lstep_linear_wgrad_batch_workspace(count, descs) bytes, 16-byte aligned. */
 typedef struct lstep_wgrad_desc {
     const float* dy;   /* [m, n], row stride ldy */
     const float* x;    /* [m, k], row stride ldx */
