@@ -1267,8 +1267,8 @@ class LSTEP(nn.Module):
                  use_dropout=False, dropout: float = 0.1, weighted_sum=False, concat_pe=True, device: str = "cuda"):
         super().__init__()
         nat.load_library()  # fail loudly: no HIP library, no model
-        if use_dropout:
-            raise NotImplementedError("use_dropout=True is never set by the reference drivers (SURVEY.md appendix A.8)")
+        # (use_dropout=True -- never set by the reference drivers, SURVEY.md appendix A.8 -- is served by plain framework tails behind the
+        # same gather kernels: a dropout between edge_mlp_2 and node_mlp breaks the pre-multiplied tail; models/LSTEP.py:171-172)
         edge_feat_dim = edge_raw_features.shape[-1]
         node_feat_dim = node_raw_features.shape[-1]
         if edge_feat_dim != node_feat_dim:
@@ -1449,6 +1449,8 @@ class LSTEP(nn.Module):
         a = self.edge_agg.weight.reshape(-1)
         h = F.linear(x_edge, self.edge_mlp_1.weight) + (a.sum() * self.edge_mlp_1.bias + self.edge_agg.bias)
         h = self.edge_mlp_2(torch.relu(h))
+        if self.use_dropout:
+            h = F.dropout(h, p=self.dropout)      # (the functional form with its default training=True, as models/LSTEP.py:171-172 calls it)
         return self.node_mlp(torch.cat([x_node, h], dim=-1))
 
     def _pe_tail(self, x_pe, own):
@@ -1475,6 +1477,13 @@ class LSTEP(nn.Module):
         x_edge, x_node, x_pe, own, _ = self._gather(pe, node_ids, node_interact_times, num_neighbors, time_gap,
                                                     nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, spliced, wide=fused, row_blocks=row_blocks,
                                                     row_groups=row_groups)
+        if self.use_dropout:
+            # the dropout of models/LSTEP.py:171-172 sits between edge_mlp_2 and node_mlp, inside the stretch the fused tail pre-multiplies:
+            # the layers one by one (framework GEMMs) behind the same fused gather launch
+            emb = self._edge_node_tail(x_edge[:, :self.time_dim + self.feat_dim], x_node[:, :self.feat_dim])
+            q = self._pe_tail(x_pe[:, :self.pe_dim + self.time_dim], own[:, :self.pe_dim])
+            out = self.out_node_emb(torch.cat([emb, q], dim=-1))
+            return F.pad(out, (0, self.ld_node - self.feat_dim)) if padded else out
         out = self._combined_tail(x_edge, x_node, x_pe, own, fused)
         # padded: the [B, 176] rows the kernels work on (columns >= 172 are 0), for lstep_head_fwd; default: the reference's [B, 172]
         return out if padded else out[:, :self.feat_dim]
@@ -1501,8 +1510,8 @@ class LSTEP(nn.Module):
 
     def _fused_tail_ok(self) -> bool:
         """The single-launch tail is compiled for the default widths (feature / PE dim 172, time dim 100); other shapes (and
-        LSTEP_TORCH_TAIL=1, the A/B switch) take the library-GEMM tail."""
-        return (os.environ.get("LSTEP_TORCH_TAIL", "0") != "1"
+        LSTEP_TORCH_TAIL=1, the A/B switch) take the library-GEMM tail.  Not with ``use_dropout``: see ``combining_pe_raw_feat``."""
+        return (os.environ.get("LSTEP_TORCH_TAIL", "0") != "1" and not self.use_dropout
                 and (self.ld_edge, self.ld_node, self.ld_pe, self.ld_self) == (272, 176, 272, 176))
 
     def _combined_tail(self, x_edge, x_node, x_pe, own, fused: bool = False):
@@ -1561,6 +1570,24 @@ class LSTEP(nn.Module):
         out = self.combining_pe_raw_feat(pe, ids, ts, num_neighbors, time_gap, spliced=spliced)
         return out[:n], out[n:]
 
+    def _fourier_transform_pe_dropout(self, node_ids, pe, batch_idx):
+        """``fourier_transform_pe(..., use_dropout=True)`` (models/LSTEP.py:131-133; no reference driver passes it): dropout on the filtered
+        history and the history itself added back as a residual -- neither is linear in the filter, so the coefficient table does not
+        apply: the transform written out with ``torch.fft`` (the mask of the short-history case as in ``fft_coefficients``)."""
+        T, t_len = self.num_fft_batches, int(pe.shape[1])
+        if t_len > T:
+            raise RuntimeError(f"history holds {t_len} snapshots but num_fft_batches={T} (the reference's filter broadcast fails the same way)")
+        x = pe[self._ids(node_ids)].to(torch.float32)                                   # [U, t, P]
+        keep = None
+        if t_len < T:
+            x = F.pad(x, (0, 0, 0, T - t_len))
+            keep = (torch.arange(T, device=x.device) < batch_idx).to(torch.float32)[None, :, None]
+        masked = (lambda z: z * keep) if keep is not None else (lambda z: z)
+        spectrum = masked(torch.fft.fft(x.to(torch.complex64), dim=1))
+        filtered = masked(torch.fft.ifft(masked(self.fft_filter.weight.unsqueeze(0) * spectrum), dim=1)).real
+        y = self.fft_dropout(filtered) + x
+        return torch.einsum("utp,t->up", y, self.fft_agg.weight.reshape(-1))
+
     # ---- F (models/LSTEP.py:104-137)
     def fft_coefficients(self, t_len: int, batch_idx: int) -> torch.Tensor:
         """Real [T, P] table c with  fourier_transform_pe(x)[u, p] = sum_s c[s, p] * x[u, s, p].
@@ -1585,10 +1612,10 @@ class LSTEP(nn.Module):
 
     def fourier_transform_pe(self, node_ids, pe, batch_idx, use_dropout=False, use_mixer=False):
         """``pe`` is the PE history ``[N+1, t, P]`` (any strides with unit last stride); returns ``[U, P]``."""
-        if use_dropout:
-            raise NotImplementedError("use_dropout=True is never used by the reference drivers")
         if pe.dim() != 3 or pe.shape[2] != self.pe_dim:
             raise ValueError("pe history must be [N+1, t, P]")
+        if use_dropout:
+            return self._fourier_transform_pe_dropout(node_ids, pe, batch_idx)
         t_len = int(pe.shape[1])
         if t_len > self.num_fft_batches:
             raise RuntimeError(f"history holds {t_len} snapshots but num_fft_batches={self.num_fft_batches} "

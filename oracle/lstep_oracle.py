@@ -133,9 +133,11 @@ class OracleLSTEP(nn.Module):
     """Same parameters (names, shapes, dtypes) and same method surface as reference ``models.LSTEP.LSTEP``."""
 
     def __init__(self, node_raw_features, edge_raw_features, neighbor_sampler, full_neighbor_sampler=None, pe_dim=172,
-                 num_neighbors=20, time_feat_dim=100, num_fft_batches=100, device="cpu", weighted_sum=False):
+                 num_neighbors=20, time_feat_dim=100, num_fft_batches=100, device="cpu", weighted_sum=False, use_dropout=False, dropout=0.1):
         super().__init__()
         self.weighted_sum = weighted_sum      # the `weighted_sum` ablation (models/LSTEP.py:74,190-206; train_LSTEP_link_prediction.py:126)
+        self.use_dropout, self.dropout = use_dropout, dropout      # models/LSTEP.py:40-41 (no reference driver sets use_dropout)
+        self.fft_dropout = nn.Dropout(p=dropout)                   # models/LSTEP.py:55
         f_edge = edge_raw_features.shape[-1]
         f_node = node_raw_features.shape[-1]
         self.num_fft_batches = num_fft_batches
@@ -194,6 +196,8 @@ class OracleLSTEP(nn.Module):
         if mask is not None:
             z = z * mask
         y = z.real.to(torch.float32)  # float32; imaginary part dropped (:129)
+        if use_dropout:               # (:131-133: dropout on the filtered window, the (padded) window itself added back)
+            y = self.fft_dropout(y) + x
         # (the widening is a no-op in the fp32 model; ``float64_yardstick`` keeps the reference's explicit complex64 / float32 casts)
         return self.fft_agg(y.permute(0, 2, 1).to(self.fft_agg.weight.dtype)).squeeze()
 
@@ -208,6 +212,8 @@ class OracleLSTEP(nn.Module):
         x = self.edge_mlp_1(x)
         x = self.edge_agg(x.permute(0, 2, 1)).squeeze()                                           # Linear over the K axis
         x = self.edge_mlp_2(torch.relu(x))
+        if self.use_dropout:          # (:171-172: the FUNCTIONAL dropout, i.e. active whatever the module's mode)
+            x = torch.nn.functional.dropout(x, p=self.dropout)
 
         nbr_g, _, nts_g = self.neighbor_sampler.get_historical_neighbors(node_ids, node_interact_times, time_gap)
         node_rows = self.node_raw_features[self._idx(nbr_g)]                                      # [B, G, F] dense
@@ -291,10 +297,10 @@ def scatter_mean_restated(src: torch.Tensor, index: torch.Tensor, size: int) -> 
 
 
 def build_oracle_model(node_raw, edge_raw, sampler, num_neighbors, num_fft_batches, state_dict=None, feat_dim=172,
-                       time_dim=100, pe_dim=172, weighted_sum=False):
+                       time_dim=100, pe_dim=172, weighted_sum=False, use_dropout=False, dropout=0.1):
     """``nn.Sequential(backbone, link_predictor)`` as the reference wraps it (train_LSTEP_link_prediction.py:140-142)."""
     bb = OracleLSTEP(node_raw, edge_raw, sampler, sampler, pe_dim=pe_dim, num_neighbors=num_neighbors,
-                     time_feat_dim=time_dim, num_fft_batches=num_fft_batches, weighted_sum=weighted_sum)
+                     time_feat_dim=time_dim, num_fft_batches=num_fft_batches, weighted_sum=weighted_sum, use_dropout=use_dropout, dropout=dropout)
     pred = OracleMergeLayer(feat_dim, feat_dim, feat_dim, 1)
     model = nn.Sequential(bb, pred)
     if state_dict is not None:

@@ -660,9 +660,49 @@ def gen_init_pe():
     print("init_pe.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------------------------- use_dropout (models/LSTEP.py:131-133,171-172)
+def gen_dropout():
+    """`use_dropout=True` -- never set by the reference's drivers, pinned where it is deterministic: (1) the model flag with p = 0 (the
+    functional dropout of models/LSTEP.py:171-172 is then the identity: the plain, un-premultiplied tail), (2) fourier_transform_pe's
+    `use_dropout=True` argument in eval mode (nn.Dropout is the identity there; what remains is the residual `batch_pe += init_pe` of
+    models/LSTEP.py:131-133), full and short history."""
+    from utils.utils import get_neighbor_sampler as ref_get
+    g = synth.make_temporal_graph(**WS_GRAPH)
+    node_raw, edge_raw = synth.make_features(g["num_nodes"], len(g["eid"]), seed=91)
+    pe0 = synth.make_initial_pe(g["num_nodes"], seed=92)
+    pe0[0] = 0.03
+    data = Data(g["src"], g["dst"], g["ts"], g["eid"], np.zeros(len(g["src"])))
+    K, T = 5, 4
+    sl = slice(900, 924)
+    src, dst, t = g["src"][sl], g["dst"][sl], g["ts"][sl]
+    sampler = ref_get(data, sample_neighbor_strategy="recent", seed=None)
+    torch.manual_seed(0)
+    bb = LSTEP(node_raw_features=node_raw, edge_raw_features=edge_raw, neighbor_sampler=sampler, full_neighbor_sampler=sampler,
+               pe_dim=synth.PE_DIM, num_neighbors=K, time_feat_dim=synth.TIME_DIM, num_fft_batches=T, use_dropout=True, dropout=0.0, device="cpu")
+    model = torch.nn.Sequential(bb, MergeLayer(input_dim1=synth.FEAT_DIM, input_dim2=synth.FEAT_DIM, hidden_dim=synth.FEAT_DIM, output_dim=1))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(K, T, seed=3).items()}, strict=True)
+    out = {}
+    with torch.no_grad():
+        for G in (6, 2000):
+            out[f"p0/agg_G{G}"] = bb.aggregated_node_embeddings(src, t, K, G).numpy()
+            out[f"p0/out_G{G}"] = bb.combining_pe_raw_feat(torch.from_numpy(pe0.copy()), dst, t, K, G).numpy()
+    model.eval()
+    rng = np.random.RandomState(94)
+    ids = np.unique(np.concatenate([src, dst]))
+    out["fft/ids"] = ids
+    for name, t_len, batch_idx in (("full", T, T + 3), ("short", 2, 2), ("short_idx1", 3, 1)):
+        hist = rng.standard_normal((g["num_nodes"] + 1, t_len, synth.PE_DIM)).astype(np.float32) * 0.1
+        out[f"fft/{name}/hist"] = hist
+        with torch.no_grad():
+            out[f"fft/{name}/out"] = bb.fourier_transform_pe(ids, torch.from_numpy(hist), batch_idx, use_dropout=True).numpy()
+            out[f"fft/{name}/out_plain"] = bb.fourier_transform_pe(ids, torch.from_numpy(hist), batch_idx).numpy()
+    np.savez_compressed(os.path.join(HERE, "dropout.npz"), **out)
+    print("dropout.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop", "variants", "traces_long", "float64", "init_pe"]
+    which = sys.argv[1:] or ["sampler", "time", "methods", "traces", "loader", "random_sampling", "eval_loop", "variants", "traces_long", "float64", "init_pe", "dropout"]
     if "sampler" in which:
         gen_sampler()
     if "time" in which:
@@ -685,3 +725,5 @@ if __name__ == "__main__":
         gen_float64()
     if "init_pe" in which:
         gen_init_pe()
+    if "dropout" in which:
+        gen_dropout()

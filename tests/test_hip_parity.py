@@ -1984,6 +1984,66 @@ def test_weighted_sum_ablation_golden(hip, golden):
             np.testing.assert_allclose(bb.combining_pe_raw_feat(pe, dst, t, WS_K, G).cpu().numpy(), z[f"ws/out_G{G}"], **TOL)
 
 
+def test_use_dropout_golden(hip, golden, monkeypatch):
+    """`use_dropout=True` (models/LSTEP.py:131-133,171-172; no reference driver sets it): the dropout between edge_mlp_2 and node_mlp sits
+    inside the stretch the fused tail pre-multiplies, so the flag routes combining_pe_raw_feat through the layers one by one behind the same
+    gather kernels.  Pinned against the reference where that is deterministic -- p = 0 (the functional dropout is the identity) and
+    fourier_transform_pe(use_dropout=True) in eval mode (what remains is the history added back as a residual), full and short windows --
+    and, for p > 0, checked for what dropout must do: the functional form (training=True whatever the module's mode) with the model's p, a
+    different draw per call, the same draw under the same generator seed."""
+    import lstep_amd.model as lm
+    from lstep_amd.model import LSTEP, MergeLayer
+    z = golden("dropout")
+    g, node_raw, edge_raw, pe0, (src, dst, t, eid) = variant_inputs()
+    s = hip_sampler(hip, g)
+
+    def build(p):
+        bb = LSTEP(node_raw, edge_raw, s, s, pe_dim=172, num_neighbors=WS_K, time_feat_dim=100, num_fft_batches=WS_T, use_dropout=True, dropout=p,
+                   device=DEV)
+        model = torch.nn.Sequential(bb, MergeLayer(172, 172, 172, 1).to(DEV))
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(WS_K, WS_T).items()}, strict=True)
+        return model
+
+    model = build(0.0)
+    bb = model[0]
+    assert not bb._fused_tail_ok()
+    pe = torch.from_numpy(pe0.copy()).to(DEV)
+    with torch.no_grad():
+        for G in (6, 2000):
+            np.testing.assert_allclose(bb.aggregated_node_embeddings(src, t, WS_K, G).cpu().numpy(), z[f"p0/agg_G{G}"], **TOL)
+            np.testing.assert_allclose(bb.combining_pe_raw_feat(pe, dst, t, WS_K, G).cpu().numpy(), z[f"p0/out_G{G}"], **TOL)
+        padded = bb.combining_pe_raw_feat(pe, dst, t, WS_K, 6, padded=True)
+        assert padded.shape[1] == bb.ld_node and float(padded[:, 172:].abs().max()) == 0.0
+    model.eval()
+    ids = z["fft/ids"]
+    with torch.no_grad():
+        for name, batch_idx in (("full", WS_T + 3), ("short", 2), ("short_idx1", 1)):
+            hist = torch.from_numpy(z[f"fft/{name}/hist"]).to(DEV)
+            np.testing.assert_allclose(bb.fourier_transform_pe(ids, hist, batch_idx, use_dropout=True).cpu().numpy(), z[f"fft/{name}/out"], **TOL)
+            np.testing.assert_allclose(bb.fourier_transform_pe(ids, hist, batch_idx).cpu().numpy(), z[f"fft/{name}/out_plain"], **TOL)
+    # p > 0
+    model = build(0.5)
+    bb = model[0]
+    model.eval()                                                           # (the functional dropout of :171-172 ignores the mode)
+    calls = []
+    real = lm.F.dropout
+    monkeypatch.setattr(lm.F, "dropout", lambda x, p=0.5, training=True, inplace=False: (calls.append((p, training)), real(x, p, training, inplace))[1])
+    with torch.no_grad():
+        torch.manual_seed(11)
+        a = bb.combining_pe_raw_feat(pe, dst, t, WS_K, 6)
+        b = bb.combining_pe_raw_feat(pe, dst, t, WS_K, 6)
+        torch.manual_seed(11)
+        c = bb.combining_pe_raw_feat(pe, dst, t, WS_K, 6)
+    assert calls == [(0.5, True)] * 3
+    assert torch.equal(a, c) and not torch.equal(a, b)
+    assert float((a.cpu() - torch.from_numpy(z["p0/out_G6"])).abs().max()) > 1e-3
+    # and it trains: a gradient reaches edge_mlp_2 through the mask
+    model.train()
+    out = bb.combining_pe_raw_feat(pe, dst, t, WS_K, 6)
+    out.square().mean().backward()
+    assert bb.edge_mlp_2.weight.grad is not None and bool(torch.isfinite(bb.edge_mlp_2.weight.grad).all()) and float(bb.edge_mlp_2.weight.grad.abs().max()) > 0
+
+
 @pytest.mark.parametrize("ws", [False, True])
 @pytest.mark.parametrize("strategy,tsf", [("uniform", 0.0), ("time_interval_aware", 1e-2)])
 def test_rng_strategies_feed_the_fused_path_golden(hip, golden, strategy, tsf, ws):
