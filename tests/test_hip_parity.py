@@ -1192,6 +1192,44 @@ def test_engine_lookahead_and_streams_do_not_change_results(hip, monkeypatch):
     assert float(d.max()) <= 5e-3 and float((d > 5e-5).float().mean()) <= 1e-3
 
 
+def test_engine_trains_with_use_dropout(hip):
+    """The engine's training iteration with a `use_dropout=True` backbone (the layer-by-layer tail behind the fused gather; launch by launch
+    and as a replayed graph): with p = 0 it follows the fused-tail engine step by step (losses, PE table), with p = 0.3 it runs, stays
+    finite and gives other losses."""
+    from lstep_amd import synth
+    from lstep_amd.engine import EdgeStream, LstepEngine
+    from lstep_amd.model import LSTEP, MergeLayer
+    from lstep_amd.optim import FusedAdam
+    from lstep_amd.sampler import NeighborSampler
+    g = synth.make_temporal_graph(num_nodes=400, num_edges=8000, seed=9)
+    node_raw, edge_raw = synth.make_features(400, 8000, seed=9)
+    K, T, B = 20, 4, 256
+    out = {}
+    for tag, kw in (("fused", {}), ("p0", dict(use_dropout=True, dropout=0.0)), ("p03", dict(use_dropout=True, dropout=0.3))):
+        sampler = NeighborSampler(g["src"], g["dst"], g["eid"], g["ts"], num_nodes=400, device=DEV)
+        bb = LSTEP(node_raw, edge_raw, sampler, sampler, pe_dim=172, num_neighbors=K, time_feat_dim=100, num_fft_batches=T, device=DEV, **kw)
+        model = torch.nn.Sequential(bb, MergeLayer(172, 172, 172, 1).to(DEV))
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(K, T).items()}, strict=True)
+        model.train()
+        eng = LstepEngine(model[0], model[1], K, 2000)
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+        stream = EdgeStream.from_numpy(g["src"], g["dst"], g["ts"], g["eid"], DEV)
+        init = torch.from_numpy(synth.make_initial_pe(400, seed=9)).to(DEV)
+        torch.manual_seed(3)
+        losses = []
+        for b in range(8):                               # (T = 4: the window is full from batch 4 on, the later iterations are graph replays)
+            lo = 4000 + b * B
+            neg = torch.from_numpy(synth.make_negatives(400, B, seed=b)).to(DEV)
+            res = eng.train_iteration(opt, b, *stream.batch(lo, lo + B), neg, initial_pe=init)
+            if res is not None:
+                losses.append([res["loss"].item(), res["lp_loss"].item(), res["pe_loss"].item()])
+        out[tag] = (np.array(losses), eng.ring.last().clone())
+    np.testing.assert_allclose(out["p0"][0], out["fused"][0], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["p0"][1].cpu().numpy(), out["fused"][1].cpu().numpy(), rtol=0, atol=5e-5)
+    assert np.isfinite(out["p03"][0]).all() and bool(torch.isfinite(out["p03"][1]).all())
+    assert np.abs(out["p03"][0] - out["fused"][0]).max() > 1e-4
+
+
 @pytest.mark.parametrize("K", [20, 5])
 def test_native_weight_composition_matches_framework_ops(hip, monkeypatch, K):
     """``lstep_tail_weights_pack`` / ``_unpack`` (csrc/compose.hip: every non-product step of the dense tail's weight composition and of
