@@ -319,6 +319,33 @@ def current_stream():
     return C.c_void_p(_raw_stream())
 
 
+def quiesce_collectives(device=None):
+    """Call right before a graph capture that a stream which has carried launch-by-launch collectives will start or join.
+
+    torch's NCCL watchdog thread polls the END EVENT of every collective issued launch by launch until it has seen it complete (one sweep
+    of its list every ~100 ms).  A synchronous collective runs on the current stream, so its end event is recorded there -- on this
+    package's update / pull streams in the launch-by-launch iterations.  When such a stream starts or joins a capture before the watchdog's
+    next sweep, ``hipEventQuery`` on that event fails with hipErrorCapturedEvent ("operation not permitted on an event last recorded in a
+    capturing stream") although the record itself was not captured, and the watchdog takes the process down: the abort round 4 saw once in
+    ``bench.py`` and round 5 once in the RCCL golden-trace test, reproduced at will by ``tools/nccl_capture_after_eager_probe.py``
+    (scenario ``same``: dies; capture on a stream that never carried a collective, or a drained watchdog list: fine).  So: finish the
+    device's work and give the watchdog one sweep to drop the completed works -- a quarter of a second, once per capture."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        if dist.get_backend() != "nccl":
+            return
+    except Exception:  # noqa: BLE001  (a group without a default backend name: nothing to wait for)
+        return
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    time.sleep(float(os.environ.get("LSTEP_CAPTURE_QUIESCE_S", "0.25")))
+
+
 _ROLE_STREAMS = {}
 
 

@@ -566,7 +566,11 @@ class GraphedTrainStep:
         dot = os.environ.get("LSTEP_GRAPH_DOT")       # diagnostics: the captured graph's nodes and edges as a DOT file (tools/graph_dot_summary.py)
         if dot:
             graph.enable_debug_mode()
-        with _no_gc(), torch.cuda.graph(graph, stream=nat.role_stream(eng.device, "capture")):
+        # (a process that also runs collectives -- lstep_amd.parallel beside this engine, a caller's own -- has an NCCL watchdog thread
+        # polling their events: thread_local keeps its queries legal during the capture, the quiesce keeps it from polling an event whose
+        # stream is about to capture; both are free without a process group)
+        nat.quiesce_collectives(eng.device)
+        with _no_gc(), torch.cuda.graph(graph, stream=nat.role_stream(eng.device, "capture"), capture_error_mode="thread_local"):
             with eng.aux_streams():
                 self.out = eng._train_iteration(self.optimizer, batch_idx, self.src, self.dst, self.ts, self.eid, self.neg, None, None)
             main = torch.cuda.current_stream(eng.device)

@@ -45,6 +45,9 @@ from .engine import HistoryRing, LstepEngine, _LinkLoss, _backward_unit, _lookup
 from .model import SplicedRows
 
 
+quiesce_collectives = nat.quiesce_collectives      # (lives beside the stream helpers: the single-GPU engine's capture needs it too)
+
+
 class LstepCapacityError(RuntimeError):
     """A fixed-capacity block of the device-driven multi-GPU iteration was too small for the data (see ``DistributedLstep.check_capacity``)."""
 
@@ -1719,7 +1722,7 @@ class GraphedDistStep:
             self.pull_graph = None
         if self.pull_graph is None:
             src, dst, ts, _, neg = self.cur
-            torch.cuda.synchronize(dl.device)
+            quiesce_collectives(dl.device)      # (the pull stream joins this capture and may have carried launch-by-launch pulls)
             g = new_graph(self)
             with _no_gc(), torch.cuda.graph(g, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
                 p = dl._pull_now_dev((src, dst, neg), ts)
@@ -1735,7 +1738,7 @@ class GraphedDistStep:
         from .model import _aux_stream, _no_gc, new_graph
         dl = self.dl
         eng, ring = dl.eng, dl._ring
-        torch.cuda.synchronize(dl.device)
+        quiesce_collectives(dl.device)      # (the update / pull streams join this capture; the iterations before it put collectives on them)
         ring._advanced = [None, None]
         if ring.dev_start is None:
             ring.position_on_device()
@@ -1746,7 +1749,8 @@ class GraphedDistStep:
         # thread_local: the process group's watchdog thread polls the events of collectives issued launch by launch BEFORE the capture
         # (hipEventQuery); in the default "global" mode that call from another thread is an error that kills the capture
         # ("operation not permitted when stream is capturing" out of ProcessGroupNCCL's watchdog -- seen once the bench's eager iterations
-        # ran right in front of the capture).  The autograd thread's launches are captured in either mode.
+        # ran right in front of the capture).  The autograd thread's launches are captured in either mode.  (thread_local does NOT cover
+        # the watchdog querying an event whose STREAM is now capturing: quiesce_collectives above.)
         with _no_gc(), torch.cuda.graph(graph, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
             with eng.aux_streams():
                 self.out = dl._train_iteration_dev(self.optimizer, batch_idx, src, dst, ts, eid, neg, None, ahead)

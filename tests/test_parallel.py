@@ -339,6 +339,22 @@ def _long_worker(rank, world, port, q, backend, expect_replays):
 
 
 @pytest.mark.gpu
+def test_capture_right_behind_launch_by_launch_collectives_is_quiesced():
+    """The sporadic "watchdog thread terminated ... event last recorded in a capturing stream" abort (round 4 in bench.py, round 5 in the RCCL
+    golden-trace test): torch's NCCL watchdog polls the end event of a launch-by-launch collective until its next sweep (~100 ms); if the
+    stream the collective ran on starts or joins a capture before that, hipEventQuery fails and the process aborts.
+    tools/nccl_capture_after_eager_probe.py re-enacts it (scenario `same`); with ``parallel.quiesce_collectives`` in front of the capture
+    (scenario `lib`: what ``GraphedDistStep`` does before both of its captures) the same sequence must run through."""
+    import subprocess
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = dict(os.environ, PROBE_REPS="5", PROBE_PORT=str(_free_port()), PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_capture_after_eager_probe.py"), "--child", "lib"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("phase2", ["replicate", "pull", "auto+clean-probe"])
 def test_distributed_graph_replay_reproduces_long_golden_trace_rccl(monkeypatch, phase2):
     """the multi-GPU iteration is device-driven and replayed as ONE HIP graph with its RCCL collectives captured inside

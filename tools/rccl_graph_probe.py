@@ -23,6 +23,15 @@ import torch
 import torch.distributed as dist
 
 
+def quiesce():
+    """Before a capture: the device idle and one sweep of the NCCL watchdog over its list of launch-by-launch collectives (it polls their end
+    events; an event on a stream that has meanwhile started capturing makes hipEventQuery fail and the watchdog abort the process --
+    lstep_amd.parallel.quiesce_collectives, tools/nccl_capture_after_eager_probe.py)."""
+    import time
+    torch.cuda.synchronize()
+    time.sleep(0.25)
+
+
 def main() -> int:
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if os.environ.get("LSTEP_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
@@ -61,7 +70,7 @@ def main() -> int:
 
     # the collectives once launch by launch (communicator set-up), then captured
     body()
-    torch.cuda.synchronize()
+    quiesce()        # (`side` carried a collective and joins the capture: the watchdog's list must be empty by then)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         body()
@@ -130,7 +139,7 @@ def pull_pattern(rank: int, world: int, dev):
     second = dist.new_group(backend="nccl")
     for name, group in (("main communicator", None), ("second communicator", second)):
         body(group)                                   # once launch by launch (communicator set-up)
-        torch.cuda.synchronize()
+        quiesce()
         if not check():
             return False, f"wrong values launch by launch on the {name}"
         graph = torch.cuda.CUDAGraph()
