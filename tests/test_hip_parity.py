@@ -2285,6 +2285,48 @@ print("checked build:", what, idx, limit, count)
     assert "checked build:" in r.stdout
 
 
+def test_long_row_gather_does_not_depend_on_rows_per_workgroup(hip):
+    """Round 5: the long-row form of the gather forward gives a workgroup one batch row (up to 1024 rows), two (up to 2048) or four (beyond),
+    so that a small batch covers the chip; a long row's slots are split over the workgroup's four waves the same way in all three and the
+    partial sums added in the same order.  So a row's outputs must not depend on how many rows the launch holds: the first rows of a
+    2050-row launch (four per workgroup; its last workgroup is half empty) bit for bit against launches of 2048, 1025 (two; a helper-only
+    half workgroup at the end), 1024, 3 and 1 rows (one), on a graph whose rows are long (every wave helps) and short (own wave only)."""
+    from lstep_amd import _native as nat
+    lib = nat.load_library()
+    N, E, K, G = 300, 50000, 8, 2000
+    g = synth.make_temporal_graph(num_nodes=N, num_edges=E, seed=181, zipf=1.2)
+    node_raw, edge_raw = synth.make_features(N, E, seed=182)
+    sampler = hip_sampler(hip, g)
+    assert sampler.max_degree > 256
+    dev = torch.device(DEV)
+    rng = np.random.RandomState(183)
+    B = 2050
+    ids = torch.from_numpy(rng.randint(0, N + 1, B)).to(dev)
+    times = torch.from_numpy(np.sort(rng.uniform(g["ts"][100], g["ts"][-1] + 1.0, B))).to(dev)
+    F, D, LE, LN = 172, 100, 272, 176
+    node_t, edge_t = torch.from_numpy(node_raw).to(dev), torch.from_numpy(edge_raw).to(dev)
+    pe = torch.from_numpy(synth.make_initial_pe(N, seed=184)).to(dev)
+    tw = torch.from_numpy(1 / 10 ** np.linspace(0, 9, D, dtype=np.float32)).to(dev)
+    tb = torch.zeros(D, device=dev)
+    aw = torch.rand(K, device=dev)
+
+    def run(rows):
+        outs = [torch.full((rows, w), float("nan"), device=dev) for w in (LE, LN, LE, LN)]
+        cnt = torch.empty(rows, dtype=torch.int32, device=dev)
+        nat.check(lib.lstep_gather_aggregate_fwd(sampler.csr, nat.ptr(node_t), nat.ptr(edge_t), nat.ptr(pe), F, F, nat.ptr(tw), nat.ptr(tb), D, nat.ptr(aw),
+                                                 nat.ptr(ids), nat.ptr(times), rows, K, G, nat.BRANCH_EDGE_NODE | nat.BRANCH_PE, nat.ptr(outs[0]),
+                                                 nat.ptr(outs[1]), nat.ptr(outs[2]), nat.ptr(outs[3]), LE, LN, LE, LN, nat.ptr(cnt), nat.current_stream()))
+        torch.cuda.synchronize()
+        return outs + [cnt]
+
+    full = run(B)
+    assert all(bool(torch.isfinite(o).all()) for o in full[:4])
+    assert int((full[4] > 256).sum()) > 100 and int((full[4] <= 256).sum()) > 100, "long and short rows expected"
+    for rows in (2048, 1025, 1024, 3, 1):
+        for name, a, b in zip(("edge", "node", "pe", "self", "count"), run(rows), full):
+            assert torch.equal(a, b[:rows]), f"{rows} rows: output {name} differs from the same rows of the {B}-row launch"
+
+
 def test_hub_node_sums_vs_gather_kernel(hip):
     """Round 5: the node channel of batch rows whose node occurs >= 16 times in the batch from prefix differences over
     the union of their windows (csrc/hub.hip: lstep_hub_worklist / lstep_gather_aggregate_fwd_skip / lstep_hub_node_sums) against the gather
