@@ -1724,7 +1724,7 @@ class GraphedDistStep:
             src, dst, ts, _, neg = self.cur
             quiesce_collectives(dl.device)      # (the pull stream joins this capture and may have carried launch-by-launch pulls)
             g = new_graph(self)
-            with _no_gc(), torch.cuda.graph(g, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
+            with _no_gc(), self._capture_streams(), torch.cuda.graph(g, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
                 p = dl._pull_now_dev((src, dst, neg), ts)
                 p.wait()
                 self._pull_now_keep = p          # (its tensors are the graph's: request blocks, served rows, the largest per-owner count)
@@ -1733,6 +1733,22 @@ class GraphedDistStep:
         self.pull_now_replays += 1
         if self._pull_now_keep is not None and self._pull_now_keep.cnt_max is not None:
             dl._note_pull_counts(self._pull_now_keep.cnt_max)
+
+    @contextlib.contextmanager
+    def _capture_streams(self):
+        """For the duration of a capture the side branches that hold collectives -- update_pe's stream, the pull's -- run on streams of their
+        own that no launch-by-launch iteration ever uses.  ``quiesce_collectives`` already keeps the NCCL watchdog from polling an event whose
+        stream has started to capture (DESIGN.md section 10 iii); with the branches on capture-only streams there is no such event to poll,
+        however late the watchdog's sweep comes on a loaded host."""
+        dl = self.dl
+        saved = (dl.eng._update_stream, dl._pull_stream)
+        dl.eng._update_stream = nat.role_stream(dl.device, "update-captured")
+        if saved[1] is not None:
+            dl._pull_stream = nat.role_stream(dl.device, "pull-captured", priority=-1 if os.environ.get("LSTEP_PULL_PRIORITY", "1") == "1" else 0)
+        try:
+            yield
+        finally:
+            dl.eng._update_stream, dl._pull_stream = saved
 
     def _capture(self, batch_idx):
         from .model import _aux_stream, _no_gc, new_graph
@@ -1751,7 +1767,7 @@ class GraphedDistStep:
         # ("operation not permitted when stream is capturing" out of ProcessGroupNCCL's watchdog -- seen once the bench's eager iterations
         # ran right in front of the capture).  The autograd thread's launches are captured in either mode.  (thread_local does NOT cover
         # the watchdog querying an event whose STREAM is now capturing: quiesce_collectives above.)
-        with _no_gc(), torch.cuda.graph(graph, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
+        with _no_gc(), self._capture_streams(), torch.cuda.graph(graph, stream=nat.role_stream(dl.device, "capture"), capture_error_mode="thread_local"):
             with eng.aux_streams():
                 self.out = dl._train_iteration_dev(self.optimizer, batch_idx, src, dst, ts, eid, neg, None, ahead)
             main = torch.cuda.current_stream(dl.device)
